@@ -1,0 +1,128 @@
+"""ctypes binding of libdspgn.so (the C ABI in include/dsp_gn.h).
+
+No fallback: if the library is missing or a call fails this raises -- the product path never runs on
+the CPU oracle or on PyTorch ops.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+c_f32p = C.POINTER(C.c_float)
+c_i32p = C.POINTER(C.c_int32)
+c_i64p = C.POINTER(C.c_int64)
+
+CODE_LEN = 64
+GRAD_DIM = 67
+
+OBJ_GOOD, OBJ_FEW_SAMPLES, OBJ_NAN = 0, 1, 2
+
+
+class DecoderDesc(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("code_len", C.c_int32), ("latent_in", C.c_int32),
+                ("out_dims", c_i32p), ("in_dims", c_i32p),
+                ("weights", C.POINTER(c_f32p)), ("biases", C.POINTER(c_f32p))]
+
+
+class GnParams(C.Structure):
+    _fields_ = [("k1", C.c_float), ("k2", C.c_float), ("k3", C.c_float), ("k4", C.c_float),
+                ("b1", C.c_float), ("b2", C.c_float), ("lr", C.c_float), ("s_damp", C.c_float),
+                ("num_iterations", C.c_int32), ("num_depth_samples", C.c_int32), ("cut_off", C.c_float),
+                ("pose_only_iterations", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_fwd_points", C.c_double), ("n_jac_points", C.c_double), ("ms_total", C.c_double),
+                ("ms_mlp_fwd", C.c_double), ("ms_mlp_jac", C.c_double),
+                ("n_mlp_fwd_launches", C.c_int32), ("n_mlp_jac_launches", C.c_int32)]
+
+
+class DspError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# every symbol include/dsp_gn.h declares: (name, restype, argtypes)
+_VP = C.c_void_p
+SYMBOLS = [
+    ("dsp_abi_version", C.c_int, []),
+    ("dsp_create", C.c_int, [C.POINTER(DecoderDesc), C.c_int, C.POINTER(_VP)]),
+    ("dsp_destroy", None, [_VP]),
+    ("dsp_last_error", C.c_char_p, [_VP]),
+    ("dsp_decode_sdf", C.c_int, [_VP, c_f32p, c_f32p, C.c_int64, c_f32p]),
+    ("dsp_sdf_jacobian", C.c_int, [_VP, c_f32p, c_f32p, C.c_int64, c_f32p, c_f32p]),
+    ("dsp_compute_sdf_loss", C.c_int, [_VP, c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p]),
+    ("dsp_compute_render_loss", C.c_int, [_VP, c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_int32, c_f32p, C.c_float,
+                                          c_i64p, c_f32p, c_f32p, c_f32p, c_i64p, c_i64p]),
+    ("dsp_reconstruct_batch", C.c_int, [_VP, C.POINTER(GnParams), C.c_int32, c_i64p, c_f32p, c_i64p, c_f32p, c_i64p, c_f32p,
+                                        c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p]),
+    ("dsp_estimate_pose_batch", C.c_int, [_VP, C.POINTER(GnParams), C.c_int32, c_i64p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p]),
+    ("dsp_batch_create", C.c_int, [_VP, C.POINTER(GnParams), C.c_int32, c_i64p, c_f32p, c_i64p, c_f32p, c_i64p, c_f32p,
+                                   c_f32p, c_f32p, C.POINTER(_VP)]),
+    ("dsp_batch_run", C.c_int, [_VP]),
+    ("dsp_batch_results", C.c_int, [_VP, c_f32p, c_f32p, c_f32p, c_i32p]),
+    ("dsp_batch_stats", C.c_int, [_VP, C.POINTER(Stats)]),
+    ("dsp_batch_enable_trace", C.c_int, [_VP, C.c_int]),
+    ("dsp_batch_trace", C.c_int, [_VP, C.c_int32, c_f32p, c_f32p, c_f32p, c_i64p, c_i64p, c_i64p, c_f32p, c_f32p]),
+    ("dsp_batch_destroy", None, [_VP]),
+    ("dsp_debug_pack", C.c_int, [C.POINTER(DecoderDesc), c_f32p, c_i64p, c_f32p, c_i64p, c_i32p, c_i32p, c_f32p]),
+]
+
+
+def lib_path():
+    return os.environ.get("DSPGN_LIB", _build.LIB_PATH)
+
+
+def load():
+    """Load libdspgn.so (building it first if hipcc is available and the .so is missing or stale)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if path == _build.LIB_PATH and _build.is_stale():
+        try:
+            _build.build()
+        except Exception as e:  # stale-but-present is usable on a box without hipcc
+            if not os.path.exists(path):
+                raise DspError("libdspgn.so is not built and cannot be built here: %s" % e)
+    lib = C.CDLL(path)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)       # AttributeError => the .so does not match include/dsp_gn.h
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def ptr(a, typ=c_f32p):
+    return None if a is None else a.ctypes.data_as(typ)
+
+
+def check(rc, handle=None, what=""):
+    if rc != 0:
+        msg = load().dsp_last_error(handle)
+        raise DspError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+class DecoderDescHolder(object):
+    """Keeps the numpy arrays referenced by a DecoderDesc alive."""
+
+    def __init__(self, layers, latent_in, code_len):
+        self.w = [f32(w) for w, _ in layers]
+        self.b = [f32(b) for _, b in layers]
+        n = len(layers)
+        self.out_dims = (C.c_int32 * n)(*[w.shape[0] for w in self.w])
+        self.in_dims = (C.c_int32 * n)(*[w.shape[1] for w in self.w])
+        self.wp = (c_f32p * n)(*[ptr(w) for w in self.w])
+        self.bp = (c_f32p * n)(*[ptr(b) for b in self.b])
+        lat = [int(x) for x in latent_in]
+        self.desc = DecoderDesc(n, int(code_len), lat[0] if len(lat) == 1 else -1,
+                                C.cast(self.out_dims, c_i32p), C.cast(self.in_dims, c_i32p),
+                                C.cast(self.wp, C.POINTER(c_f32p)), C.cast(self.bp, C.POINTER(c_f32p)))

@@ -1,0 +1,730 @@
+// Host side of libdspgn: decoder packing, device memory, the per-iteration launch sequence and the C ABI
+// declared in include/dsp_gn.h.  No Python / PyTorch dependency.
+#include "dsp_gn.h"
+#include "dsp_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+using namespace dsp;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+#define HIP_TRY(expr)                                                                                       \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess) {                                                                             \
+            char buf_[512];                                                                                 \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            throw std::runtime_error(buf_);                                                                 \
+        }                                                                                                   \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    void alloc(size_t count) {
+        free();
+        if (count == 0) count = 1;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
+        n = count;
+    }
+    void ensure(size_t count) { if (count > n) alloc(count + count / 4); }
+    void free() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+    ~DevBuf() { free(); }
+};
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+}  // namespace
+
+struct dsp_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int n_cu = 256;
+    // packed decoder
+    DevBuf<float> wstream, bias_tab;
+    float b_last = 0.f;
+    int n_bias_rows = 0, n_fwd = 0, n_pass_all = 0, chunks_fwd = 0, chunks_all = 0;
+    PassDesc pass[MAX_PASSES];
+    // scratch of the single-shot decoder calls
+    DevBuf<float4> s_pts;
+    DevBuf<float> s_code, s_out;
+    DevBuf<int4> s_tiles;
+    DevBuf<int> s_ntiles;
+};
+
+// ------------------------------------------------------------------------------------------------
+// decoder packing: weights -> chunk stream in MFMA operand order (see mlp_kernel.hip / DESIGN.md)
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct NetView {
+    int n_layers, hidden, lat;
+    std::vector<int> out_dims, in_dims;
+    std::vector<const float*> w, b;
+    // forward layer k: slab row -> original weight column (or -1)
+    std::vector<int> colmap(int k) const {
+        std::vector<int> m(WIDTH, -1);
+        if (k == 0) {
+            for (int r = 0; r < CODE_LEN; ++r) m[r] = r;
+            m[64] = CODE_LEN; m[68] = CODE_LEN + 1; m[72] = CODE_LEN + 2;   // xyz on lane groups 0,1,2 of k-step 16
+        } else if (k == lat) {
+            const int p = WIDTH - IN_DIM;                                  // 445
+            for (int r = 0; r < p; ++r) m[r] = r;
+            for (int r = 0; r < 3; ++r) m[p + r] = p + CODE_LEN + r;         // xyz re-injected at rows 445..447
+            for (int r = 0; r < CODE_LEN; ++r) m[p + 3 + r] = p + r;         // code re-injected at rows 448..511
+        } else {
+            for (int r = 0; r < in_dims[k]; ++r) m[r] = r;
+        }
+        return m;
+    }
+};
+
+template <class F>
+void pack_pass(std::vector<float>& stream, int nog, int nchunks, F value) {
+    const size_t base = stream.size();
+    stream.resize(base + (size_t)nog * nchunks * (CHUNK_BYTES / 4));
+    float* dst = stream.data() + base;
+    for (int og = 0; og < nog; ++og)
+        for (int c = 0; c < nchunks; ++c) {
+            float* ch = dst + ((size_t)og * nchunks + c) * (CHUNK_BYTES / 4);
+            for (int sl = 0; sl < KSTEPS_PER_CHUNK; ++sl)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 4; ++j) {
+                        const int s = KSTEPS_PER_CHUNK * c + sl;
+                        const int krow = 16 * (s >> 2) + 4 * (lane >> 4) + (s & 3);
+                        const int orow = 64 * og + 16 * j + (lane & 15);
+                        ch[(sl * 64 + lane) * 4 + j] = value(orow, krow);
+                    }
+        }
+}
+
+struct PackedNet {
+    std::vector<float> stream, bias;
+    float b_last = 0.f;
+    int n_bias_rows = 0, n_fwd = 0, n_pass_all = 0, chunks_fwd = 0, chunks_all = 0;
+    PassDesc pass[MAX_PASSES];
+};
+
+void pack_decoder_host(PackedNet* h, const dsp_decoder_desc* d) {
+    NetView nv;
+    nv.n_layers = d->n_layers;
+    nv.hidden = d->n_layers - 1;
+    nv.lat = d->latent_in;
+    if (d->code_len != CODE_LEN) throw std::invalid_argument("code_len must be 64");
+    if (nv.hidden < 2 || nv.hidden > 8) throw std::invalid_argument("need 2..8 hidden layers");
+    if (nv.lat < 2 || nv.lat >= nv.hidden) throw std::invalid_argument("latent_in must name one hidden layer >= 2");
+    for (int k = 0; k < d->n_layers; ++k) {
+        nv.out_dims.push_back(d->out_dims[k]);
+        nv.in_dims.push_back(d->in_dims[k]);
+        nv.w.push_back(d->weights[k]);
+        nv.b.push_back(d->biases[k]);
+        const int want_in = (k == 0) ? IN_DIM : WIDTH;
+        const int want_out = (k == nv.hidden) ? 1 : (k + 1 == nv.lat ? WIDTH - IN_DIM : WIDTH);
+        if (d->in_dims[k] != want_in || d->out_dims[k] != want_out)
+            throw std::invalid_argument("unsupported decoder geometry (hidden width must be 512, input 67, output 1)");
+    }
+    std::vector<float>& stream = h->stream;
+    std::vector<float>& bias = h->bias;
+    stream.clear();
+    bias.assign((size_t)(nv.hidden + 1) * WIDTH, 0.f);
+    memset(h->pass, 0, sizeof h->pass);
+    int np = 0, chunk = 0;
+    // forward passes
+    for (int k = 0; k < nv.hidden; ++k) {
+        const std::vector<int> cm = nv.colmap(k);
+        const int od = nv.out_dims[k], id = nv.in_dims[k];
+        const float* W = nv.w[k];
+        PassDesc& p = h->pass[np++];
+        p.nog = (int16_t)((od + 63) / 64);
+        p.nchunks = (int16_t)(k == 0 ? 2 : 8);
+        p.bias_row = (int16_t)k;
+        p.relu = 1;
+        p.mask_slot = (int16_t)k;
+        p.kind = (int16_t)(k == 0 ? 0 : (k == nv.lat ? 2 : 1));
+        p.chunk_base = chunk;
+        pack_pass(stream, p.nog, p.nchunks, [&](int orow, int krow) -> float {
+            if (orow >= od || krow >= WIDTH || cm[krow] < 0) return 0.f;
+            return W[(size_t)orow * id + cm[krow]];
+        });
+        chunk += p.nog * p.nchunks;
+        for (int o = 0; o < od; ++o) bias[(size_t)k * WIDTH + o] = nv.b[k][o];
+    }
+    h->n_fwd = np;
+    h->chunks_fwd = chunk;
+    for (int o = 0; o < WIDTH; ++o) bias[(size_t)nv.hidden * WIDTH + o] = nv.w[nv.hidden][o];
+    h->b_last = nv.b[nv.hidden][0];
+    h->n_bias_rows = nv.hidden + 1;
+    // backward passes (transposed weights): output rows = the forward layer's INPUT slab rows
+    for (int k = nv.hidden - 1; k >= 0; --k) {
+        const std::vector<int> cm = nv.colmap(k);
+        const int od = nv.out_dims[k], id = nv.in_dims[k];
+        const float* W = nv.w[k];
+        PassDesc& p = h->pass[np++];
+        p.nog = (int16_t)(k == 0 ? 2 : 8);
+        p.nchunks = (int16_t)((od + 63) / 64);
+        p.bias_row = -1;
+        p.relu = 0;
+        p.mask_slot = (int16_t)(k - 1);
+        p.kind = (int16_t)(k == nv.lat ? 4 : (k == 0 ? 5 : 3));
+        p.chunk_base = chunk;
+        pack_pass(stream, p.nog, p.nchunks, [&](int orow, int krow) -> float {
+            if (krow >= od || orow >= WIDTH || cm[orow] < 0) return 0.f;
+            return W[(size_t)krow * id + cm[orow]];
+        });
+        chunk += p.nog * p.nchunks;
+    }
+    h->n_pass_all = np;
+    h->chunks_all = chunk;
+}
+
+void pack_decoder(dsp_handle* h, const dsp_decoder_desc* d) {
+    PackedNet pn;
+    pack_decoder_host(&pn, d);
+    h->b_last = pn.b_last; h->n_bias_rows = pn.n_bias_rows; h->n_fwd = pn.n_fwd; h->n_pass_all = pn.n_pass_all;
+    h->chunks_fwd = pn.chunks_fwd; h->chunks_all = pn.chunks_all;
+    memcpy(h->pass, pn.pass, sizeof h->pass);
+    h->wstream.alloc(pn.stream.size());
+    HIP_TRY(hipMemcpy(h->wstream.p, pn.stream.data(), pn.stream.size() * 4, hipMemcpyHostToDevice));
+    h->bias_tab.alloc(pn.bias.size());
+    HIP_TRY(hipMemcpy(h->bias_tab.p, pn.bias.data(), pn.bias.size() * 4, hipMemcpyHostToDevice));
+}
+
+MlpArgs make_mlp_args(const dsp_handle* h, bool bwd) {
+    MlpArgs a;
+    memset(&a, 0, sizeof a);
+    a.wstream = h->wstream.p;
+    a.bias_tab = h->bias_tab.p;
+    a.b_last = h->b_last;
+    a.n_bias_rows = h->n_bias_rows;
+    a.n_fwd = h->n_fwd;
+    a.n_pass = bwd ? h->n_pass_all : h->n_fwd;
+    a.total_chunks = bwd ? h->chunks_all : h->chunks_fwd;
+    memcpy(a.pass, h->pass, sizeof a.pass);
+    return a;
+}
+
+// one object, n points already in the object frame: forward or forward+gradient
+void run_decoder_points(dsp_handle* h, const float* code, const float* pts, int64_t n, bool bwd, float* sdf_out, float* grad_out) {
+    if (n <= 0) return;
+    HIP_TRY(hipSetDevice(h->device));
+    const int nt = (int)((n + TILE_PTS - 1) / TILE_PTS);
+    std::vector<float4> p4((size_t)n);
+    for (int64_t i = 0; i < n; ++i) p4[i] = make_float4(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], 0.f);
+    std::vector<int4> tiles(nt);
+    for (int i = 0; i < nt; ++i) tiles[i] = make_int4(i * TILE_PTS, (int)std::min<int64_t>(TILE_PTS, n - (int64_t)i * TILE_PTS), 0, 0);
+    h->s_pts.ensure(n);
+    h->s_code.ensure(CODE_LEN);
+    h->s_tiles.ensure(nt);
+    h->s_ntiles.ensure(1);
+    h->s_out.ensure(bwd ? (size_t)n * GRAD_STRIDE : (size_t)n);
+    HIP_TRY(hipMemcpyAsync(h->s_pts.p, p4.data(), n * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->s_code.p, code, CODE_LEN * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->s_tiles.p, tiles.data(), nt * sizeof(int4), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->s_ntiles.p, &nt, 4, hipMemcpyHostToDevice, h->stream));
+    MlpArgs a = make_mlp_args(h, bwd);
+    a.n_tiles = h->s_ntiles.p;
+    a.tiles = h->s_tiles.p;
+    a.pts = h->s_pts.p;
+    a.codes = h->s_code.p;
+    a.code_stride = CODE_LEN;
+    a.out_sdf = h->s_out.p;
+    a.out_grad = h->s_out.p;
+    HIP_TRY(launch_mlp(bwd, a, std::min(nt, h->n_cu), h->stream));
+    if (!bwd) {
+        HIP_TRY(hipMemcpyAsync(sdf_out, h->s_out.p, n * 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    } else {
+        std::vector<float> tmp((size_t)n * GRAD_STRIDE);
+        HIP_TRY(hipMemcpyAsync(tmp.data(), h->s_out.p, tmp.size() * 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        for (int64_t i = 0; i < n; ++i) {
+            if (grad_out) memcpy(grad_out + i * DSP_GRAD_DIM, tmp.data() + i * GRAD_STRIDE, DSP_GRAD_DIM * 4);
+            if (sdf_out) sdf_out[i] = tmp[i * GRAD_STRIDE + 67];
+        }
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// batches
+// ------------------------------------------------------------------------------------------------
+struct dsp_batch {
+    dsp_handle* h = nullptr;
+    dsp_gn_params prm;
+    int B = 0, D = 0, maxR = 0, maxM = 0, n_slices = 1;
+    bool pose_only = false, trace_on = false;
+    int64_t sum_pts = 0, sum_rays = 0, sum_depth = 0, cap_s = 0, cap_j = 0;
+    std::vector<ObjConst> oc_host;
+    DevBuf<ObjConst> oc;
+    DevBuf<ObjState> st;
+    DevBuf<float> pts, rays, depth, t_in, codes_in, scale_in;
+    bool have_codes = false;
+    DevBuf<unsigned long long> raymask;
+    DevBuf<int> raycnt, rayoff, kcnt, koff, mcnt;
+    DevBuf<float> ray_res, ssdf, sdeds, jgrad, partials, trace, out_t, out_code, out_loss, rows;
+    DevBuf<float4> spts, jpts;
+    DevBuf<float2> jaux;
+    DevBuf<unsigned char> alive;
+    DevBuf<int4> tiles_f, tiles_j;
+    DevBuf<int> n_tiles, out_status;
+    DevBuf<double> counters;
+    std::vector<hipEvent_t> ev;   // pairs around every decoder launch + [run start, run end]
+    std::vector<int> ev_kind;
+    dsp_stats stats;
+    int iters_run = 0;
+    ~dsp_batch() { for (auto e : ev) (void)hipEventDestroy(e); }
+};
+
+namespace {
+
+dsp_batch* batch_build(dsp_handle* h, const dsp_gn_params* prm, int B, const int64_t* pts_off, const float* pts,
+                       const int64_t* ray_off, const float* rays, const int64_t* depth_off, const float* depth,
+                       const float* t_in, const float* codes_in, const float* scale_in, bool pose_only) {
+    if (B <= 0) throw std::invalid_argument("n_objects must be positive");
+    if (!pose_only && (prm->num_depth_samples < 2 || prm->num_depth_samples > MAX_DEPTH_SAMPLES))
+        throw std::invalid_argument("num_depth_samples must be in [2, 64]");
+    HIP_TRY(hipSetDevice(h->device));
+    std::unique_ptr<dsp_batch> b(new dsp_batch);
+    b->h = h;
+    b->prm = *prm;
+    b->B = B;
+    b->D = pose_only ? 2 : prm->num_depth_samples;
+    b->pose_only = pose_only;
+    b->oc_host.resize(B);
+    int64_t cap_s = 0, cap_j = 0;
+    for (int i = 0; i < B; ++i) {
+        ObjConst& c = b->oc_host[i];
+        memset(&c, 0, sizeof c);
+        c.pts_off = (int)pts_off[i];
+        c.n_pts = (int)(pts_off[i + 1] - pts_off[i]);
+        if (!pose_only) {
+            c.ray_off = (int)ray_off[i];
+            c.n_rays = (int)(ray_off[i + 1] - ray_off[i]);
+            c.depth_off = (int)depth_off[i];
+            c.n_fg = (int)(depth_off[i + 1] - depth_off[i]);
+            if (c.n_fg > c.n_rays) throw std::invalid_argument("more depths than rays");
+            if (c.n_rays >= (1 << 25)) throw std::invalid_argument("too many rays per object");
+        }
+        const int scap = pose_only ? 0 : round_up(c.n_rays * b->D, TILE_PTS);
+        c.samp_off = (int)cap_s;
+        cap_s += scap;
+        c.jsdf_off = (int)cap_j;
+        cap_j += round_up(c.n_pts, TILE_PTS);
+        c.jren_off = (int)cap_j;
+        cap_j += scap;
+        b->maxR = std::max(b->maxR, c.n_rays);
+        b->maxM = std::max(b->maxM, c.n_pts);
+        if (cap_j > (int64_t)1 << 30) throw std::invalid_argument("batch too large for 32-bit point indices");
+    }
+    b->cap_s = cap_s;
+    b->cap_j = cap_j;
+    b->sum_pts = pts_off[B];
+    b->sum_rays = pose_only ? 0 : ray_off[B];
+    b->sum_depth = pose_only ? 0 : depth_off[B];
+    b->n_slices = std::max(2, std::min(32, 2048 / B));
+    b->oc.alloc(B);
+    b->st.alloc(B);
+    HIP_TRY(hipMemcpy(b->oc.p, b->oc_host.data(), B * sizeof(ObjConst), hipMemcpyHostToDevice));
+    b->pts.alloc(b->sum_pts * 3);
+    HIP_TRY(hipMemcpy(b->pts.p, pts, b->sum_pts * 12, hipMemcpyHostToDevice));
+    b->t_in.alloc((size_t)B * 16);
+    HIP_TRY(hipMemcpy(b->t_in.p, t_in, (size_t)B * 64, hipMemcpyHostToDevice));
+    b->codes_in.alloc((size_t)B * CODE_LEN);
+    b->have_codes = codes_in != nullptr;
+    if (codes_in) HIP_TRY(hipMemcpy(b->codes_in.p, codes_in, (size_t)B * CODE_LEN * 4, hipMemcpyHostToDevice));
+    b->scale_in.alloc(B);
+    if (scale_in) HIP_TRY(hipMemcpy(b->scale_in.p, scale_in, (size_t)B * 4, hipMemcpyHostToDevice));
+    if (!pose_only) {
+        b->rays.alloc(b->sum_rays * 3);
+        HIP_TRY(hipMemcpy(b->rays.p, rays, b->sum_rays * 12, hipMemcpyHostToDevice));
+        b->depth.alloc(b->sum_depth);
+        if (b->sum_depth) HIP_TRY(hipMemcpy(b->depth.p, depth, b->sum_depth * 4, hipMemcpyHostToDevice));
+        b->raymask.alloc(b->sum_rays);
+        b->raycnt.alloc(b->sum_rays); b->rayoff.alloc(b->sum_rays);
+        b->kcnt.alloc(b->sum_rays); b->koff.alloc(b->sum_rays); b->mcnt.alloc(b->sum_rays);
+        b->ray_res.alloc(b->sum_rays);
+        b->spts.alloc(cap_s); b->ssdf.alloc(cap_s); b->sdeds.alloc(cap_s);
+        b->tiles_f.alloc(cap_s / TILE_PTS + B);
+    } else {
+        b->alive.alloc(cap_j);
+    }
+    b->jpts.alloc(cap_j); b->jaux.alloc(cap_j);
+    b->jgrad.alloc((size_t)cap_j * GRAD_STRIDE);
+    b->tiles_j.alloc(cap_j / TILE_PTS + 2 * B);
+    b->n_tiles.alloc(2);
+    b->counters.alloc(2);
+    b->partials.alloc((size_t)B * 2 * b->n_slices * 72 * 72);
+    b->out_t.alloc((size_t)B * 16); b->out_code.alloc((size_t)B * CODE_LEN); b->out_loss.alloc(B); b->out_status.alloc(B);
+    memset(&b->stats, 0, sizeof b->stats);
+    return b.release();
+}
+
+GnParamsDev dev_params(const dsp_batch* b) {
+    GnParamsDev p;
+    p.k1 = b->prm.k1; p.k2 = b->prm.k2; p.k3 = b->prm.k3; p.k4 = b->prm.k4;
+    p.b1 = b->prm.b1; p.b2 = b->prm.b2; p.lr = b->prm.lr; p.s_damp = b->prm.s_damp; p.cut_off = b->prm.cut_off;
+    p.n_depth = b->D; p.pose_only = b->pose_only ? 1 : 0;
+    return p;
+}
+
+hipEvent_t next_event(dsp_batch* b, size_t& cursor) {
+    if (cursor == b->ev.size()) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        b->ev.push_back(e);
+    }
+    return b->ev[cursor++];
+}
+
+void launch_decoder(dsp_batch* b, bool bwd, size_t& cursor) {
+    dsp_handle* h = b->h;
+    MlpArgs a = make_mlp_args(h, bwd);
+    a.n_tiles = b->n_tiles.p + (bwd ? 1 : 0);
+    a.tiles = bwd ? b->tiles_j.p : b->tiles_f.p;
+    a.pts = bwd ? b->jpts.p : b->spts.p;
+    a.codes = reinterpret_cast<const float*>(reinterpret_cast<const char*>(b->st.p) + offsetof(ObjState, code));
+    a.code_stride = sizeof(ObjState) / 4;
+    a.out_sdf = b->ssdf.p;
+    a.out_grad = b->jgrad.p;
+    hipEvent_t e0 = next_event(b, cursor), e1 = next_event(b, cursor);
+    b->ev_kind.push_back(bwd ? 1 : 0);
+    HIP_TRY(hipEventRecord(e0, h->stream));
+    HIP_TRY(launch_mlp(bwd, a, h->n_cu, h->stream));
+    HIP_TRY(hipEventRecord(e1, h->stream));
+}
+
+// the first half of an iteration up to and including the J rows' inputs (shared with the stand-alone terms)
+void iteration_front(dsp_batch* b, size_t& cursor, bool do_render) {
+    dsp_handle* h = b->h;
+    hipStream_t s = h->stream;
+    const int B = b->B;
+    if (do_render) {
+        launch_sample_count(b->oc.p, b->st.p, b->rays.p, b->raymask.p, b->raycnt.p, b->D, b->maxR, B, s);
+        launch_scan_rays(b->oc.p, b->st.p, b->raycnt.p, b->rayoff.p, 0, B, s);
+        launch_sample_write(b->oc.p, b->st.p, b->rays.p, b->raymask.p, b->rayoff.p, b->spts.p, b->D, b->maxR, B, s);
+        launch_build_tiles(b->oc.p, b->st.p, B, 0, b->tiles_f.p, b->n_tiles.p, b->counters.p, s);
+        launch_decoder(b, false, cursor);
+        launch_render_scan(b->oc.p, b->st.p, b->raymask.p, b->rayoff.p, b->ssdf.p, b->depth.p, b->sdeds.p, b->ray_res.p,
+                           b->kcnt.p, b->mcnt.p, b->D, b->prm.cut_off, b->maxR, B, s);
+        launch_scan_rays(b->oc.p, b->st.p, b->kcnt.p, b->koff.p, 1, B, s);
+        launch_sum_m(b->oc.p, b->st.p, b->mcnt.p, B, s);
+        launch_render_write(b->oc.p, b->st.p, b->raycnt.p, b->rayoff.p, b->koff.p, b->spts.p, b->sdeds.p, b->ray_res.p,
+                            b->jpts.p, b->jaux.p, b->maxR, B, s);
+    }
+    launch_surface(b->oc.p, b->st.p, b->pts.p, b->jpts.p, b->jaux.p, b->maxM, B, s);
+    launch_build_tiles(b->oc.p, b->st.p, B, 1, b->tiles_j.p, b->n_tiles.p + 1, b->counters.p, s);
+    launch_decoder(b, true, cursor);
+}
+
+void batch_run(dsp_batch* b) {
+    dsp_handle* h = b->h;
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const int B = b->B;
+    const int iters = b->pose_only ? b->prm.pose_only_iterations : b->prm.num_iterations;
+    if (b->trace_on) b->trace.ensure((size_t)std::max(iters, 1) * B * TRACE_STRIDE);
+    size_t cursor = 0;
+    b->ev_kind.clear();
+    hipEvent_t e_start = next_event(b, cursor);
+    HIP_TRY(hipEventRecord(e_start, s));
+    HIP_TRY(hipMemsetAsync(b->counters.p, 0, 2 * sizeof(double), s));
+    HIP_TRY(hipMemsetAsync(b->st.p, 0, (size_t)B * sizeof(ObjState), s));
+    launch_init_state(b->st.p, b->t_in.p, b->have_codes ? b->codes_in.p : nullptr, b->scale_in.p, B, b->D, b->pose_only ? 1 : 0, s);
+    if (b->pose_only) HIP_TRY(hipMemsetAsync(b->alive.p, 1, b->cap_j, s));
+    const GnParamsDev dp = dev_params(b);
+    for (int e = 0; e < iters; ++e) {
+        iteration_front(b, cursor, !b->pose_only);
+        launch_gram(b->oc.p, b->st.p, b->jpts.p, b->jaux.p, b->jgrad.p, b->pose_only ? b->alive.p : nullptr, b->partials.p,
+                    b->n_slices, b->prm.b2, b->prm.b1, b->pose_only ? 0 : 1, b->pose_only ? 1 : 2, B, s);
+        launch_solve(b->oc.p, b->st.p, b->partials.p, b->n_slices, dp, e, b->trace_on ? b->trace.p : nullptr, B, s);
+        if (b->pose_only && e == 4) launch_inlier_filter(b->oc.p, b->st.p, b->jgrad.p, b->alive.p, b->maxM, B, s);
+    }
+    launch_finalize(b->st.p, b->scale_in.p, B, b->pose_only ? 1 : 0, b->out_t.p, b->out_code.p, b->out_loss.p, b->out_status.p, s);
+    hipEvent_t e_end = next_event(b, cursor);
+    HIP_TRY(hipEventRecord(e_end, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipGetLastError());
+    b->iters_run = iters;
+    // stats
+    dsp_stats st;
+    memset(&st, 0, sizeof st);
+    double cnt[2];
+    HIP_TRY(hipMemcpy(cnt, b->counters.p, sizeof cnt, hipMemcpyDeviceToHost));
+    st.n_fwd_points = cnt[0];
+    st.n_jac_points = cnt[1];
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e_start, e_end));
+    st.ms_total = ms;
+    for (size_t i = 0; i < b->ev_kind.size(); ++i) {
+        HIP_TRY(hipEventElapsedTime(&ms, b->ev[1 + 2 * i], b->ev[2 + 2 * i]));
+        if (b->ev_kind[i]) { st.ms_mlp_jac += ms; st.n_mlp_jac_launches++; }
+        else { st.ms_mlp_fwd += ms; st.n_mlp_fwd_launches++; }
+    }
+    b->stats = st;
+}
+
+void batch_results(dsp_batch* b, float* t_out, float* codes_out, float* loss_out, int32_t* status_out) {
+    const int B = b->B;
+    HIP_TRY(hipSetDevice(b->h->device));
+    if (t_out) HIP_TRY(hipMemcpy(t_out, b->out_t.p, (size_t)B * 64, hipMemcpyDeviceToHost));
+    if (codes_out) HIP_TRY(hipMemcpy(codes_out, b->out_code.p, (size_t)B * CODE_LEN * 4, hipMemcpyDeviceToHost));
+    if (loss_out) HIP_TRY(hipMemcpy(loss_out, b->out_loss.p, (size_t)B * 4, hipMemcpyDeviceToHost));
+    if (status_out) HIP_TRY(hipMemcpy(status_out, b->out_status.p, (size_t)B * 4, hipMemcpyDeviceToHost));
+}
+
+template <class F>
+int guarded(dsp_handle* h, F f) {
+    try {
+        f();
+        return DSP_OK;
+    } catch (const std::invalid_argument& e) {
+        if (h) h->err = e.what(); else g_create_error = e.what();
+        return DSP_E_ARG;
+    } catch (const std::bad_alloc& e) {
+        if (h) h->err = "out of host memory"; else g_create_error = "out of host memory";
+        return DSP_E_NOMEM;
+    } catch (const std::exception& e) {
+        if (h) h->err = e.what(); else g_create_error = e.what();
+        return DSP_E_HIP;
+    }
+}
+
+// stand-alone residual terms: a one-object batch whose state is set from the caller's t_obj_cam / depths
+void run_terms(dsp_handle* h, const float* pts_cam, int64_t n_pts, const float* rays, int64_t n_rays, const float* depth_obs,
+               const float* t_obj_cam, const float* sampled, int n_depths, const float* code, float th, int term,
+               int64_t* k_out, float* jac_pose, float* jac_code, float* res, int64_t* v_out, int64_t* m_out) {
+    dsp_gn_params prm;
+    memset(&prm, 0, sizeof prm);
+    prm.num_iterations = 1; prm.num_depth_samples = std::max(n_depths, 2); prm.cut_off = th; prm.lr = 1.f;
+    const float eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    const float dummy_pt[3] = {0, 0, 0};
+    int64_t po[2] = {0, n_pts}, ro[2] = {0, n_rays}, dof[2] = {0, n_rays};
+    const bool render = term == 1;
+    if (render) { po[1] = 1; pts_cam = dummy_pt; }
+    std::unique_ptr<dsp_batch> b(batch_build(h, &prm, 1, po, pts_cam, ro, rays, dof, depth_obs, eye, nullptr, nullptr, !render));
+    ObjState st;
+    memset(&st, 0, sizeof st);
+    memcpy(st.t_oc, t_obj_cam, 64);
+    memcpy(st.code, code, CODE_LEN * 4);
+    if (render) {
+        memcpy(st.depths, sampled, n_depths * 4);
+        st.dmin = sampled[0]; st.dmax = sampled[n_depths - 1];
+    }
+    st.n_alive = -1;
+    HIP_TRY(hipMemcpyAsync(b->st.p, &st, sizeof st, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemsetAsync(b->counters.p, 0, 2 * sizeof(double), h->stream));
+    size_t cursor = 0;
+    b->ev_kind.clear();
+    (void)next_event(b.get(), cursor);
+    iteration_front(b.get(), cursor, render);
+    const int cap = render ? (int)(n_rays * n_depths) : (int)n_pts;
+    b->rows.alloc((size_t)std::max(cap, 1) * 72);
+    launch_jrows(b->oc.p, b->st.p, b->jpts.p, b->jaux.p, b->jgrad.p, term, b->rows.p, std::max(cap, 1), h->stream);
+    HIP_TRY(hipMemcpyAsync(&st, b->st.p, sizeof st, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipGetLastError());
+    int64_t n = render ? st.K : n_pts;
+    if (render) {
+        if (v_out) *v_out = st.V;
+        if (m_out) *m_out = st.m;
+        if (st.status == DSP_STATUS_FEW) { *k_out = -1; return; }
+        *k_out = n;
+    }
+    std::vector<float> rows((size_t)n * 72);
+    if (n) HIP_TRY(hipMemcpy(rows.data(), b->rows.p, rows.size() * 4, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < n; ++i) {
+        memcpy(jac_pose + i * 7, rows.data() + i * 72, 7 * 4);
+        memcpy(jac_code + i * CODE_LEN, rows.data() + i * 72 + 7, CODE_LEN * 4);
+        res[i] = rows[i * 72 + 71];
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int dsp_abi_version(void) { return 1; }
+
+/* Host-only: pack a decoder exactly as dsp_create does and copy the result out (tests emulate the kernel's
+ * data flow on it without a GPU).  pass_out receives n_pass x 8 int32 {nog,nchunks,bias_row,relu,mask_slot,kind,chunk_base,0};
+ * meta_out = {n_fwd, n_pass, chunks_fwd, chunks_all, n_bias_rows}.  Call with NULL buffers to query sizes. */
+int dsp_debug_pack(const dsp_decoder_desc* decoder, float* stream_out, int64_t* stream_len, float* bias_out,
+                   int64_t* bias_len, int32_t* pass_out, int32_t* meta_out, float* b_last_out) {
+    if (!decoder || !stream_len || !bias_len || !meta_out) return DSP_E_ARG;
+    return guarded(nullptr, [&] {
+        PackedNet pn;
+        pack_decoder_host(&pn, decoder);
+        *stream_len = (int64_t)pn.stream.size();
+        *bias_len = (int64_t)pn.bias.size();
+        meta_out[0] = pn.n_fwd; meta_out[1] = pn.n_pass_all; meta_out[2] = pn.chunks_fwd; meta_out[3] = pn.chunks_all; meta_out[4] = pn.n_bias_rows;
+        if (b_last_out) *b_last_out = pn.b_last;
+        if (stream_out) memcpy(stream_out, pn.stream.data(), pn.stream.size() * 4);
+        if (bias_out) memcpy(bias_out, pn.bias.data(), pn.bias.size() * 4);
+        if (pass_out)
+            for (int i = 0; i < pn.n_pass_all; ++i) {
+                const PassDesc& p = pn.pass[i];
+                int32_t* o = pass_out + 8 * i;
+                o[0] = p.nog; o[1] = p.nchunks; o[2] = p.bias_row; o[3] = p.relu; o[4] = p.mask_slot; o[5] = p.kind; o[6] = p.chunk_base; o[7] = 0;
+            }
+    });
+}
+
+int dsp_create(const dsp_decoder_desc* decoder, int device, dsp_handle** out) {
+    if (!decoder || !out) { g_create_error = "null argument"; return DSP_E_ARG; }
+    *out = nullptr;
+    dsp_handle* h = nullptr;
+    int rc = guarded(nullptr, [&] {
+        int ndev = 0;
+        HIP_TRY(hipGetDeviceCount(&ndev));
+        if (device < 0 || device >= ndev) throw std::invalid_argument("no such HIP device");
+        HIP_TRY(hipSetDevice(device));
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+            throw std::runtime_error(std::string("libdspgn is built for gfx950 (MI355X); device is ") + prop.gcnArchName);
+        h = new dsp_handle;
+        h->device = device;
+        h->n_cu = prop.multiProcessorCount;
+        HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        pack_decoder(h, decoder);
+    });
+    if (rc != DSP_OK) { delete h; return rc; }
+    *out = h;
+    return DSP_OK;
+}
+
+void dsp_destroy(dsp_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    delete h;
+}
+
+const char* dsp_last_error(const dsp_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int dsp_decode_sdf(dsp_handle* h, const float* code, const float* pts, int64_t n, float* sdf_out) {
+    if (!h || !code || (n > 0 && (!pts || !sdf_out)) || n < 0) return DSP_E_ARG;
+    return guarded(h, [&] { run_decoder_points(h, code, pts, n, false, sdf_out, nullptr); });
+}
+
+int dsp_sdf_jacobian(dsp_handle* h, const float* code, const float* pts, int64_t n, float* sdf_out, float* grad_out) {
+    if (!h || !code || (n > 0 && !pts) || n < 0) return DSP_E_ARG;
+    return guarded(h, [&] { run_decoder_points(h, code, pts, n, true, sdf_out, grad_out); });
+}
+
+int dsp_compute_sdf_loss(dsp_handle* h, const float* pts_cam, int64_t n, const float* t_obj_cam, const float* code,
+                         float* jac_pose, float* jac_code, float* res) {
+    if (!h || !pts_cam || n <= 0 || !t_obj_cam || !code || !jac_pose || !jac_code || !res) return DSP_E_ARG;
+    return guarded(h, [&] {
+        run_terms(h, pts_cam, n, nullptr, 0, nullptr, t_obj_cam, nullptr, 0, code, 0.01f, 0, nullptr, jac_pose, jac_code, res, nullptr, nullptr);
+    });
+}
+
+int dsp_compute_render_loss(dsp_handle* h, const float* rays, int64_t n_rays, const float* depth_obs, const float* t_obj_cam,
+                            const float* sampled_depth, int32_t n_depths, const float* code, float th, int64_t* k_out,
+                            float* jac_pose, float* jac_code, float* res, int64_t* v_out, int64_t* m_out) {
+    if (!h || !rays || n_rays <= 0 || !depth_obs || !t_obj_cam || !sampled_depth || n_depths < 2 || n_depths > MAX_DEPTH_SAMPLES ||
+        !code || !k_out || !jac_pose || !jac_code || !res)
+        return DSP_E_ARG;
+    return guarded(h, [&] {
+        run_terms(h, nullptr, 0, rays, n_rays, depth_obs, t_obj_cam, sampled_depth, n_depths, code, th, 1, k_out, jac_pose, jac_code, res, v_out, m_out);
+    });
+}
+
+int dsp_batch_create(dsp_handle* h, const dsp_gn_params* prm, int32_t n_objects, const int64_t* pts_off, const float* pts,
+                     const int64_t* ray_off, const float* rays, const int64_t* depth_off, const float* depth,
+                     const float* t_cam_obj_in, const float* codes_in, dsp_batch** out) {
+    if (!h || !prm || !pts_off || !pts || !ray_off || !rays || !depth_off || !t_cam_obj_in || !out) return DSP_E_ARG;
+    return guarded(h, [&] { *out = batch_build(h, prm, n_objects, pts_off, pts, ray_off, rays, depth_off, depth, t_cam_obj_in, codes_in, nullptr, false); });
+}
+
+int dsp_batch_run(dsp_batch* b) {
+    if (!b) return DSP_E_ARG;
+    return guarded(b->h, [&] { batch_run(b); });
+}
+
+int dsp_batch_results(dsp_batch* b, float* t_cam_obj_out, float* codes_out, float* loss_out, int32_t* status_out) {
+    if (!b) return DSP_E_ARG;
+    return guarded(b->h, [&] { batch_results(b, t_cam_obj_out, codes_out, loss_out, status_out); });
+}
+
+int dsp_batch_stats(dsp_batch* b, dsp_stats* out) {
+    if (!b || !out) return DSP_E_ARG;
+    *out = b->stats;
+    return DSP_OK;
+}
+
+int dsp_batch_enable_trace(dsp_batch* b, int on) {
+    if (!b) return DSP_E_ARG;
+    b->trace_on = on != 0;
+    return DSP_OK;
+}
+
+int dsp_batch_trace(dsp_batch* b, int32_t iteration, float* H, float* bvec, float* dx, int64_t* V, int64_t* m, int64_t* K,
+                    float* t_obj_cam, float* code) {
+    if (!b || !b->trace_on || iteration < 0 || iteration >= b->iters_run) return DSP_E_STATE;
+    return guarded(b->h, [&] {
+        const int B = b->B;
+        std::vector<float> tr((size_t)B * TRACE_STRIDE);
+        HIP_TRY(hipSetDevice(b->h->device));
+        HIP_TRY(hipMemcpy(tr.data(), b->trace.p + (size_t)iteration * B * TRACE_STRIDE, tr.size() * 4, hipMemcpyDeviceToHost));
+        const int n = b->pose_only ? 6 : 71;
+        for (int i = 0; i < B; ++i) {
+            const float* t = tr.data() + (size_t)i * TRACE_STRIDE;
+            if (H) for (int r = 0; r < n; ++r) memcpy(H + ((size_t)i * n + r) * n, t + r * 71, n * 4);
+            if (bvec) memcpy(bvec + (size_t)i * n, t + 71 * 71, n * 4);
+            if (dx) memcpy(dx + (size_t)i * n, t + 71 * 71 + 71, n * 4);
+            if (t_obj_cam) memcpy(t_obj_cam + (size_t)i * 16, t + 71 * 71 + 142, 64);
+            if (code) memcpy(code + (size_t)i * CODE_LEN, t + 71 * 71 + 142 + 16, CODE_LEN * 4);
+            if (V) V[i] = (int64_t)t[71 * 71 + 142 + 80];
+            if (m) m[i] = (int64_t)t[71 * 71 + 142 + 81];
+            if (K) K[i] = (int64_t)t[71 * 71 + 142 + 82];
+        }
+    });
+}
+
+void dsp_batch_destroy(dsp_batch* b) {
+    if (!b) return;
+    (void)hipSetDevice(b->h->device);
+    delete b;
+}
+
+int dsp_reconstruct_batch(dsp_handle* h, const dsp_gn_params* prm, int32_t n_objects, const int64_t* pts_off, const float* pts,
+                          const int64_t* ray_off, const float* rays, const int64_t* depth_off, const float* depth,
+                          const float* t_cam_obj_in, const float* codes_in, float* t_cam_obj_out, float* codes_out,
+                          float* loss_out, int32_t* status_out) {
+    if (!h || !prm || !pts_off || !pts || !ray_off || !rays || !depth_off || !t_cam_obj_in) return DSP_E_ARG;
+    return guarded(h, [&] {
+        std::unique_ptr<dsp_batch> b(batch_build(h, prm, n_objects, pts_off, pts, ray_off, rays, depth_off, depth, t_cam_obj_in, codes_in, nullptr, false));
+        batch_run(b.get());
+        batch_results(b.get(), t_cam_obj_out, codes_out, loss_out, status_out);
+    });
+}
+
+int dsp_estimate_pose_batch(dsp_handle* h, const dsp_gn_params* prm, int32_t n_objects, const int64_t* pts_off, const float* pts,
+                            const float* t_co_se3_in, const float* scale, const float* codes, float* t_co_se3_out) {
+    if (!h || !prm || !pts_off || !pts || !t_co_se3_in || !scale || !codes || !t_co_se3_out) return DSP_E_ARG;
+    return guarded(h, [&] {
+        std::unique_ptr<dsp_batch> b(batch_build(h, prm, n_objects, pts_off, pts, nullptr, nullptr, nullptr, nullptr, t_co_se3_in, codes, scale, true));
+        batch_run(b.get());
+        batch_results(b.get(), t_co_se3_out, nullptr, nullptr, nullptr);
+    });
+}
+
+}  // extern "C"

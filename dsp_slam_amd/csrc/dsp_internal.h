@@ -1,0 +1,104 @@
+// Internal definitions shared by the HIP kernels and the host side of libdspgn.
+// (The public C-ABI is include/dsp_gn.h.)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dsp {
+
+// ---- decoder geometry the MLP kernel is built for (DeepSDF as used by DSP-SLAM) -------------
+// hidden width 512, code length 64, one latent_in layer; see DESIGN.md "MLP kernel".
+constexpr int WIDTH = 512;          // hidden width == slab rows
+constexpr int CODE_LEN = 64;
+constexpr int IN_DIM = CODE_LEN + 3;
+constexpr int TILE_PTS = 64;        // points per workgroup tile (4 waves x 16)
+constexpr int WAVE_PTS = 16;
+constexpr int KSTEPS_PER_CHUNK = 16;            // 16 MFMA k-steps (64 slab rows) per weight chunk
+constexpr int CHUNK_BYTES = KSTEPS_PER_CHUNK * 64 * 16;   // 16 KiB: [kstep][lane] float4
+constexpr int MAX_PASSES = 32;
+constexpr int GRAD_STRIDE = 68;     // per-point output row: d/dcode[64], d/dxyz[3], sdf
+
+// One "pass" = one dense layer traversal (forward layer or backward layer) of the weight stream.
+struct PassDesc {
+    int16_t nog;        // number of 64-row output groups
+    int16_t nchunks;    // number of 64-row K chunks per output group
+    int16_t bias_row;   // row of the LDS bias table to start the accumulators from, -1 = zero
+    int16_t relu;       // 1: relu + store mask (forward hidden layer)
+    int16_t mask_slot;  // forward: slot the relu mask is stored to; backward: slot applied; -1 none
+    int16_t kind;       // 0 fwd first layer, 1 fwd hidden, 2 fwd latent_in layer, 3 bwd, 4 bwd latent_in, 5 bwd first
+    int32_t chunk_base; // first chunk of this pass in the packed stream
+};
+
+struct MlpArgs {
+    const float* wstream;       // packed weight stream (fwd passes then bwd passes), chunk-major
+    const float* bias_tab;      // [n_bias_rows][512]: hidden biases, last row = final layer weights
+    float b_last;               // final layer bias
+    int n_bias_rows;
+    int n_fwd;                  // number of forward passes (hidden layers)
+    int n_pass;                 // fwd (+ bwd when BWD)
+    int total_chunks;           // chunks consumed per tile
+    PassDesc pass[MAX_PASSES];
+    // work list (device memory, produced on device)
+    const int* n_tiles;         // [1]
+    const int4* tiles;          // [n_tiles] {first point, n points, object, unused}
+    const float4* pts;          // object-frame points (xyz, w unused)
+    const float* codes;         // code of object o at codes + o * code_stride
+    int code_stride;            // in floats (multiple of 4)
+    float* out_sdf;             // FWD: [n_points]
+    float* out_grad;            // BWD: [n_points][GRAD_STRIDE]
+};
+
+// ---- Gauss-Newton batch state ------------------------------------------------------------------
+constexpr int DSP_STATUS_GOOD = 0;
+constexpr int DSP_STATUS_FEW = 1;    // < 10 in-sphere samples (loss.py:73-74)
+constexpr int DSP_STATUS_NAN = 2;    // NaN loss / singular system (optimizer.py:135-136,149-150)
+constexpr int MAX_DEPTH_SAMPLES = 64;
+constexpr int TRACE_STRIDE = 5272;   // 71*71 H | 71 b | 71 dx | 16 t_oc | 64 code | V m K (+pad)
+
+struct ObjConst {           // static layout of one object inside the batch arrays
+    int pts_off, n_pts;     // surface points (camera frame)
+    int ray_off, n_rays, n_fg;
+    int depth_off;          // foreground depths
+    int samp_off;           // segment of the in-sphere sample list (capacity roundup64(n_rays * D))
+    int jsdf_off;           // jacobian-point segment, surface term (capacity roundup64(n_pts))
+    int jren_off;           // jacobian-point segment, render term (capacity = sample capacity)
+    int pad;
+};
+
+struct ObjState {           // per-object optimiser state, lives on the device for the whole run
+    float t_oc[16];         // camera -> object Sim(3)/SE(3)   (t_obj_cam)
+    float t_co[16];
+    float code[CODE_LEN];
+    float depths[MAX_DEPTH_SAMPLES];
+    float scale, dmin, dmax, loss;
+    int status, V, m, K;
+    int n_alive, pad0, pad1, pad2;
+};
+
+struct GnParamsDev {
+    float k1, k2, k3, k4, b1, b2, lr, s_damp, cut_off;
+    int n_depth, pose_only;
+};
+
+// kernels_mlp / kernels_gn launchers
+size_t mlp_lds_bytes(bool bwd);
+hipError_t launch_mlp(bool bwd, const MlpArgs& args, int n_blocks, hipStream_t stream);
+void launch_init_state(ObjState* st, const float* t, const float* codes, const float* scale, int B, int D, int pose_only, hipStream_t s);
+void launch_sample_count(const ObjConst* oc, const ObjState* st, const float* rays, unsigned long long* m, int* c, int D, int maxR, int B, hipStream_t s);
+void launch_scan_rays(const ObjConst* oc, ObjState* st, const int* cnt, int* off, int which, int B, hipStream_t s);
+void launch_sample_write(const ObjConst* oc, const ObjState* st, const float* rays, const unsigned long long* m, const int* off, float4* spts, int D, int maxR, int B, hipStream_t s);
+void launch_surface(const ObjConst* oc, const ObjState* st, const float* pts, float4* jpts, float2* jaux, int maxM, int B, hipStream_t s);
+void launch_build_tiles(const ObjConst* oc, const ObjState* st, int B, int mode, int4* tiles, int* n_tiles, double* counters, hipStream_t s);
+void launch_render_scan(const ObjConst* oc, const ObjState* st, const unsigned long long* m, const int* off, const float* ssdf, const float* depth,
+                        float* sdeds, float* ray_res, int* kcnt, int* mcnt, int D, float th, int maxR, int B, hipStream_t s);
+void launch_render_write(const ObjConst* oc, const ObjState* st, const int* raycnt, const int* rayoff, const int* koff, const float4* spts,
+                         const float* sdeds, const float* ray_res, float4* jpts, float2* jaux, int maxR, int B, hipStream_t s);
+void launch_sum_m(const ObjConst* oc, ObjState* st, const int* mcnt, int B, hipStream_t s);
+void launch_gram(const ObjConst* oc, const ObjState* st, const float4* jpts, const float2* jaux, const float* jgrad, const unsigned char* alive,
+                 float* partials, int n_slices, float b_sdf, float b_render, int robust, int n_terms, int B, hipStream_t s);
+void launch_jrows(const ObjConst* oc, const ObjState* st, const float4* jpts, const float2* jaux, const float* jgrad, int term, float* rows, int cap, hipStream_t s);
+void launch_solve(const ObjConst* oc, ObjState* st, const float* partials, int n_slices, const GnParamsDev& prm, int iter, float* trace, int B, hipStream_t s);
+void launch_inlier_filter(const ObjConst* oc, ObjState* st, const float* jgrad, unsigned char* alive, int maxM, int B, hipStream_t s);
+void launch_finalize(ObjState* st, const float* scale, int B, int pose_only, float* t, float* code, float* loss, int* status, hipStream_t s);
+
+}  // namespace dsp

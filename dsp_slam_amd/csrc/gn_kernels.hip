@@ -1,0 +1,757 @@
+// Everything around the decoder in one Gauss-Newton iteration, batched over independent objects:
+// ray sampling + in-sphere compaction, occupancy/transmittance scan per ray, J-row assembly,
+// 72x72 Gram (normal-equation) reduction, damped solve + Lie-group update.
+//
+// Reference functions restated on the device (file:line relative to the reference tree):
+//   compute_sdf_loss / compute_render_loss / compute_rotation_loss_sim3   reconstruct/loss.py:22-178
+//   get_points_to_pose_jacobian_sim3, exp_se3, exp_sim3, huber_norm_weights reconstruct/loss_utils.py:107-265
+//   Optimizer.reconstruct_object / estimate_pose_cam_obj                   reconstruct/optimizer.py:45-203
+// These kernels are HBM/latency-bound integer+float bookkeeping (< 0.5 % of the FLOPs); they exist so
+// that the whole iteration stays on the device with no host round trip.
+#include "dsp_internal.h"
+
+#include <algorithm>
+
+namespace dsp {
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+// (p[..., None, :] * R).sum(-1) + t with fp32 products and adds in the reference's order, no FMA
+// contraction, so that in-sphere decisions agree with the oracle bit for bit (loss.py:31-32,62-63).
+__device__ __forceinline__ float3 xform(const float* T, float x, float y, float z) {
+    float3 o;
+    o.x = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(x, T[0]), __fmul_rn(y, T[1])), __fmul_rn(z, T[2])), T[3]);
+    o.y = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(x, T[4]), __fmul_rn(y, T[5])), __fmul_rn(z, T[6])), T[7]);
+    o.z = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(x, T[8]), __fmul_rn(y, T[9])), __fmul_rn(z, T[10])), T[11]);
+    return o;
+}
+
+__device__ bool inv4(const double* a, double* out) {   // Gauss-Jordan with partial pivoting
+    double m[4][8];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) { m[i][j] = a[4 * i + j]; m[i][4 + j] = (i == j) ? 1.0 : 0.0; }
+    for (int c = 0; c < 4; ++c) {
+        int p = c;
+        for (int r = c + 1; r < 4; ++r) if (fabs(m[r][c]) > fabs(m[p][c])) p = r;
+        if (m[p][c] == 0.0) return false;
+        if (p != c) for (int j = 0; j < 8; ++j) { double t = m[c][j]; m[c][j] = m[p][j]; m[p][j] = t; }
+        const double inv = 1.0 / m[c][c];
+        for (int j = 0; j < 8; ++j) m[c][j] *= inv;
+        for (int r = 0; r < 4; ++r) if (r != c) {
+            const double f = m[r][c];
+            for (int j = 0; j < 8; ++j) m[r][j] -= f * m[c][j];
+        }
+    }
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) out[4 * i + j] = m[i][4 + j];
+    return true;
+}
+
+__device__ double det3(const double* r, int ld) {
+    return r[0] * (r[ld + 1] * r[2 * ld + 2] - r[ld + 2] * r[2 * ld + 1]) -
+           r[1] * (r[ld] * r[2 * ld + 2] - r[ld + 2] * r[2 * ld]) +
+           r[2] * (r[ld] * r[2 * ld + 1] - r[ld + 1] * r[2 * ld]);
+}
+
+// Per-iteration derived quantities of one object (optimizer.py:120-126): T_co = inv(T_oc), scale =
+// det(R_co)^(1/3), depth range t_z -+ scale, torch.linspace(d_min, d_max, D) in float32.
+__device__ void derive_iter_state(ObjState& s, int n_depth) {
+    double toc[16], tco[16];
+    for (int i = 0; i < 16; ++i) toc[i] = (double)s.t_oc[i];
+    if (!inv4(toc, tco)) { s.status = DSP_STATUS_NAN; return; }
+    for (int i = 0; i < 16; ++i) s.t_co[i] = (float)tco[i];
+    const double det = det3(tco, 4);
+    const float scale = (float)cbrt(det);
+    s.scale = scale;
+    const float tz = s.t_co[11];
+    const float dmin = tz - 1.0f * scale, dmax = tz + 1.0f * scale;
+    s.dmin = dmin; s.dmax = dmax;
+    const float step = (dmax - dmin) / (float)(n_depth - 1);
+    for (int i = 0; i < n_depth; ++i)   // ATen linspace: first half from start, second half from end
+        s.depths[i] = (i < n_depth / 2) ? __fadd_rn(dmin, __fmul_rn(step, (float)i))
+                                        : __fsub_rn(dmax, __fmul_rn(step, (float)(n_depth - 1 - i)));
+}
+
+__global__ void k_init_state(ObjState* st, const float* t_cam_obj, const float* codes, const float* scale_in,
+                             int n_obj, int n_depth, int pose_only) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_obj) return;
+    ObjState& s = st[b];
+    double tco[16], toc[16];
+    for (int i = 0; i < 16; ++i) tco[i] = (double)t_cam_obj[16 * b + i];
+    if (pose_only) {   // optimizer.py:52-55: R *= scale before inverting
+        const double sc = (double)scale_in[b];
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) tco[4 * r + c] = (double)(float)(tco[4 * r + c] * sc);
+    }
+    s.status = DSP_STATUS_GOOD;
+    if (!inv4(tco, toc)) { s.status = DSP_STATUS_NAN; for (int i = 0; i < 16; ++i) toc[i] = (i % 5 == 0); }
+    for (int i = 0; i < 16; ++i) s.t_oc[i] = (float)toc[i];
+    for (int i = 0; i < CODE_LEN; ++i) s.code[i] = codes ? codes[CODE_LEN * b + i] : 0.f;
+    s.loss = 0.f; s.V = 0; s.m = 0; s.K = 0; s.n_alive = -1;
+    if (!pose_only) derive_iter_state(s, n_depth);
+}
+
+// ------------------------------------------------------------------------------------------------
+// ray sampling: in-sphere mask + count per ray  (loss.py:60-70)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_sample_count(const ObjConst* oc, const ObjState* st, const float* rays, unsigned long long* raymask,
+                               int* raycnt, int n_depth) {
+    const int b = blockIdx.y;
+    const ObjConst c = oc[b];
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= c.n_rays) return;
+    const ObjState& s = st[b];
+    unsigned long long mask = 0ull;
+    if (s.status == DSP_STATUS_GOOD) {
+        const float* d3 = rays + 3 * (size_t)(c.ray_off + r);
+        const float dx = d3[0], dy = d3[1], dz = d3[2];
+        for (int j = 0; j < n_depth; ++j) {
+            const float d = s.depths[j];
+            const float3 p = xform(s.t_oc, __fmul_rn(dx, d), __fmul_rn(dy, d), __fmul_rn(dz, d));
+            const float n2 = __fadd_rn(__fadd_rn(__fmul_rn(p.x, p.x), __fmul_rn(p.y, p.y)), __fmul_rn(p.z, p.z));
+            if (__fsqrt_rn(n2) < 1.0f) mask |= 1ull << j;
+        }
+    }
+    raymask[c.ray_off + r] = mask;
+    raycnt[c.ray_off + r] = __popcll(mask);
+}
+
+// exclusive scan of per-ray counts inside each object (one workgroup per object)
+__global__ __launch_bounds__(256) void k_scan_rays(const ObjConst* oc, ObjState* st, const int* cnt, int* off, int which) {
+    __shared__ int part[256];
+    const int b = blockIdx.x;
+    const ObjConst c = oc[b];
+    const int tid = threadIdx.x;
+    const int per = (c.n_rays + 255) / 256;
+    const int lo = min(tid * per, c.n_rays), hi = min(lo + per, c.n_rays);
+    int sum = 0;
+    for (int r = lo; r < hi; ++r) sum += cnt[c.ray_off + r];
+    part[tid] = sum;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const int v = (tid >= d) ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - sum;
+    for (int r = lo; r < hi; ++r) { off[c.ray_off + r] = run; run += cnt[c.ray_off + r]; }
+    if (tid == 255) {
+        const int total = part[255];
+        ObjState& s = st[b];
+        if (which == 0) {
+            s.V = total;
+            if (s.status == DSP_STATUS_GOOD && total < 10) s.status = DSP_STATUS_FEW;   // loss.py:73-74
+        } else {
+            s.K = total;
+        }
+    }
+}
+
+__global__ void k_sample_write(const ObjConst* oc, const ObjState* st, const float* rays, const unsigned long long* raymask,
+                               const int* rayoff, float4* spts, int n_depth) {
+    const int b = blockIdx.y;
+    const ObjConst c = oc[b];
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= c.n_rays) return;
+    const ObjState& s = st[b];
+    if (s.status != DSP_STATUS_GOOD) return;
+    unsigned long long mask = raymask[c.ray_off + r];
+    const float* d3 = rays + 3 * (size_t)(c.ray_off + r);
+    const float dx = d3[0], dy = d3[1], dz = d3[2];
+    float4* dst = spts + c.samp_off + rayoff[c.ray_off + r];
+    while (mask) {
+        const int j = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        const float d = s.depths[j];
+        const float3 p = xform(s.t_oc, __fmul_rn(dx, d), __fmul_rn(dy, d), __fmul_rn(dz, d));
+        *dst++ = make_float4(p.x, p.y, p.z, __int_as_float((r << 6) | j));
+    }
+}
+
+// surface points -> object frame (loss.py:31-32); also the pose-only inlier bookkeeping (optimizer.py:76-78)
+__global__ void k_surface(const ObjConst* oc, const ObjState* st, const float* pts, float4* jpts, float2* jaux) {
+    const int b = blockIdx.y;
+    const ObjConst c = oc[b];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c.n_pts) return;
+    const ObjState& s = st[b];
+    if (s.status != DSP_STATUS_GOOD) return;
+    const float* p = pts + 3 * (size_t)(c.pts_off + i);
+    const float3 o = xform(s.t_oc, p[0], p[1], p[2]);
+    jpts[c.jsdf_off + i] = make_float4(o.x, o.y, o.z, __int_as_float(i));
+    jaux[c.jsdf_off + i] = make_float2(1.f, 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// tile lists for the decoder kernels (single workgroup; counts live on the device)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_build_tiles(const ObjConst* oc, const ObjState* st, int n_obj, int mode, int4* tiles,
+                                                     int* n_tiles, double* counters) {
+    // mode 0: forward tiles over the V in-sphere samples; mode 1: jacobian tiles over M surface + K render points
+    __shared__ int base;
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    double cnt = 0.0;
+    for (int b = 0; b < n_obj; ++b) {
+        const ObjConst c = oc[b];
+        const ObjState& s = st[b];
+        const bool good = s.status == DSP_STATUS_GOOD;
+        const int b0 = base;
+        __syncthreads();
+        if (mode == 0) {
+            const int n = good ? s.V : 0;
+            const int nt = (n + TILE_PTS - 1) / TILE_PTS;
+            for (int i = threadIdx.x; i < nt; i += 256)
+                tiles[b0 + i] = make_int4(c.samp_off + i * TILE_PTS, min(TILE_PTS, n - i * TILE_PTS), b, 0);
+            if (threadIdx.x == 0) { base = b0 + nt; cnt += n; }
+        } else {
+            const int n1 = good ? c.n_pts : 0;
+            const int n2 = good ? s.K : 0;
+            const int nt1 = (n1 + TILE_PTS - 1) / TILE_PTS, nt2 = (n2 + TILE_PTS - 1) / TILE_PTS;
+            for (int i = threadIdx.x; i < nt1; i += 256)
+                tiles[b0 + i] = make_int4(c.jsdf_off + i * TILE_PTS, min(TILE_PTS, n1 - i * TILE_PTS), b, 0);
+            for (int i = threadIdx.x; i < nt2; i += 256)
+                tiles[b0 + nt1 + i] = make_int4(c.jren_off + i * TILE_PTS, min(TILE_PTS, n2 - i * TILE_PTS), b, 1);
+            if (threadIdx.x == 0) { base = b0 + nt1 + nt2; cnt += n1 + n2; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { *n_tiles = base; counters[mode] += cnt; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-ray occupancy / transmittance scan  (loss.py:84-141)
+// ------------------------------------------------------------------------------------------------
+// One thread per ray, the 50-sample row kept in registers.  Pass 1 (count): occupancy o_j, T_l =
+// prod_{i<=l}(1-o_i), rendered depth d_u, suffix sums for de_do, keeps samples with |sdf| < th and
+// de_do > 1e-2; stores de_ds per compact sample (0 = dropped), d_u per ray and the kept count.
+__global__ void k_render_scan(const ObjConst* oc, const ObjState* st, const unsigned long long* raymask, const int* rayoff,
+                              const float* ssdf, const float* depth_fg, float* sdeds, float* ray_res, int* kcnt, int* mcnt,
+                              int n_depth, float th) {
+    const int b = blockIdx.y;
+    const ObjConst c = oc[b];
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= c.n_rays) return;
+    const ObjState& s = st[b];
+    const int gr = c.ray_off + r;
+    if (s.status != DSP_STATUS_GOOD) { kcnt[gr] = 0; mcnt[gr] = 0; return; }
+    const unsigned long long mask = raymask[gr];
+    const int base = c.samp_off + rayoff[gr];
+    float o[64], T[64];
+    unsigned long long wg = 0ull;   // with_grad: -th < sdf < th  (loss.py:88)
+    {
+        int k = 0;
+        float acc = 1.f;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            float oj = 0.f;
+            if (j < n_depth && ((mask >> j) & 1ull)) {
+                const float sd = ssdf[base + k];
+                ++k;
+                const float cl = fminf(fmaxf(sd, -th), th);
+                oj = __fsub_rn(0.5f, __fdiv_rn(cl, __fmul_rn(2.f, th)));   // sdf_to_occupancy (loss_utils.py:40-48)
+                if (sd > -th && sd < th) wg |= 1ull << j;
+            }
+            acc = __fmul_rn(acc, __fsub_rn(1.f, oj));
+            o[j] = oj;
+            T[j] = acc;
+        }
+    }
+    const float d_bg = __fmul_rn(1.1f, s.depths[n_depth - 1]);
+    // d_u = sum_l d_l * o_l * T_{l-1} + d_bg * T_{D-1}   (loss.py:100-114)
+    float du = 0.f;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+        if (j < n_depth) {
+            const float tp = __fmul_rn(o[j], (j == 0) ? 1.f : T[j - 1]);
+            du = __fadd_rn(du, __fmul_rn(s.depths[j], tp));
+        }
+    }
+    du = __fadd_rn(du, __fmul_rn(d_bg, T[n_depth - 1]));
+    const float obs = (r < c.n_fg) ? depth_fg[c.depth_off + r] : d_bg;   // optimizer.py:126
+    float res = __fsub_rn(obs, du);
+    res = fminf(fmaxf(res, -0.30f), 0.30f);                               // loss.py:139-140
+    ray_res[gr] = res;
+    // de_do_k = sum_{l>=k} T_l / (1 - o_k); keep > 1e-2; de_ds = de_do * delta_d * (-1/(2 th))  (loss.py:118-130)
+    const float delta_d = __fdiv_rn(__fsub_rn(s.depths[n_depth - 1], s.depths[0]), (float)(n_depth - 1));
+    const float do_ds = __fdiv_rn(-1.f, __fmul_rn(2.f, th));
+    float suf[64];
+    {
+        float sacc = 0.f;
+#pragma unroll
+        for (int j = 63; j >= 0; --j) {
+            if (j < n_depth) sacc = __fadd_rn(sacc, T[j]);
+            suf[j] = sacc;
+        }
+    }
+    int kept = 0, k = 0;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+        if (j < n_depth && ((mask >> j) & 1ull)) {
+            float deds = 0.f;
+            if ((wg >> j) & 1ull) {
+                const float dedo = __fdiv_rn(suf[j], __fsub_rn(1.f, o[j]));
+                if (dedo > 1e-2f) { deds = __fmul_rn(__fmul_rn(dedo, delta_d), do_ds); ++kept; }
+            }
+            sdeds[base + k] = deds;   // never exactly 0 for a kept sample (dedo > 0.01, delta_d > 0)
+            ++k;
+        }
+    }
+    kcnt[gr] = kept;
+    mcnt[gr] = __popcll(wg);
+}
+
+__global__ void k_render_write(const ObjConst* oc, const ObjState* st, const int* raycnt, const int* rayoff, const int* koff,
+                               const float4* spts, const float* sdeds, const float* ray_res, float4* jpts, float2* jaux) {
+    const int b = blockIdx.y;
+    const ObjConst c = oc[b];
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= c.n_rays) return;
+    if (st[b].status != DSP_STATUS_GOOD) return;
+    const int gr = c.ray_off + r;
+    const int n = raycnt[gr];
+    const int base = c.samp_off + rayoff[gr];
+    int dst = c.jren_off + koff[gr];
+    const float res = ray_res[gr];
+    for (int k = 0; k < n; ++k) {
+        const float deds = sdeds[base + k];
+        if (deds != 0.f) {
+            jpts[dst] = spts[base + k];
+            jaux[dst] = make_float2(deds, res);
+            ++dst;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sum_m(const ObjConst* oc, ObjState* st, const int* mcnt) {
+    __shared__ int part[256];
+    const int b = blockIdx.x;
+    const ObjConst c = oc[b];
+    int sum = 0;
+    for (int r = threadIdx.x; r < c.n_rays; r += 256) sum += mcnt[c.ray_off + r];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if (threadIdx.x < d) part[threadIdx.x] += part[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) st[b].m = part[0];
+}
+
+// ------------------------------------------------------------------------------------------------
+// J rows and the 72x72 Gram reduction  (loss.py:36-41,143-150; loss_utils.py:166-185,236-265; optimizer.py:159-167)
+// ------------------------------------------------------------------------------------------------
+// row = [ J_pose(7) | J_code(64) | r~ ]:  J^T J is H, -J^T r~ is b and r~^2 sums to the loss, so one
+// 72x72 Gram matrix per (object, term) carries everything the solve needs.
+__device__ __forceinline__ void build_row(const float* g68, float4 p, float2 aux, int term, float huber_b, int robust,
+                                          float* row /*72, stride 1*/) {
+    const float sc = aux.x;                       // de_ds (render) or 1 (sdf)
+    const float r = (term == 0) ? g68[67] : aux.y;   // sdf term: residual is the sdf itself (loss.py:34,43)
+    const float d0 = __fmul_rn(sc, g68[64]), d1 = __fmul_rn(sc, g68[65]), d2 = __fmul_rn(sc, g68[66]);
+    row[0] = d0; row[1] = d1; row[2] = d2;
+    // [I | -[p]x | p]  (loss_utils.py:166-185)
+    row[3] = __fadd_rn(__fmul_rn(-p.z, d1), __fmul_rn(p.y, d2));
+    row[4] = __fadd_rn(__fmul_rn(p.z, d0), __fmul_rn(-p.x, d2));
+    row[5] = __fadd_rn(__fmul_rn(-p.y, d0), __fmul_rn(p.x, d1));
+    row[6] = __fadd_rn(__fadd_rn(__fmul_rn(p.x, d0), __fmul_rn(p.y, d1)), __fmul_rn(p.z, d2));
+    for (int i = 0; i < 64; ++i) row[7 + i] = __fmul_rn(sc, g68[i]);
+    float rr = r;
+    if (robust) {   // huber_norm_weights: w = sqrt(rho)/|r|, only the residual is reweighted (loss_utils.py:236-265)
+        const float a = fabsf(r);
+        const float rho = (a <= huber_b) ? __fmul_rn(a, a) : __fsub_rn(__fmul_rn(__fmul_rn(2.f, huber_b), a), __fmul_rn(huber_b, huber_b));
+        const float w = (a == 0.f) ? 0.f : __fdiv_rn(__fsqrt_rn(rho), a);
+        rr = __fmul_rn(w, r);
+    }
+    row[71] = rr;
+}
+
+constexpr int GRAM_PTS = 32;    // points staged per step
+constexpr int JLD = 73;         // LDS row stride (odd: conflict-free column access)
+
+__global__ __launch_bounds__(256) void k_gram(const ObjConst* oc, const ObjState* st, const float4* jpts, const float2* jaux,
+                                              const float* jgrad, const unsigned char* alive, float* partials, int n_slices,
+                                              float b_sdf, float b_render, int robust) {
+    __shared__ float J[GRAM_PTS * JLD];
+    const int slice = blockIdx.x, b = blockIdx.y, term = blockIdx.z;
+    const ObjConst c = oc[b];
+    const ObjState& s = st[b];
+    const int n = (s.status != DSP_STATUS_GOOD) ? 0 : (term == 0 ? c.n_pts : s.K);
+    const int off = (term == 0) ? c.jsdf_off : c.jren_off;
+    const int per = ((n + n_slices - 1) / n_slices + GRAM_PTS - 1) / GRAM_PTS * GRAM_PTS;
+    const int lo = min(slice * per, n), hi = min(lo + per, n);
+    const int tid = threadIdx.x;
+    // thread owns a 4 x 6 block of the 72 x 72 Gram matrix (18 x 12 = 216 active threads)
+    const int bi = (tid / 12) * 4, bj = (tid % 12) * 6;
+    const bool active = tid < 216;
+    float acc[4][6];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[i][j] = 0.f;
+    const float hb = (term == 0) ? b_sdf : b_render;
+    for (int p0 = lo; p0 < hi; p0 += GRAM_PTS) {
+        const int np = min(GRAM_PTS, hi - p0);
+        __syncthreads();
+        if (tid < GRAM_PTS) {
+            float* row = J + tid * JLD;
+            if (tid < np && (alive == nullptr || term != 0 || alive[off + p0 + tid])) {
+                const int idx = off + p0 + tid;
+                build_row(jgrad + (size_t)idx * GRAD_STRIDE, jpts[idx], jaux[idx], term, hb, robust, row);
+            } else {
+                for (int i = 0; i < 72; ++i) row[i] = 0.f;
+            }
+        }
+        __syncthreads();
+        if (active) {
+            for (int p = 0; p < GRAM_PTS; ++p) {
+                const float* row = J + p * JLD;
+                float a[4], bb[6];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = row[bi + i];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) bb[j] = row[bj + j];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) acc[i][j] = fmaf(a[i], bb[j], acc[i][j]);
+            }
+        }
+    }
+    if (active) {
+        float* out = partials + (((size_t)b * 2 + term) * n_slices + slice) * (72 * 72);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) out[(bi + i) * 72 + bj + j] = acc[i][j];
+    }
+}
+
+// J rows to memory, for the stand-alone compute_sdf_loss / compute_render_loss entry points
+__global__ void k_jrows(const ObjConst* oc, const ObjState* st, const float4* jpts, const float2* jaux, const float* jgrad,
+                        int term, float* rows /*[n][72]*/) {
+    const ObjConst c = oc[0];
+    const int n = (term == 0) ? c.n_pts : st[0].K;
+    const int off = (term == 0) ? c.jsdf_off : c.jren_off;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float row[72];
+    build_row(jgrad + (size_t)(off + i) * GRAD_STRIDE, jpts[off + i], jaux[off + i], term, 0.f, 0, row);
+    for (int k = 0; k < 72; ++k) rows[(size_t)i * 72 + k] = row[k];
+}
+
+// ------------------------------------------------------------------------------------------------
+// solve + update  (optimizer.py:153-192, 68-78; loss.py:155-178; loss_utils.py:129-233)
+// ------------------------------------------------------------------------------------------------
+__device__ void exp_so3_parts(const float* w, float& theta, float wh[9], float wh2[9]) {
+    wh[0] = 0.f;   wh[1] = -w[2]; wh[2] = w[1];
+    wh[3] = w[2];  wh[4] = 0.f;   wh[5] = -w[0];
+    wh[6] = -w[1]; wh[7] = w[0];  wh[8] = 0.f;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            float a = 0.f;
+            for (int k = 0; k < 3; ++k) a += wh[3 * i + k] * wh[3 * k + j];
+            wh2[3 * i + j] = a;
+        }
+    theta = sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+}
+
+__device__ void exp_sim3_dev(const float* x, float* out /*16*/) {   // loss_utils.py:188-233, quirks kept
+    const float* v = x; const float* w = x + 3; const float s = x[6];
+    float theta, wh[9], wh2[9];
+    exp_so3_parts(w, theta, wh, wh2);
+    const float t2 = theta * theta;
+    const float sn = sinf(theta), cs = cosf(theta);
+    const float es = expf(s);
+    const float s2 = s * s;
+    float ew[9], j[9];
+    const float eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (theta <= 1e-8f) {
+        const float c = (s == 0.f) ? 1.f : (es - 1.f) / s;
+        for (int i = 0; i < 9; ++i) { ew[i] = eye[i]; j[i] = c * eye[i]; }
+    } else {
+        const float a = es * sn, bq = es * cs;
+        const float c = (s <= 1e-8f) ? 0.f : (es - 1.f) / s;     // :223 -- drops the c*I term for s <= 1e-8
+        const float k1 = (a * s + (1.f - bq) * theta) / (s2 + t2);
+        const float k2 = c - ((bq - 1.f) * s + a * theta) / (s2 + t2);
+        for (int i = 0; i < 9; ++i) {
+            ew[i] = eye[i] + wh[i] * sn / theta + wh2[i] * (1.f - cs) / t2;
+            j[i] = c * eye[i] + k1 * wh[i] / theta + k2 * wh2[i] / t2;
+        }
+    }
+    for (int i = 0; i < 16; ++i) out[i] = (i % 5 == 0) ? 1.f : 0.f;
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) out[4 * r + c] = es * ew[3 * r + c];
+        out[4 * r + 3] = j[3 * r] * v[0] + j[3 * r + 1] * v[1] + j[3 * r + 2] * v[2];
+    }
+}
+
+__device__ void exp_se3_dev(const float* x, float* out /*16*/) {    // loss_utils.py:129-163
+    const float* v = x; const float* w = x + 3;
+    float theta, wh[9], wh2[9];
+    exp_so3_parts(w, theta, wh, wh2);
+    float ew[9], j[9];
+    const float eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (theta <= 1e-8f) {
+        for (int i = 0; i < 9; ++i) { ew[i] = eye[i]; j[i] = eye[i]; }
+    } else {
+        const float sn = sinf(theta), cs = cosf(theta);
+        const float t2 = theta * theta, t3 = t2 * theta;
+        const float k1 = (1.f - cs) / t2, k2 = (theta - sn) / t3;
+        for (int i = 0; i < 9; ++i) {
+            ew[i] = eye[i] + wh[i] * sn / theta + wh2[i] * (1.f - cs) / t2;
+            j[i] = eye[i] + k1 * wh[i] + k2 * wh2[i];
+        }
+    }
+    for (int i = 0; i < 16; ++i) out[i] = (i % 5 == 0) ? 1.f : 0.f;
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) out[4 * r + c] = ew[3 * r + c];
+        out[4 * r + 3] = j[3 * r] * v[0] + j[3 * r + 1] * v[1] + j[3 * r + 2] * v[2];
+    }
+}
+
+// compute_rotation_loss_sim3 (loss.py:155-178): J (7) and residual from T_oc
+__device__ void rotation_prior(const ObjState& s, float* jrot, float& res) {
+    double rco[9];
+    const double sc = (double)s.scale;
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) rco[3 * r + c] = (double)(float)((double)s.t_co[4 * r + c] / sc);
+    // r_oc = inv(r_co); for a (near-)rotation this is the adjugate / det
+    const double det = det3(rco, 3);
+    double roc[9];
+    roc[0] = (rco[4] * rco[8] - rco[5] * rco[7]) / det; roc[1] = (rco[2] * rco[7] - rco[1] * rco[8]) / det; roc[2] = (rco[1] * rco[5] - rco[2] * rco[4]) / det;
+    roc[3] = (rco[5] * rco[6] - rco[3] * rco[8]) / det; roc[4] = (rco[0] * rco[8] - rco[2] * rco[6]) / det; roc[5] = (rco[2] * rco[3] - rco[0] * rco[5]) / det;
+    roc[6] = (rco[3] * rco[7] - rco[4] * rco[6]) / det; roc[7] = (rco[1] * rco[6] - rco[0] * rco[7]) / det; roc[8] = (rco[0] * rco[4] - rco[1] * rco[3]) / det;
+    // ry = r_co e_y (column 1); res = 1 - ry . n_g, n_g = (0,-1,0)
+    const float ry1 = (float)rco[4];
+    res = 1.f - (-ry1);
+    for (int i = 0; i < 7; ++i) jrot[i] = 0.f;
+    if (res < 1e-7f) { res = 0.f; return; }
+    // J[3:6] = (r_oc n_g) x e_y ; r_oc n_g = -column 1 of r_oc
+    const float a0 = (float)(-roc[1]), a2 = (float)(-roc[7]);
+    // a x e_y = (a1*0 - a2*1, a2*0 - a0*0, a0*1 - a1*0) = (-a2, 0, a0)
+    jrot[3] = -a2; jrot[4] = 0.f; jrot[5] = a0;
+}
+
+constexpr int NSOLVE = 71;
+
+__global__ __launch_bounds__(256) void k_solve(const ObjConst* oc, ObjState* st, const float* partials, int n_slices,
+                                               GnParamsDev prm, int iter, float* trace /*nullable*/, int n_obj) {
+    __shared__ double A[NSOLVE][NSOLVE + 1];
+    __shared__ int piv;
+    __shared__ double pval;
+    __shared__ float lossv[2];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const ObjConst c = oc[b];
+    ObjState& s = st[b];
+    if (s.status != DSP_STATUS_GOOD) return;
+    // Gram entry (term, i, j) = sum of the per-slice partials (fp64 accumulation, fixed order)
+    auto gram = [&](int term, int i, int j) -> double {
+        const float* p = partials + (((size_t)b * 2 + term) * n_slices) * (72 * 72) + i * 72 + j;
+        double a = 0.0;
+        for (int sl = 0; sl < n_slices; ++sl) a += (double)p[(size_t)sl * 72 * 72];
+        return a;
+    };
+    const int M = c.n_pts, K = s.K;
+    const int pd = prm.pose_only ? 6 : 7;
+    const int n = prm.pose_only ? 6 : NSOLVE;
+    if (!prm.pose_only) {
+        // losses (optimizer.py:134-155): mean of robust residual^2; an empty set gives NaN in the reference
+        if (M == 0 || K == 0) { if (tid == 0) s.status = DSP_STATUS_NAN; return; }
+        if (tid < 2) lossv[tid] = (float)gram(tid, 71, 71) / (float)(tid == 0 ? M : K);
+        __syncthreads();
+        const float sdf_loss = lossv[0], ren_loss = lossv[1];
+        if (isnan(sdf_loss) || isnan(ren_loss)) { if (tid == 0) s.status = DSP_STATUS_NAN; return; }
+        if (tid == 0) s.loss = prm.k1 * ren_loss + prm.k2 * sdf_loss;
+        float jrot[7], res_rot;
+        rotation_prior(s, jrot, res_rot);
+        const double w_s = (double)prm.k2 / (double)M, w_r = (double)prm.k1 / (double)K;
+        for (int e = tid; e < n * (n + 1); e += 256) {
+            const int i = e / (n + 1), j = e % (n + 1);
+            double v;
+            if (j < n) {
+                v = w_s * gram(0, i, j) + w_r * gram(1, i, j);                                  // :161-168
+                if (i >= pd && i == j) v += (double)prm.k3;                                    // :170
+                if (i < pd && j < pd) v += (double)prm.k4 * (double)jrot[i] * (double)jrot[j]; // :176,178
+                if (i < pd && i == j) v += 1.0;                                                // :183
+                if (i == pd - 1 && j == pd - 1) v += (double)prm.s_damp;                       // :184
+            } else {
+                v = -(w_s * gram(0, i, 71) + w_r * gram(1, i, 71));                            // b = -J^T r~
+                if (i >= pd) v -= (double)prm.k3 * (double)s.code[i - pd];                     // :172
+                if (i < pd) v += (double)prm.k4 * (double)jrot[i] * (double)res_rot;           // :177,179 (sign as written)
+            }
+            A[i][j] = v;
+        }
+    } else {
+        // pose-only (optimizer.py:68-72): H = J6^T J6 / M + 1e-2 I, b = -J6^T r / M with the raw residual
+        const int Ma = (s.n_alive >= 0) ? s.n_alive : M;
+        if (Ma == 0) { if (tid == 0) s.status = DSP_STATUS_NAN; return; }
+        for (int e = tid; e < n * (n + 1); e += 256) {
+            const int i = e / (n + 1), j = e % (n + 1);
+            double v;
+            if (j < n) { v = gram(0, i, j) / (double)Ma; if (i == j) v += 1e-2; }
+            else v = -gram(0, i, 71) / (double)Ma;
+            A[i][j] = v;
+        }
+    }
+    __syncthreads();
+    if (trace) {   // [iter][obj][71*71 H | 71 b | 71 dx | 16 t_oc | 64 code | V m K]
+        float* tr = trace + ((size_t)iter * n_obj + b) * TRACE_STRIDE;
+        for (int e = tid; e < n * n; e += 256) tr[(e / n) * NSOLVE + (e % n)] = (float)A[e / n][e % n];
+        for (int e = tid; e < n; e += 256) tr[NSOLVE * NSOLVE + e] = (float)A[e][n];
+        if (tid < 16) tr[NSOLVE * NSOLVE + 2 * NSOLVE + tid] = s.t_oc[tid];
+        if (tid < 64) tr[NSOLVE * NSOLVE + 2 * NSOLVE + 16 + tid] = s.code[tid];
+        if (tid == 0) {
+            tr[NSOLVE * NSOLVE + 2 * NSOLVE + 80] = (float)s.V;
+            tr[NSOLVE * NSOLVE + 2 * NSOLVE + 81] = (float)s.m;
+            tr[NSOLVE * NSOLVE + 2 * NSOLVE + 82] = (float)s.K;
+        }
+    }
+    __syncthreads();
+    // 2. Gaussian elimination with partial pivoting on [H | b] in fp64 (the reference inverts H in fp32, :186)
+    for (int k = 0; k < n; ++k) {
+        if (tid == 0) {
+            int p = k; double best = fabs(A[k][k]);
+            for (int r = k + 1; r < n; ++r) { const double v = fabs(A[r][k]); if (v > best) { best = v; p = r; } }
+            piv = p; pval = A[p][k];
+        }
+        __syncthreads();
+        if (piv != k) {
+            for (int j = tid; j <= n; j += 256) { const double t = A[k][j]; A[k][j] = A[piv][j]; A[piv][j] = t; }
+            __syncthreads();
+        }
+        if (pval == 0.0 || isnan(pval)) { if (tid == 0) s.status = DSP_STATUS_NAN; return; }
+        const int rows = n - k - 1, cols = n - k;   // columns k+1..n
+        for (int e = tid; e < rows * cols; e += 256) {
+            const int r = k + 1 + e / cols, j = k + 1 + e % cols;
+            A[r][j] -= (A[r][k] / pval) * A[k][j];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        for (int i = n - 1; i >= 0; --i) {
+            double v = A[i][n];
+            for (int j = i + 1; j < n; ++j) v -= A[i][j] * A[j][n];
+            A[i][n] = v / A[i][i];
+        }
+    }
+    __syncthreads();
+    if (trace) {
+        float* tr = trace + ((size_t)iter * n_obj + b) * TRACE_STRIDE;
+        for (int e = tid; e < n; e += 256) tr[NSOLVE * NSOLVE + NSOLVE + e] = (float)A[e][n];
+    }
+    // 3. update (optimizer.py:187-192 / 73-74)
+    if (!prm.pose_only) {
+        if (tid >= 64 && tid < 64 + CODE_LEN) {
+            const int i = tid - 64;
+            s.code[i] = s.code[i] + prm.lr * (float)A[pd + i][n];
+        }
+    }
+    if (tid == 0) {
+        float dx[7], dT[16], nt[16];
+        for (int i = 0; i < pd; ++i) dx[i] = (prm.pose_only ? 1.f : prm.lr) * (float)A[i][n];
+        if (prm.pose_only) exp_se3_dev(dx, dT); else exp_sim3_dev(dx, dT);
+        for (int r = 0; r < 4; ++r)
+            for (int cc = 0; cc < 4; ++cc) {
+                float a = 0.f;
+                for (int k = 0; k < 4; ++k) a += dT[4 * r + k] * s.t_oc[4 * k + cc];
+                nt[4 * r + cc] = a;
+            }
+        for (int i = 0; i < 16; ++i) s.t_oc[i] = nt[i];
+        if (!prm.pose_only) derive_iter_state(s, prm.n_depth);
+    }
+}
+
+// pose-only inlier filter at e == 4 (optimizer.py:76-78): keep |r| <= 0.05 for the following iterations
+__global__ void k_inlier_filter(const ObjConst* oc, ObjState* st, const float* jgrad, unsigned char* alive) {
+    const int b = blockIdx.y;
+    const ObjConst c = oc[b];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c.n_pts) return;
+    const int idx = c.jsdf_off + i;
+    const bool keep = alive[idx] && fabsf(jgrad[(size_t)idx * GRAD_STRIDE + 67]) <= 0.05f;
+    alive[idx] = keep ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void k_count_alive(const ObjConst* oc, ObjState* st, const unsigned char* alive) {
+    __shared__ int part[256];
+    const int b = blockIdx.x;
+    const ObjConst c = oc[b];
+    int sum = 0;
+    for (int i = threadIdx.x; i < c.n_pts; i += 256) sum += alive[c.jsdf_off + i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) { if (threadIdx.x < d) part[threadIdx.x] += part[threadIdx.x + d]; __syncthreads(); }
+    if (threadIdx.x == 0) st[b].n_alive = part[0];
+}
+
+// final result: T_co = inv(T_oc) (optimizer.py:200; 81-84 for pose-only, which also divides the scale out)
+__global__ void k_finalize(ObjState* st, const float* scale_in, int n_obj, int pose_only, float* out_t, float* out_code,
+                           float* out_loss, int* out_status) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_obj) return;
+    const ObjState& s = st[b];
+    double toc[16], tco[16];
+    for (int i = 0; i < 16; ++i) toc[i] = (double)s.t_oc[i];
+    if (!inv4(toc, tco)) for (int i = 0; i < 16; ++i) tco[i] = nan("");
+    for (int i = 0; i < 16; ++i) {
+        float v = (float)tco[i];
+        if (pose_only && (i % 4) < 3 && i < 12) v = v / scale_in[b];
+        out_t[16 * b + i] = v;
+    }
+    for (int i = 0; i < CODE_LEN; ++i) out_code[CODE_LEN * b + i] = s.code[i];
+    out_loss[b] = s.loss;
+    out_status[b] = s.status;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side launchers (used by dsp_gn.hip)
+// ------------------------------------------------------------------------------------------------
+#define GRID2(n, B) dim3((unsigned)std::max(1, ((n) + 255) / 256), (unsigned)(B))
+
+void launch_init_state(ObjState* st, const float* t, const float* codes, const float* scale, int B, int D, int pose_only, hipStream_t s) {
+    hipLaunchKernelGGL(k_init_state, dim3((B + 63) / 64), dim3(64), 0, s, st, t, codes, scale, B, D, pose_only);
+}
+void launch_sample_count(const ObjConst* oc, const ObjState* st, const float* rays, unsigned long long* m, int* c, int D, int maxR, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_sample_count, GRID2(maxR, B), dim3(256), 0, s, oc, st, rays, m, c, D);
+}
+void launch_scan_rays(const ObjConst* oc, ObjState* st, const int* cnt, int* off, int which, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_scan_rays, dim3(B), dim3(256), 0, s, oc, st, cnt, off, which);
+}
+void launch_sample_write(const ObjConst* oc, const ObjState* st, const float* rays, const unsigned long long* m, const int* off, float4* spts, int D, int maxR, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_sample_write, GRID2(maxR, B), dim3(256), 0, s, oc, st, rays, m, off, spts, D);
+}
+void launch_surface(const ObjConst* oc, const ObjState* st, const float* pts, float4* jpts, float2* jaux, int maxM, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_surface, GRID2(maxM, B), dim3(256), 0, s, oc, st, pts, jpts, jaux);
+}
+void launch_build_tiles(const ObjConst* oc, const ObjState* st, int B, int mode, int4* tiles, int* n_tiles, double* counters, hipStream_t s) {
+    hipLaunchKernelGGL(k_build_tiles, dim3(1), dim3(256), 0, s, oc, st, B, mode, tiles, n_tiles, counters);
+}
+void launch_render_scan(const ObjConst* oc, const ObjState* st, const unsigned long long* m, const int* off, const float* ssdf, const float* depth,
+                        float* sdeds, float* ray_res, int* kcnt, int* mcnt, int D, float th, int maxR, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_render_scan, GRID2(maxR, B), dim3(256), 0, s, oc, st, m, off, ssdf, depth, sdeds, ray_res, kcnt, mcnt, D, th);
+}
+void launch_render_write(const ObjConst* oc, const ObjState* st, const int* raycnt, const int* rayoff, const int* koff, const float4* spts,
+                         const float* sdeds, const float* ray_res, float4* jpts, float2* jaux, int maxR, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_render_write, GRID2(maxR, B), dim3(256), 0, s, oc, st, raycnt, rayoff, koff, spts, sdeds, ray_res, jpts, jaux);
+}
+void launch_sum_m(const ObjConst* oc, ObjState* st, const int* mcnt, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_sum_m, dim3(B), dim3(256), 0, s, oc, st, mcnt);
+}
+void launch_gram(const ObjConst* oc, const ObjState* st, const float4* jpts, const float2* jaux, const float* jgrad, const unsigned char* alive,
+                 float* partials, int n_slices, float b_sdf, float b_render, int robust, int n_terms, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_gram, dim3(n_slices, B, n_terms), dim3(256), 0, s, oc, st, jpts, jaux, jgrad, alive, partials, n_slices, b_sdf, b_render, robust);
+}
+void launch_jrows(const ObjConst* oc, const ObjState* st, const float4* jpts, const float2* jaux, const float* jgrad, int term, float* rows, int cap, hipStream_t s) {
+    hipLaunchKernelGGL(k_jrows, dim3((cap + 255) / 256), dim3(256), 0, s, oc, st, jpts, jaux, jgrad, term, rows);
+}
+void launch_solve(const ObjConst* oc, ObjState* st, const float* partials, int n_slices, const GnParamsDev& prm, int iter, float* trace, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_solve, dim3(B), dim3(256), 0, s, oc, st, partials, n_slices, prm, iter, trace, B);
+}
+void launch_inlier_filter(const ObjConst* oc, ObjState* st, const float* jgrad, unsigned char* alive, int maxM, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_inlier_filter, GRID2(maxM, B), dim3(256), 0, s, oc, st, jgrad, alive);
+    hipLaunchKernelGGL(k_count_alive, dim3(B), dim3(256), 0, s, oc, st, alive);
+}
+void launch_finalize(ObjState* st, const float* scale, int B, int pose_only, float* t, float* code, float* loss, int* status, hipStream_t s) {
+    hipLaunchKernelGGL(k_finalize, dim3((B + 63) / 64), dim3(64), 0, s, st, scale, B, pose_only, t, code, loss, status);
+}
+
+}  // namespace dsp

@@ -1,0 +1,326 @@
+// DeepSDF decoder forward / forward+input-gradient for gfx950 (MI355X), fp32 MFMA.
+//
+// Replaces, for batches of object-frame points:
+//   decode_sdf              reconstruct/loss_utils.py:51-79   (mlp_kernel<false>)
+//   get_batch_sdf_jacobian  reconstruct/loss_utils.py:82-103  (mlp_kernel<true>)
+//   Decoder.forward         deep_sdf/deep_sdf_decoder.py:75-110
+//
+// Design (DESIGN.md "K1/K2"):  one workgroup = 4 waves = one 64-point tile, one wave per SIMD with the
+// whole 512-entry register file.  Each wave owns 16 points and keeps its [512 rows x 16 points]
+// activation slab IN REGISTERS for the whole network: v_mfma_f32_16x16x4_f32 produces D[row][pt] with
+// lane (pt = l&15, g = l>>4) holding rows 4g..4g+3 of each 16-row tile -- which is exactly the B-operand
+// layout (k = l>>4) of the next layer if that layer's weights are packed with the matching k
+// permutation.  So activations never touch LDS or HBM; only the weights stream through a 6-deep LDS
+// ring filled by LDS-DMA (global_load_lds_dwordx4) with counted vmcnt waits and one s_barrier per
+// 16 KiB chunk (64 MFMAs per wave).  ReLU masks for the backward sweep live in LDS (32 KiB).
+#include "dsp_internal.h"
+
+namespace dsp {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int NBUF = 6;                       // LDS ring depth (chunks)
+constexpr int BIAS_ROWS_MAX = 9;              // 8 hidden biases + final-layer weights
+constexpr int BIAS_BYTES = BIAS_ROWS_MAX * WIDTH * 4;      // 18 KiB
+constexpr int MASK_SLOTS = 8;
+constexpr int MASK_BYTES = MASK_SLOTS * 8 * 256 * 2;       // [slot][og][tid] u16 = 32 KiB
+constexpr int GLDS_PER_CHUNK = 4;             // per wave: 4 x 1 KiB pieces of a 16 KiB chunk
+
+#define MFMA16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x4f32((A), (B), (C), 0, 0, 0)
+
+// LDS-DMA of 64 lanes x 16 B: global (per-lane address) -> LDS (wave-uniform base + lane*16).
+// Invisible to hipcc's s_waitcnt bookkeeping by design: completion is counted by hand below.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
+}
+
+#define FOR16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
+
+template <bool BWD>
+__global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4;    // MFMA k index of this lane group == 4-row block inside a 16-row tile
+    const int pl = lane & 15;   // point of this lane inside the wave
+
+    float* bias_l = reinterpret_cast<float*>(smem);
+    unsigned short* mask_l = reinterpret_cast<unsigned short*>(smem + BIAS_BYTES);
+    char* ring_ptr = smem + BIAS_BYTES + (BWD ? MASK_BYTES : 0);
+    const unsigned ring0 = lds_addr(ring_ptr);
+
+    const int n_tiles = *a.n_tiles;
+    if ((int)blockIdx.x >= n_tiles) return;
+    for (int i = tid; i < a.n_bias_rows * WIDTH; i += 256) bias_l[i] = a.bias_tab[i];
+    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- weight stream state (all wave-uniform) ---------------------------------------------------
+    int issue_pos = 0, issue_slot = 0, rd_slot = 0;
+    const char* wbase = reinterpret_cast<const char*>(a.wstream) + wave * 4096 + lane * 16;
+    const int total_chunks = a.total_chunks;
+    auto issue = [&]() {
+        const char* src = wbase + (size_t)issue_pos * CHUNK_BYTES;
+        const unsigned dst = ring0 + issue_slot * CHUNK_BYTES + wave * 4096;
+        glds16(src, dst);
+        glds16(src + 1024, dst + 1024);
+        glds16(src + 2048, dst + 2048);
+        glds16(src + 3072, dst + 3072);
+        issue_pos = (issue_pos + 1 == total_chunks) ? 0 : issue_pos + 1;
+        issue_slot = (issue_slot + 1 == NBUF) ? 0 : issue_slot + 1;
+    };
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; ++i) issue();
+    // chunk 0 visible to every wave; from here on the barrier for chunk q+1 sits in the middle of chunk q
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(GLDS_PER_CHUNK * (NBUF - 2)) : "memory");
+    f32x4 abuf[3];   // A operands run two k-steps ahead of the MFMAs, across chunk / group / pass seams
+    abuf[0] = *reinterpret_cast<const f32x4*>(ring_ptr + lane * 16);
+    abuf[1] = *reinterpret_cast<const f32x4*>(ring_ptr + lane * 16 + 1024);
+
+    float sin_[128];   // input slab of the current pass:  sin_[4t+r] = row 16t + 4g + r of point pl
+    float sout[128];   // output slab being produced
+#pragma unroll
+    for (int i = 0; i < 128; ++i) { sin_[i] = 0.f; sout[i] = 0.f; }
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int4 td = a.tiles[tile];
+        const int local = wave * WAVE_PTS + pl;
+        const bool valid = local < td.y;
+        const int pidx = td.x + (valid ? local : 0);
+        float4 pt = a.pts[pidx];
+        if (!valid) pt = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float pcoord = (g == 0) ? pt.x : (g == 1) ? pt.y : (g == 2) ? pt.z : 0.f;
+        float zr[16];   // zr[4t+r] = code[16t + 4g + r]
+        {
+            const float4* cz = reinterpret_cast<const float4*>(a.codes + (size_t)td.z * a.code_stride);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float4 v = cz[4 * t + g];
+                zr[4 * t + 0] = v.x; zr[4 * t + 1] = v.y; zr[4 * t + 2] = v.z; zr[4 * t + 3] = v.w;
+            }
+        }
+        float skipc[16];
+        float skipx[3];
+        float y = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) skipc[i] = 0.f;
+        skipx[0] = skipx[1] = skipx[2] = 0.f;
+
+        for (int ps = 0; ps < a.n_pass; ++ps) {
+            const PassDesc pd = a.pass[ps];
+            // ---- pass prologue: inject code / xyz rows -------------------------------------------
+            if (pd.kind == 0) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sin_[i] = zr[i];
+                sin_[16] = pcoord;
+#pragma unroll
+                for (int i = 17; i < 32; ++i) sin_[i] = 0.f;
+            } else if (pd.kind == 2) {
+                if (g == 3) { sin_[109] = pt.x; sin_[110] = pt.y; sin_[111] = pt.z; }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sin_[112 + i] = zr[i];
+            }
+
+            for (int og = 0; og < pd.nog; ++og) {
+                f32x4 acc[4];
+                if (pd.bias_row >= 0) {
+                    const float* bp = bias_l + pd.bias_row * WIDTH + 64 * og + 4 * g;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] = *reinterpret_cast<const f32x4*>(bp + 16 * j);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    if (c < pd.nchunks) {
+                        const int nx_slot = (rd_slot + 1 == NBUF) ? 0 : rd_slot + 1;
+                        const char* cb = ring_ptr + rd_slot * CHUNK_BYTES + lane * 16;
+                        const char* nb = ring_ptr + nx_slot * CHUNK_BYTES + lane * 16;
+#pragma unroll
+                        for (int s = 0; s < KSTEPS_PER_CHUNK; ++s) {
+                            if (s == KSTEPS_PER_CHUNK / 2) {
+                                // Chunk q+1 has landed for this wave once <= NBUF-3 younger chunks are in flight; the
+                                // barrier publishes every wave's quarter and proves all reads of chunk q-1 retired
+                                // (every wave is inside chunk q), so its slot can be refilled right away.
+                                asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(GLDS_PER_CHUNK * (NBUF - 3)) : "memory");
+                                issue();
+                            }
+                            const int sp = s + 2;
+                            abuf[sp % 3] = (sp < KSTEPS_PER_CHUNK)
+                                               ? *reinterpret_cast<const f32x4*>(cb + sp * 1024)
+                                               : *reinterpret_cast<const f32x4*>(nb + (sp - KSTEPS_PER_CHUNK) * 1024);
+                            const f32x4 av = abuf[s % 3];
+                            const float b = sin_[16 * c + s];
+                            acc[0] = MFMA16(av.x, b, acc[0]);
+                            acc[1] = MFMA16(av.y, b, acc[1]);
+                            acc[2] = MFMA16(av.z, b, acc[2]);
+                            acc[3] = MFMA16(av.w, b, acc[3]);
+                            // pin "read for k-step s+2, then the four MFMAs of k-step s": left alone, hipcc sinks
+                            // every ds_read next to its use (one A buffer, lgkmcnt(0) before each MFMA quad)
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        rd_slot = nx_slot;
+                    }
+                }
+                // ---- output-group epilogue --------------------------------------------------------
+                float v[16];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[4 * j + 0] = acc[j].x; v[4 * j + 1] = acc[j].y; v[4 * j + 2] = acc[j].z; v[4 * j + 3] = acc[j].w;
+                }
+                if (pd.relu) {
+                    unsigned bits = 0;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        bits |= (v[k] > 0.f ? 1u : 0u) << k;
+                        v[k] = fmaxf(v[k], 0.f);
+                    }
+                    if (BWD) mask_l[(pd.mask_slot * 8 + og) * 256 + tid] = (unsigned short)bits;
+                } else if (BWD && pd.mask_slot >= 0) {
+                    if (pd.kind == 4) {
+                        // latent_in layer: rows 445..447 / 448..511 of its input are the re-injected xyz / code, not
+                        // relu outputs -- keep their gradients (unmasked) for the final d/d[code,xyz] sum
+                        if (og == 6) { skipx[0] = v[13]; skipx[1] = v[14]; skipx[2] = v[15]; }
+                        if (og == 7) {
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) skipc[k] = v[k];
+                        }
+                    }
+                    const unsigned bits = mask_l[(pd.mask_slot * 8 + og) * 256 + tid];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) v[k] = ((bits >> k) & 1u) ? v[k] : 0.f;
+                }
+#define ST(K) sout[BASE + K] = v[K];
+                switch (og) {
+#define BASE 0
+                    case 0: FOR16(ST) break;
+#undef BASE
+#define BASE 16
+                    case 1: FOR16(ST) break;
+#undef BASE
+#define BASE 32
+                    case 2: FOR16(ST) break;
+#undef BASE
+#define BASE 48
+                    case 3: FOR16(ST) break;
+#undef BASE
+#define BASE 64
+                    case 4: FOR16(ST) break;
+#undef BASE
+#define BASE 80
+                    case 5: FOR16(ST) break;
+#undef BASE
+#define BASE 96
+                    case 6: FOR16(ST) break;
+#undef BASE
+#define BASE 112
+                    default: FOR16(ST) break;
+#undef BASE
+                }
+#undef ST
+            }
+
+            // ---- pass epilogue ---------------------------------------------------------------------
+#pragma unroll
+            for (int i = 0; i < 128; ++i) sin_[i] = sout[i];
+
+            if (ps == a.n_fwd - 1) {
+                // final layer (512 -> 1) on the VALU + tanh  (deep_sdf_decoder.py:93,107-108)
+                const float* wl = bias_l + (a.n_bias_rows - 1) * WIDTH + 4 * g;
+                float part = 0.f;
+#pragma unroll
+                for (int t = 0; t < 32; ++t) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(wl + 16 * t);
+                    part = fmaf(sin_[4 * t + 0], w4.x, part);
+                    part = fmaf(sin_[4 * t + 1], w4.y, part);
+                    part = fmaf(sin_[4 * t + 2], w4.z, part);
+                    part = fmaf(sin_[4 * t + 3], w4.w, part);
+                }
+                part += __shfl_xor(part, 16);
+                part += __shfl_xor(part, 32);
+                y = tanhf(part + a.b_last);
+                if (!BWD) {
+                    if (valid && g == 0) a.out_sdf[pidx] = y;
+                } else {
+                    // seed of the backward sweep: d tanh * W_last, masked by the last hidden relu
+                    const float d = 1.f - y * y;
+                    const int slot = pd.mask_slot;
+#pragma unroll
+                    for (int o = 0; o < 8; ++o) {
+                        const unsigned bits = mask_l[(slot * 8 + o) * 256 + tid];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const f32x4 w4 = *reinterpret_cast<const f32x4*>(wl + 16 * (4 * o + j));
+                            sin_[16 * o + 4 * j + 0] = ((bits >> (4 * j + 0)) & 1u) ? d * w4.x : 0.f;
+                            sin_[16 * o + 4 * j + 1] = ((bits >> (4 * j + 1)) & 1u) ? d * w4.y : 0.f;
+                            sin_[16 * o + 4 * j + 2] = ((bits >> (4 * j + 2)) & 1u) ? d * w4.z : 0.f;
+                            sin_[16 * o + 4 * j + 3] = ((bits >> (4 * j + 3)) & 1u) ? d * w4.w : 0.f;
+                        }
+                    }
+                }
+            }
+        }
+
+        if (BWD) {
+            // sin_ now holds d y / d [code rows 0..63 | xyz at rows 64,68,72]  (first-layer part)
+            float* orow = a.out_grad + (size_t)pidx * GRAD_STRIDE;
+            if (valid) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    float4 o4;
+                    o4.x = sin_[4 * t + 0] + skipc[4 * t + 0];
+                    o4.y = sin_[4 * t + 1] + skipc[4 * t + 1];
+                    o4.z = sin_[4 * t + 2] + skipc[4 * t + 2];
+                    o4.w = sin_[4 * t + 3] + skipc[4 * t + 3];
+                    *reinterpret_cast<float4*>(orow + 16 * t + 4 * g) = o4;
+                }
+            }
+            const float s0 = __shfl(skipx[0], pl + 48);
+            const float s1 = __shfl(skipx[1], pl + 48);
+            const float s2 = __shfl(skipx[2], pl + 48);
+            const float sk = (g == 0) ? s0 : (g == 1) ? s1 : s2;
+            if (valid) orow[64 + g] = (g < 3) ? (sin_[16] + sk) : y;
+        }
+        // stores and LDS-DMA share vmcnt and may retire out of order: drain before counting again
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template __global__ void mlp_kernel<false>(const MlpArgs);
+template __global__ void mlp_kernel<true>(const MlpArgs);
+
+size_t mlp_lds_bytes(bool bwd) { return BIAS_BYTES + (bwd ? MASK_BYTES : 0) + NBUF * CHUNK_BYTES; }
+
+hipError_t launch_mlp(bool bwd, const MlpArgs& args, int n_blocks, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)mlp_lds_bytes(false));
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)mlp_lds_bytes(true));
+        attr_set = true;
+    }
+    if (bwd)
+        hipLaunchKernelGGL(mlp_kernel<true>, dim3(n_blocks), dim3(256), mlp_lds_bytes(true), stream, args);
+    else
+        hipLaunchKernelGGL(mlp_kernel<false>, dim3(n_blocks), dim3(256), mlp_lds_bytes(false), stream, args);
+    return hipGetLastError();
+}
+
+}  // namespace dsp

@@ -1,0 +1,202 @@
+"""Python face of libdspgn: one Engine per (decoder, GPU).  Thin: marshals numpy arrays into the C ABI.
+
+Everything numeric happens in the HIP library; there is no CPU or PyTorch fallback.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def gn_params(k1=1.0, k2=100.0, k3=0.25, k4=1e7, b1=0.2, b2=0.025, lr=1.0, s_damp=1.0, num_iterations=10,
+              num_depth_samples=50, cut_off=0.01, pose_only_iterations=5):
+    return L.GnParams(k1, k2, k3, k4, b1, b2, lr, s_damp, int(num_iterations), int(num_depth_samples), cut_off,
+                      int(pose_only_iterations))
+
+
+def params_from_configs(configs):
+    """Hyper-parameters as Optimizer.__init__ reads them (reference reconstruct/optimizer.py:27-43)."""
+    o = configs["optimizer"] if isinstance(configs, dict) else configs.optimizer
+    get = (lambda d, k: d[k]) if isinstance(o, dict) else getattr
+    j = get(o, "joint_optim")
+    try:
+        pose_it = get(get(o, "pose_only_optim"), "num_iterations")
+    except (KeyError, AttributeError):
+        pose_it = 5
+    return gn_params(get(j, "k1"), get(j, "k2"), get(j, "k3"), get(j, "k4"), get(j, "b1"), get(j, "b2"),
+                     get(j, "learning_rate"), get(j, "scale_damping"), get(j, "num_iterations"),
+                     get(o, "num_depth_samples"), get(o, "cut_off_threshold"), pose_it)
+
+
+def _ragged(arrays, width):
+    """list of (n_i, width) arrays -> (offsets int64 (B+1), flat float32 (sum n_i, width))."""
+    arrays = [L.f32(a).reshape(-1, width) if width else L.f32(a).reshape(-1) for a in arrays]
+    off = np.zeros(len(arrays) + 1, np.int64)
+    off[1:] = np.cumsum([a.shape[0] for a in arrays])
+    flat = np.concatenate(arrays, 0) if arrays else np.zeros((0, width), np.float32)
+    if flat.size == 0:
+        flat = np.zeros((1, width) if width else (1,), np.float32)
+    return off, np.ascontiguousarray(flat, np.float32)
+
+
+class Batch(object):
+    """Device-resident batch of objects (dsp_batch_*): upload once, run many times."""
+
+    def __init__(self, engine, prm, t_cam_obj, pts, rays, depth, codes=None, trace=False):
+        self.engine = engine
+        self.n = len(pts)
+        self._keep = (
+            _ragged(pts, 3), _ragged(rays, 3), _ragged(depth, 0),
+            L.f32(np.stack([np.asarray(t, np.float32).reshape(4, 4) for t in t_cam_obj])),
+            None if codes is None else L.f32(np.stack([np.asarray(c, np.float32)[:L.CODE_LEN] for c in codes])),
+        )
+        (po, p), (ro, r), (do, d), t, c = self._keep
+        self._h = C.c_void_p()
+        lib = L.load()
+        L.check(lib.dsp_batch_create(engine._h, C.byref(prm), self.n, L.ptr(po, L.c_i64p), L.ptr(p), L.ptr(ro, L.c_i64p),
+                                     L.ptr(r), L.ptr(do, L.c_i64p), L.ptr(d), L.ptr(t), L.ptr(c), C.byref(self._h)),
+                engine._h, "dsp_batch_create")
+        self.iters = prm.num_iterations
+        if trace:
+            L.check(lib.dsp_batch_enable_trace(self._h, 1), engine._h, "dsp_batch_enable_trace")
+
+    def run(self):
+        L.check(L.load().dsp_batch_run(self._h), self.engine._h, "dsp_batch_run")
+
+    def results(self):
+        n = self.n
+        t = np.zeros((n, 4, 4), np.float32)
+        code = np.zeros((n, L.CODE_LEN), np.float32)
+        loss = np.zeros(n, np.float32)
+        status = np.zeros(n, np.int32)
+        L.check(L.load().dsp_batch_results(self._h, L.ptr(t), L.ptr(code), L.ptr(loss), L.ptr(status, L.c_i32p)),
+                self.engine._h, "dsp_batch_results")
+        return t, code, loss, status
+
+    def stats(self):
+        s = L.Stats()
+        L.check(L.load().dsp_batch_stats(self._h, C.byref(s)), self.engine._h, "dsp_batch_stats")
+        return {k: getattr(s, k) for k, _ in L.Stats._fields_}
+
+    def trace(self, iteration):
+        n = self.n
+        out = dict(H=np.zeros((n, 71, 71), np.float32), b=np.zeros((n, 71), np.float32), dx=np.zeros((n, 71), np.float32),
+                   V=np.zeros(n, np.int64), m=np.zeros(n, np.int64), K=np.zeros(n, np.int64),
+                   t_obj_cam=np.zeros((n, 4, 4), np.float32), code=np.zeros((n, L.CODE_LEN), np.float32))
+        L.check(L.load().dsp_batch_trace(self._h, int(iteration), L.ptr(out["H"]), L.ptr(out["b"]), L.ptr(out["dx"]),
+                                         L.ptr(out["V"], L.c_i64p), L.ptr(out["m"], L.c_i64p), L.ptr(out["K"], L.c_i64p),
+                                         L.ptr(out["t_obj_cam"]), L.ptr(out["code"])), self.engine._h, "dsp_batch_trace")
+        return out
+
+    def close(self):
+        if self._h:
+            L.load().dsp_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Engine(object):
+    """Owns a dsp_handle: packed decoder weights on one MI355X + a HIP stream."""
+
+    def __init__(self, layers, latent_in, code_len=64, device=0):
+        """layers: list of (W (out,in), b (out,)) float32 with weight-norm already folded."""
+        lib = L.load()
+        self._desc = L.DecoderDescHolder(layers, latent_in, code_len)
+        self._h = C.c_void_p()
+        rc = lib.dsp_create(C.byref(self._desc.desc), int(device), C.byref(self._h))
+        if rc != 0:
+            msg = lib.dsp_last_error(None)
+            raise L.DspError("dsp_create failed (%d): %s" % (rc, msg.decode() if msg else "?"))
+        self.device = int(device)
+        self.code_len = int(code_len)
+
+    # -- decoder ------------------------------------------------------------------------------------
+    def decode_sdf(self, code, pts):
+        pts = L.f32(pts).reshape(-1, 3)
+        code = L.f32(code).reshape(-1)[:L.CODE_LEN]
+        out = np.zeros(pts.shape[0], np.float32)
+        L.check(L.load().dsp_decode_sdf(self._h, L.ptr(code), L.ptr(pts), pts.shape[0], L.ptr(out)), self._h, "dsp_decode_sdf")
+        return out
+
+    def sdf_jacobian(self, code, pts):
+        pts = L.f32(pts).reshape(-1, 3)
+        code = L.f32(code).reshape(-1)[:L.CODE_LEN]
+        n = pts.shape[0]
+        sdf = np.zeros(n, np.float32)
+        grad = np.zeros((n, L.GRAD_DIM), np.float32)
+        L.check(L.load().dsp_sdf_jacobian(self._h, L.ptr(code), L.ptr(pts), n, L.ptr(sdf), L.ptr(grad)), self._h, "dsp_sdf_jacobian")
+        return sdf, grad
+
+    # -- residual terms -----------------------------------------------------------------------------
+    def compute_sdf_loss(self, pts_cam, t_obj_cam, code):
+        pts = L.f32(pts_cam).reshape(-1, 3)
+        n = pts.shape[0]
+        t = L.f32(t_obj_cam).reshape(4, 4)
+        code = L.f32(code).reshape(-1)[:L.CODE_LEN]
+        j7 = np.zeros((n, 7), np.float32)
+        jc = np.zeros((n, L.CODE_LEN), np.float32)
+        r = np.zeros(n, np.float32)
+        L.check(L.load().dsp_compute_sdf_loss(self._h, L.ptr(pts), n, L.ptr(t), L.ptr(code), L.ptr(j7), L.ptr(jc), L.ptr(r)),
+                self._h, "dsp_compute_sdf_loss")
+        return j7, jc, r
+
+    def compute_render_loss(self, rays, depth_obs, t_obj_cam, sampled_depth, code, th=0.01):
+        rays = L.f32(rays).reshape(-1, 3)
+        depth_obs = L.f32(depth_obs).reshape(-1)
+        sampled = L.f32(sampled_depth).reshape(-1)
+        t = L.f32(t_obj_cam).reshape(4, 4)
+        code = L.f32(code).reshape(-1)[:L.CODE_LEN]
+        cap = rays.shape[0] * sampled.shape[0]
+        j7 = np.zeros((cap, 7), np.float32)
+        jc = np.zeros((cap, L.CODE_LEN), np.float32)
+        r = np.zeros(cap, np.float32)
+        k = C.c_int64(0)
+        v = C.c_int64(0)
+        m = C.c_int64(0)
+        L.check(L.load().dsp_compute_render_loss(self._h, L.ptr(rays), rays.shape[0], L.ptr(depth_obs), L.ptr(t), L.ptr(sampled),
+                                                 sampled.shape[0], L.ptr(code), float(th), C.byref(k), L.ptr(j7), L.ptr(jc),
+                                                 L.ptr(r), C.byref(v), C.byref(m)), self._h, "dsp_compute_render_loss")
+        stats = dict(V=v.value, m=m.value, K=k.value)
+        if k.value < 0:
+            return None, stats
+        return (j7[:k.value].copy(), jc[:k.value].copy(), r[:k.value].copy()), stats
+
+    # -- optimiser ----------------------------------------------------------------------------------
+    def batch(self, prm, t_cam_obj, pts, rays, depth, codes=None, trace=False):
+        return Batch(self, prm, t_cam_obj, pts, rays, depth, codes, trace)
+
+    def reconstruct_batch(self, prm, t_cam_obj, pts, rays, depth, codes=None):
+        b = Batch(self, prm, t_cam_obj, pts, rays, depth, codes)
+        try:
+            b.run()
+            return b.results()
+        finally:
+            b.close()
+
+    def estimate_pose_batch(self, prm, t_co_se3, scale, pts, codes):
+        n = len(pts)
+        po, p = _ragged(pts, 3)
+        t = L.f32(np.stack([np.asarray(x, np.float32).reshape(4, 4) for x in t_co_se3]))
+        sc = L.f32(np.asarray(scale, np.float32).reshape(n))
+        cd = L.f32(np.stack([np.asarray(c, np.float32)[:L.CODE_LEN] for c in codes]))
+        out = np.zeros((n, 4, 4), np.float32)
+        L.check(L.load().dsp_estimate_pose_batch(self._h, C.byref(prm), n, L.ptr(po, L.c_i64p), L.ptr(p), L.ptr(t), L.ptr(sc),
+                                                 L.ptr(cd), L.ptr(out)), self._h, "dsp_estimate_pose_batch")
+        return out
+
+    def close(self):
+        if self._h:
+            L.load().dsp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,129 @@
+"""Optimizer / MeshExtractor -- mirror of reference reconstruct/optimizer.py:26-223.
+
+Same constructor arguments, method names, argument meaning and result fields as the reference, so that
+DSP-SLAM's C++ (src/LocalMapping.cc:38-40; src/LocalMapping_util.cc:109-110,179-196,391-426) can call it
+unchanged.  The whole Gauss-Newton loop (all iterations) runs on the MI355X inside libdspgn with no host
+round trip; `reconstruct_objects` / `estimate_poses_cam_obj` are the batched forms (new, for many
+independent objects per call).
+"""
+import numpy as np
+import torch
+
+from reconstruct.utils import ForceKeyErrorDict, create_voxel_grid, convert_sdf_voxels_to_mesh
+from reconstruct.loss_utils import get_time
+from dsp_slam_amd import engine as _engine
+from dsp_slam_amd import _lib as _L
+
+
+def _f32(a):
+    """Eigen hands over Fortran-ordered float32 copies (pybind11 eigen caster); accept any strides / dtype."""
+    if hasattr(a, "detach"):
+        a = a.detach().cpu().numpy()
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Optimizer(object):
+    def __init__(self, decoder, configs):
+        self.decoder = decoder
+        optim_cfg = configs.optimizer
+        self.k1 = optim_cfg.joint_optim.k1
+        self.k2 = optim_cfg.joint_optim.k2
+        self.k3 = optim_cfg.joint_optim.k3
+        self.k4 = optim_cfg.joint_optim.k4
+        self.b1 = optim_cfg.joint_optim.b1
+        self.b2 = optim_cfg.joint_optim.b2
+        self.lr = optim_cfg.joint_optim.learning_rate
+        self.s_damp = optim_cfg.joint_optim.scale_damping
+        self.num_iterations_joint_optim = optim_cfg.joint_optim.num_iterations
+        self.code_len = optim_cfg.code_len
+        self.num_depth_samples = optim_cfg.num_depth_samples
+        self.cut_off = optim_cfg.cut_off_threshold
+        self.num_iterations_pose_only = 5
+        if configs.data_type == "KITTI":
+            self.num_iterations_pose_only = optim_cfg.pose_only_optim.num_iterations
+        if self.code_len != _L.CODE_LEN:
+            raise NotImplementedError("the MI355X decoder kernel is built for 64-D codes (got %d)" % self.code_len)
+        self.verbose = True
+
+    def _params(self):
+        return _engine.gn_params(self.k1, self.k2, self.k3, self.k4, self.b1, self.b2, self.lr, self.s_damp,
+                                 self.num_iterations_joint_optim, self.num_depth_samples, self.cut_off,
+                                 self.num_iterations_pose_only)
+
+    # ---- pose only (reference optimizer.py:45-86) ---------------------------------------------------
+    def estimate_poses_cam_obj(self, t_co_se3_list, scales, pts_list, codes):
+        """Batched form: lists of per-object inputs -> (B,4,4) float32 array of optimised SE(3) poses."""
+        return self.decoder.engine.estimate_pose_batch(self._params(), [_f32(t) for t in t_co_se3_list], scales,
+                                                       [_f32(p) for p in pts_list], [_f32(c) for c in codes])
+
+    def estimate_pose_cam_obj(self, t_co_se3, scale, pts, code):
+        """
+        :param t_co_se3: o2c transformation (4, 4) in SE(3)
+        :param scale: object scale
+        :param pts: surface points (M, 3)
+        :param code: shape code
+        :return: optimized o2c transformation (torch.Tensor (4,4), as the reference returns)
+        """
+        out = self.estimate_poses_cam_obj([t_co_se3], [float(scale)], [pts], [code])
+        return torch.from_numpy(out[0].copy())
+
+    # ---- joint shape + pose (reference optimizer.py:88-203) -----------------------------------------
+    def reconstruct_objects(self, t_cam_obj_list, pts_list, rays_list, depth_list, codes=None):
+        """Batched form: B independent objects in one device run -> list of result dicts."""
+        B = len(pts_list)
+        codes_in = None
+        if codes is not None:
+            codes_in = [np.zeros(self.code_len, np.float32) if c is None else _f32(c)[:self.code_len] for c in codes]
+        t, code, loss, status = self.decoder.engine.reconstruct_batch(
+            self._params(), [_f32(x) for x in t_cam_obj_list], [_f32(p) for p in pts_list],
+            [_f32(r) for r in rays_list], [_f32(d).reshape(-1) for d in depth_list], codes_in)
+        out = []
+        for i in range(B):
+            if status[i] == _L.OBJ_GOOD:
+                out.append(ForceKeyErrorDict(t_cam_obj=t[i].copy(), code=code[i].copy(), is_good=True,
+                                             loss=torch.tensor(float(loss[i]))))
+            else:   # reference: t_cam_obj=None, code=None, is_good=False, loss=<last computed loss> (:131,136,143,150)
+                out.append(ForceKeyErrorDict(t_cam_obj=None, code=None, is_good=False, loss=float(loss[i])))
+        return out
+
+    def reconstruct_object(self, t_cam_obj, pts, rays, depth, code=None):
+        """
+        :param t_cam_obj: object pose, object-to-camera transformation
+        :param pts: surface points, under camera coordinate (M, 3)
+        :param rays: sampled ray directions (N, 3)
+        :param depth: depth values (K,) only contain foreground pixels, K = M for KITTI
+        :return: optimized opject pose and shape, saved as a dict
+        """
+        start = get_time()
+        rst = self.reconstruct_objects([t_cam_obj], [pts], [rays], [depth], None if code is None else [code])[0]
+        if self.verbose and rst.is_good:
+            print("Reconstruction takes %f seconds" % (get_time() - start))
+        return rst
+
+    @staticmethod
+    def get_shape_code(result):
+        """Shape code of a reconstruction result (the C++ side keeps it in MapObject::GetShapeCode,
+        src/MapObject.cc:469-473).  Addition named by BASELINE.json; not present in the reference's Python."""
+        return result.code
+
+
+class MeshExtractor(object):
+    def __init__(self, decoder, code_len=64, voxels_dim=64):
+        self.decoder = decoder
+        self.code_len = code_len
+        self.voxels_dim = voxels_dim
+        self.voxel_points = create_voxel_grid(vol_dim=self.voxels_dim)
+
+    def decode_grid(self, code):
+        """SDF on the voxels_dim^3 grid, decoded on the GPU (the part of extract_mesh_from_code that is
+        decoder work, reference optimizer.py:217-218)."""
+        sdf = self.decoder.engine.decode_sdf(_f32(code)[:self.code_len], self.voxel_points)
+        return sdf.reshape(self.voxels_dim, self.voxels_dim, self.voxels_dim)
+
+    def extract_mesh_from_code(self, code):
+        start = get_time()
+        vertices, faces = convert_sdf_voxels_to_mesh(self.decode_grid(code))
+        vertices = vertices.astype("float32")
+        faces = faces.astype("int32")
+        print("Extract mesh takes %f seconds" % (get_time() - start))
+        return ForceKeyErrorDict(vertices=vertices, faces=faces)

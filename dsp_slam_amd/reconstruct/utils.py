@@ -1,0 +1,71 @@
+"""Config / decoder plumbing -- mirror of reference reconstruct/utils.py:82-116 (the parts on the hot path)."""
+import json
+
+import numpy as np
+
+from deep_sdf.workspace import config_decoder
+
+
+class ForceKeyErrorDict(dict):
+    """Attribute-access dict that raises KeyError on a missing key (reference utils.py:82-84, there an
+    addict.Dict subclass; addict is not required here)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        for a in args:
+            for k, v in dict(a).items():
+                self[k] = v
+        for k, v in kwargs.items():
+            self[k] = v
+
+    def __setitem__(self, k, v):
+        if isinstance(v, dict) and not isinstance(v, ForceKeyErrorDict):
+            v = ForceKeyErrorDict(v)
+        super().__setitem__(k, v)
+
+    def __getattr__(self, k):
+        if k.startswith("__"):
+            raise AttributeError(k)
+        return self[k]          # KeyError on a missing key, as the reference's __missing__ does
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def __missing__(self, key):
+        raise KeyError(key)
+
+
+def get_configs(cfg_file):
+    with open(cfg_file) as f:
+        cfg_dict = json.load(f)
+    return ForceKeyErrorDict(**cfg_dict)
+
+
+def get_decoder(configs):
+    return config_decoder(configs.DeepSDF_DIR)
+
+
+def create_voxel_grid(vol_dim=128):
+    """(vol_dim^3, 3) float32 grid over [-1,1]^3, x slowest (reference utils.py:97-116)."""
+    voxel_size = 2.0 / (vol_dim - 1)
+    idx = np.arange(vol_dim ** 3, dtype=np.int64)
+    v = np.zeros((vol_dim ** 3, 3), np.float32)
+    v[:, 2] = idx % vol_dim
+    v[:, 1] = (idx // vol_dim) % vol_dim
+    v[:, 0] = (idx // vol_dim // vol_dim) % vol_dim
+    return (v * np.float32(voxel_size) + np.float32(-1.0)).astype(np.float32)
+
+
+def convert_sdf_voxels_to_mesh(sdf_volume):
+    """Marching cubes on the decoded grid (reference utils.py:119-140).  CPU / scikit-image, as in the reference."""
+    try:
+        import skimage.measure as measure
+    except ImportError as e:  # not in this image; the SDF grid itself comes from the GPU (MeshExtractor.decode_grid)
+        raise ImportError("extract_mesh_from_code needs scikit-image for marching cubes: %s" % e)
+    vol = np.asarray(sdf_volume, np.float32)
+    n = vol.shape[0]
+    voxel_size = 2.0 / (n - 1)
+    mc = getattr(measure, "marching_cubes_lewiner", None) or measure.marching_cubes
+    verts, faces, _, _ = mc(vol, level=0.0, spacing=[voxel_size] * 3)
+    verts = verts + np.array([-1.0, -1.0, -1.0])
+    return verts, faces

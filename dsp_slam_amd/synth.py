@@ -1,0 +1,146 @@
+"""Seeded synthetic inputs for the DeepSDF Gauss-Newton path.
+
+The reference ships no data, weights or tests, so every input of the tests / bench is made
+here: an analytic rounded-box shape family (the decoder fixture under tests/golden/ is fitted
+to it), surface points seen by a pinhole camera, their pixel rays + depths (KITTI convention
+n_fg == M, reconstruct/kitti_sequence.py:207-210), background rays that miss the object, and
+a perturbed initial object pose.  Pure numpy; deterministic for a given seed.
+"""
+import numpy as np
+
+BOX_HALF = np.array([0.38, 0.28, 0.80], dtype=np.float64)
+BOX_ROUND = 0.08
+
+
+def shape_half_extents(code3):
+    """Half extents of the rounded box for shape parameters code3 (first 3 code dims)."""
+    code3 = np.asarray(code3, dtype=np.float64)
+    return BOX_HALF * (1.0 + 0.2 * np.tanh(code3))
+
+
+def rounded_box_sdf(p, code3):
+    """Signed distance of points p (...,3) to the rounded box with parameters code3 (...,3)|(3,)."""
+    p = np.asarray(p, dtype=np.float64)
+    b = shape_half_extents(code3)
+    q = np.abs(p) - b
+    outside = np.linalg.norm(np.maximum(q, 0.0), axis=-1)
+    inside = np.minimum(np.max(q, axis=-1), 0.0)
+    return outside + inside - BOX_ROUND
+
+
+def _sdf_normal(p, code3, h=1e-4):
+    g = np.zeros_like(p)
+    for a in range(3):
+        e = np.zeros(3)
+        e[a] = h
+        g[:, a] = (rounded_box_sdf(p + e, code3) - rounded_box_sdf(p - e, code3)) / (2 * h)
+    n = np.linalg.norm(g, axis=-1, keepdims=True)
+    return g / np.maximum(n, 1e-12)
+
+
+def surface_points(code3, n, rng):
+    """n points on the zero level set, found by bisection along random rays from the centre."""
+    u = rng.normal(size=(n, 3))
+    u /= np.linalg.norm(u, axis=-1, keepdims=True)
+    lo = np.zeros(n)
+    hi = np.full(n, 1.6)
+    for _ in range(40):
+        mid = 0.5 * (lo + hi)
+        s = rounded_box_sdf(u * mid[:, None], code3)
+        inside = s < 0
+        lo = np.where(inside, mid, lo)
+        hi = np.where(inside, hi, mid)
+    return u * (0.5 * (lo + hi))[:, None]
+
+
+def rot_y(theta):
+    c, s = np.cos(theta), np.sin(theta)
+    return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]], dtype=np.float64)
+
+
+def _ray_hits_shape(o, d, code3, n_steps=96):
+    """Sphere-trace rays (origin o (n,3), unit dir d (n,3), object frame); True where they hit."""
+    t = np.zeros(o.shape[0])
+    hit = np.zeros(o.shape[0], dtype=bool)
+    alive = np.ones(o.shape[0], dtype=bool)
+    for _ in range(n_steps):
+        p = o + d * t[:, None]
+        s = rounded_box_sdf(p, code3)
+        hit |= alive & (s < 1e-4)
+        alive &= ~hit
+        alive &= t < 60.0
+        t = np.where(alive, t + np.maximum(s, 1e-4), t)
+    return hit
+
+
+def make_object(seed, n_surface=2000, n_background=500, code_len=64,
+                t_noise=0.25, yaw_noise_deg=5.0):
+    """One synthetic detection.
+
+    Returns a dict with float32 arrays, laid out as the reference's callers build them
+    (reconstruct_frame.py:48-57, src/LocalMapping_util.cc:179-180):
+      t_cam_obj_gt / t_cam_obj_init (4,4) Sim(3) object->camera, pts (M,3) camera frame,
+      rays (M+B,3) with z=1 (foreground rows first), depth (M,), code_gt (code_len,).
+    """
+    rng = np.random.default_rng(1000 + seed)
+    code_gt = np.zeros(code_len)
+    code_gt[:3] = rng.normal(scale=0.3, size=3)
+    scale = rng.uniform(1.8, 2.2)
+    theta = rng.uniform(-np.pi, np.pi)
+    t = np.array([rng.uniform(-4.0, 4.0), 1.2, rng.uniform(8.0, 25.0)])
+    flip = np.diag([1.0, -1.0, -1.0])  # object +y <-> camera -y (KITTI convention)
+    r_co = rot_y(theta) @ flip
+    t_co = np.eye(4)
+    t_co[:3, :3] = scale * r_co
+    t_co[:3, 3] = t
+
+    # camera-facing surface points (a convex shape is visible where its normal faces the camera)
+    pts_o = np.zeros((0, 3))
+    cam_o = r_co.T @ (-t) / scale  # camera centre in the object frame
+    while pts_o.shape[0] < n_surface:
+        cand = surface_points(code_gt[:3], 4 * n_surface, rng)
+        nrm = _sdf_normal(cand, code_gt[:3])
+        vis = np.einsum("ij,ij->i", nrm, cam_o[None, :] - cand) > 0.05
+        pts_o = np.concatenate([pts_o, cand[vis]], axis=0)
+    pts_o = pts_o[:n_surface]
+    pts_c = pts_o @ (scale * r_co).T + t
+    depth = pts_c[:, 2].copy()
+    fg_rays = pts_c / pts_c[:, 2:3]
+
+    # background rays: uniform in the foreground pixel box (+margin), rejected if they hit the shape
+    lo = fg_rays[:, :2].min(0) - 0.05
+    hi = fg_rays[:, :2].max(0) + 0.05
+    bg = np.zeros((0, 3))
+    while bg.shape[0] < n_background:
+        uv = rng.uniform(lo, hi, size=(4 * max(n_background, 1), 2))
+        d_c = np.concatenate([uv, np.ones((uv.shape[0], 1))], axis=-1)
+        d_o = d_c @ r_co  # R^T d  (row-vector form)
+        d_o /= np.linalg.norm(d_o, axis=-1, keepdims=True)
+        hit = _ray_hits_shape(np.repeat(cam_o[None, :], uv.shape[0], 0), d_o, code_gt[:3])
+        bg = np.concatenate([bg, d_c[~hit]], axis=0)
+        if n_background == 0:
+            break
+    bg = bg[:n_background]
+    rays = np.concatenate([fg_rays, bg], axis=0)
+
+    # perturbed initial pose
+    dyaw = np.deg2rad(yaw_noise_deg) * rng.uniform(-1.0, 1.0)
+    dt = rng.normal(size=3)
+    dt *= t_noise / np.linalg.norm(dt)
+    t_init = np.eye(4)
+    t_init[:3, :3] = scale * (rot_y(theta + dyaw) @ flip)
+    t_init[:3, 3] = t + dt
+
+    return dict(
+        t_cam_obj_gt=t_co.astype(np.float32),
+        t_cam_obj_init=t_init.astype(np.float32),
+        pts=np.ascontiguousarray(pts_c, dtype=np.float32),
+        rays=np.ascontiguousarray(rays, dtype=np.float32),
+        depth=np.ascontiguousarray(depth, dtype=np.float32),
+        code_gt=code_gt.astype(np.float32),
+        scale=np.float32(scale),
+    )
+
+
+def make_batch(n_objects, first_seed=0, **kw):
+    return [make_object(first_seed + i, **kw) for i in range(n_objects)]

@@ -1,0 +1,144 @@
+/* dsp_gn.h -- C ABI of libdspgn: MI355X (gfx950) DeepSDF shape-code + pose Gauss-Newton optimiser.
+ *
+ * Drop-in boundary for ONE hot path of DSP-SLAM (reference: JingwenWang95/DSP-SLAM).  The reference has
+ * no FFI of its own for this path: C++ reaches it through an embedded CPython interpreter
+ * (src/LocalMapping.cc:38-40, src/LocalMapping_util.cc:109-110,179-196,391-426) calling the Python
+ * functions listed below.  Each entry point here cites the reference interface it replaces; the Python
+ * mirror package (dsp_slam_amd/reconstruct, dsp_slam_amd/deep_sdf) binds these through ctypes and keeps
+ * the reference's Python names, so the C++ caller is unchanged.
+ *
+ * Conventions: plain C types; all pointers are HOST pointers unless a name ends in _dev; row-major
+ * float32; every function returns 0 on success or a negative DSP_E_* code (dsp_last_error() gives
+ * text).  A handle owns one device, one HIP stream and its device memory; calls on one handle must be
+ * serialised by the caller (the reference serialises them through the GIL), different handles are
+ * independent.  Nothing here depends on Python or PyTorch.
+ */
+#ifndef DSP_GN_H
+#define DSP_GN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSP_OK 0
+#define DSP_E_ARG (-1)      /* bad argument / unsupported decoder geometry */
+#define DSP_E_HIP (-2)      /* HIP runtime error */
+#define DSP_E_NOMEM (-3)
+#define DSP_E_STATE (-4)
+
+#define DSP_CODE_LEN 64
+#define DSP_GRAD_DIM 67     /* d sdf / d [code(64), x, y, z] */
+
+typedef struct dsp_handle dsp_handle;
+typedef struct dsp_batch dsp_batch;
+
+/* Folded decoder weights, layer k: weights[k] is (out_dims[k] x in_dims[k]) row-major, biases[k] (out_dims[k]).
+ * Replaces deep_sdf/workspace.py:202-223 (config_decoder) + Decoder.__init__ (deep_sdf/deep_sdf_decoder.py:10-73):
+ * weight-norm is folded by the caller, W = g * v / ||v||_row.  Supported geometry: hidden width 512, code_len 64,
+ * 2..8 hidden layers, exactly one latent_in layer (input re-concatenated there), final layer 512 -> 1 + tanh. */
+typedef struct dsp_decoder_desc {
+    int32_t n_layers;            /* number of Linear layers (9 for DSP-SLAM) */
+    int32_t code_len;            /* 64 */
+    int32_t latent_in;           /* index of the layer whose input is [h | code | xyz] (4), or -1 */
+    const int32_t* out_dims;     /* [n_layers] */
+    const int32_t* in_dims;      /* [n_layers] */
+    const float* const* weights; /* [n_layers] */
+    const float* const* biases;  /* [n_layers] */
+} dsp_decoder_desc;
+
+/* Hyper-parameters read by Optimizer.__init__ (reconstruct/optimizer.py:27-43). */
+typedef struct dsp_gn_params {
+    float k1, k2, k3, k4;        /* render / sdf / code-prior / rotation-prior weights */
+    float b1, b2;                /* Huber thresholds: render, sdf */
+    float lr;                    /* learning_rate */
+    float s_damp;                /* scale_damping */
+    int32_t num_iterations;      /* joint_optim.num_iterations */
+    int32_t num_depth_samples;   /* optimizer.num_depth_samples (<= 64) */
+    float cut_off;               /* optimizer.cut_off_threshold */
+    int32_t pose_only_iterations;/* pose_only_optim.num_iterations */
+} dsp_gn_params;
+
+/* Per-object status of a batch run (ragged failures do not poison the batch). */
+#define DSP_OBJ_GOOD 0
+#define DSP_OBJ_FEW_SAMPLES 1   /* < 10 in-sphere ray samples: compute_render_loss returned None (loss.py:73-74) */
+#define DSP_OBJ_NAN 2           /* NaN loss, e.g. K == 0 (optimizer.py:135-136,149-150) */
+
+/* Counters and device timings of the last run of a batch. */
+typedef struct dsp_stats {
+    double n_fwd_points;         /* sum over iterations and objects of V (forward-only decoder points) */
+    double n_jac_points;         /* sum of M + K (forward + input-gradient points) */
+    double ms_total;             /* HIP-event time of the whole run on the handle's stream */
+    double ms_mlp_fwd;           /* summed time of the forward-only decoder kernel launches */
+    double ms_mlp_jac;           /* summed time of the forward+gradient decoder kernel launches */
+    int32_t n_mlp_fwd_launches;
+    int32_t n_mlp_jac_launches;
+} dsp_stats;
+
+/* ---- lifetime --------------------------------------------------------------------------------- */
+int dsp_create(const dsp_decoder_desc* decoder, int device, dsp_handle** out);
+void dsp_destroy(dsp_handle* h);
+const char* dsp_last_error(const dsp_handle* h);   /* h may be NULL: error of the last failed dsp_create */
+int dsp_abi_version(void);
+
+/* ---- decoder ---------------------------------------------------------------------------------- */
+/* decode_sdf(decoder, lat_vec, x)  -- reconstruct/loss_utils.py:51-79.  pts (n,3) object frame -> sdf (n). */
+int dsp_decode_sdf(dsp_handle* h, const float* code, const float* pts, int64_t n, float* sdf_out);
+/* get_batch_sdf_jacobian(decoder, lat_vec, x, 1) -- reconstruct/loss_utils.py:82-103.
+ * sdf_out (n), grad_out (n, 67) = d sdf / d [code, xyz]. */
+int dsp_sdf_jacobian(dsp_handle* h, const float* code, const float* pts, int64_t n, float* sdf_out, float* grad_out);
+
+/* ---- residual terms --------------------------------------------------------------------------- */
+/* compute_sdf_loss(decoder, pts_surface_cam, t_obj_cam, latent_vector) -- reconstruct/loss.py:22-43.
+ * Outputs: jac_pose (n,7), jac_code (n,64), res (n). */
+int dsp_compute_sdf_loss(dsp_handle* h, const float* pts_cam, int64_t n, const float* t_obj_cam, const float* code,
+                         float* jac_pose, float* jac_code, float* res);
+/* compute_render_loss(decoder, ray_directions, depth_obs, t_obj_cam, sampled_ray_depth, latent_vector, th)
+ * -- reconstruct/loss.py:46-152.  *k_out = number of rows K, or -1 when the reference returns None
+ * (< 10 in-sphere samples).  Outputs need capacity n_rays * n_depths rows; row order = the reference's
+ * (ray-major, depth-minor).  v_out / m_out (optional) receive the ragged set sizes V and m. */
+int dsp_compute_render_loss(dsp_handle* h, const float* rays, int64_t n_rays, const float* depth_obs,
+                            const float* t_obj_cam, const float* sampled_depth, int32_t n_depths, const float* code,
+                            float th, int64_t* k_out, float* jac_pose, float* jac_code, float* res, int64_t* v_out,
+                            int64_t* m_out);
+
+/* ---- optimiser -------------------------------------------------------------------------------- */
+/* Optimizer.reconstruct_object for a ragged batch of independent objects -- reconstruct/optimizer.py:88-203.
+ * Object i uses pts[pts_off[i]..pts_off[i+1]) (camera frame, (M_i,3)), rays[ray_off[i]..ray_off[i+1]) ((R_i,3);
+ * the first n_fg[i] rows are foreground and pair with depth[depth_off[i] + r]), t_cam_obj[i] (4x4 Sim(3)
+ * object->camera initial estimate) and codes_in[i] (64; NULL => zero start, optimizer.py:96-99).
+ * Outputs per object: t_cam_obj (16), code (64), loss (k1*L_render + k2*L_sdf at the last linearisation
+ * point, :155), status (DSP_OBJ_*).  For a failed object t_cam_obj/code hold the last state. */
+int dsp_reconstruct_batch(dsp_handle* h, const dsp_gn_params* prm, int32_t n_objects, const int64_t* pts_off,
+                          const float* pts, const int64_t* ray_off, const float* rays, const int64_t* depth_off,
+                          const float* depth, const float* t_cam_obj_in, const float* codes_in,
+                          float* t_cam_obj_out, float* codes_out, float* loss_out, int32_t* status_out);
+
+/* Optimizer.estimate_pose_cam_obj for a ragged batch -- reconstruct/optimizer.py:45-86.
+ * t_co_se3_in[i] (4x4 SE(3)), scale[i], pts as above, codes[i] (64).  Output t_co_se3_out[i] (4x4 SE(3)).
+ * The inputs are not modified (the reference scales the caller's matrix in place, :53-54). */
+int dsp_estimate_pose_batch(dsp_handle* h, const dsp_gn_params* prm, int32_t n_objects, const int64_t* pts_off,
+                            const float* pts, const float* t_co_se3_in, const float* scale, const float* codes,
+                            float* t_co_se3_out);
+
+/* ---- device-resident batches (bench / steady-state serving: inputs stay in HBM between runs) --- */
+int dsp_batch_create(dsp_handle* h, const dsp_gn_params* prm, int32_t n_objects, const int64_t* pts_off,
+                     const float* pts, const int64_t* ray_off, const float* rays, const int64_t* depth_off,
+                     const float* depth, const float* t_cam_obj_in, const float* codes_in, dsp_batch** out);
+int dsp_batch_run(dsp_batch* b);        /* resets the state to the uploaded initial estimate, runs, synchronises */
+int dsp_batch_results(dsp_batch* b, float* t_cam_obj_out, float* codes_out, float* loss_out, int32_t* status_out);
+int dsp_batch_stats(dsp_batch* b, dsp_stats* out);
+/* Record per-iteration traces during the following runs (testing; costs ~21 KB per object-iteration). */
+int dsp_batch_enable_trace(dsp_batch* b, int on);
+/* Per-iteration trace of the last run (testing): for iteration e < num_iterations and object i,
+ * H (71x71), b (71), dx (71), V, m, K.  Any pointer may be NULL. */
+int dsp_batch_trace(dsp_batch* b, int32_t iteration, float* H, float* bvec, float* dx, int64_t* V, int64_t* m,
+                    int64_t* K, float* t_obj_cam, float* code);
+void dsp_batch_destroy(dsp_batch* b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSP_GN_H */
