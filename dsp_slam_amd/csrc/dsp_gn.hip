@@ -561,6 +561,35 @@ extern "C" {
 
 int dsp_abi_version(void) { return 1; }
 
+/* Development aid: run forward+gradient on <= 64 points and dump every pass's output slab of the tile:
+ * slabs_out[pass][wave][reg 0..127][lane 0..63], n_pass passes. */
+int dsp_debug_slabs(dsp_handle* h, const float* code, const float* pts, int n, float* slabs_out, float* grad_out) {
+    if (!h || n < 1 || n > 64) return DSP_E_ARG;
+    return guarded(h, [&] {
+        HIP_TRY(hipSetDevice(h->device));
+        std::vector<float4> p4(n);
+        for (int i = 0; i < n; ++i) p4[i] = make_float4(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], 0.f);
+        int4 tile = make_int4(0, n, 0, 0);
+        int nt = 1;
+        DevBuf<float> dbg, out;
+        const size_t nd = (size_t)h->n_pass_all * 4 * 128 * 64;
+        dbg.alloc(nd);
+        out.alloc(64 * GRAD_STRIDE);
+        h->s_pts.ensure(64); h->s_code.ensure(CODE_LEN); h->s_tiles.ensure(1); h->s_ntiles.ensure(1);
+        HIP_TRY(hipMemcpy(h->s_pts.p, p4.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->s_code.p, code, CODE_LEN * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->s_tiles.p, &tile, sizeof tile, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->s_ntiles.p, &nt, 4, hipMemcpyHostToDevice));
+        MlpArgs a = make_mlp_args(h, true);
+        a.n_tiles = h->s_ntiles.p; a.tiles = h->s_tiles.p; a.pts = h->s_pts.p; a.codes = h->s_code.p; a.code_stride = CODE_LEN;
+        a.out_sdf = out.p; a.out_grad = out.p; a.dbg = dbg.p;
+        HIP_TRY(launch_mlp(true, a, 1, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        HIP_TRY(hipMemcpy(slabs_out, dbg.p, nd * 4, hipMemcpyDeviceToHost));
+        if (grad_out) HIP_TRY(hipMemcpy(grad_out, out.p, (size_t)n * GRAD_STRIDE * 4, hipMemcpyDeviceToHost));
+    });
+}
+
 /* Host-only: pack a decoder exactly as dsp_create does and copy the result out (tests emulate the kernel's
  * data flow on it without a GPU).  pass_out receives n_pass x 8 int32 {nog,nchunks,bias_row,relu,mask_slot,kind,chunk_base,0};
  * meta_out = {n_fwd, n_pass, chunks_fwd, chunks_all, n_bias_rows}.  Call with NULL buffers to query sizes. */

@@ -49,7 +49,7 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 
 #define FOR16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
 
-template <bool BWD>
+template <bool BWD, bool DBG>
 __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
     for (int i = 0; i < NBUF - 1; ++i) issue();
     // chunk 0 visible to every wave; from here on the barrier for chunk q+1 sits in the middle of chunk q
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(GLDS_PER_CHUNK * (NBUF - 2)) : "memory");
-    f32x4 abuf[3];   // A operands run two k-steps ahead of the MFMAs, across chunk / group / pass seams
+    f32x4 abuf[4];   // A operands run two k-steps ahead of the MFMAs, across chunk / group / pass seams
+                     // (4 slots, not 3: 16 k-steps per chunk must be a multiple of the rotation length)
     abuf[0] = *reinterpret_cast<const f32x4*>(ring_ptr + lane * 16);
     abuf[1] = *reinterpret_cast<const f32x4*>(ring_ptr + lane * 16 + 1024);
 
@@ -161,10 +162,10 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
                                 issue();
                             }
                             const int sp = s + 2;
-                            abuf[sp % 3] = (sp < KSTEPS_PER_CHUNK)
+                            abuf[sp % 4] = (sp < KSTEPS_PER_CHUNK)
                                                ? *reinterpret_cast<const f32x4*>(cb + sp * 1024)
                                                : *reinterpret_cast<const f32x4*>(nb + (sp - KSTEPS_PER_CHUNK) * 1024);
-                            const f32x4 av = abuf[s % 3];
+                            const f32x4 av = abuf[s % 4];
                             const float b = sin_[16 * c + s];
                             acc[0] = MFMA16(av.x, b, acc[0]);
                             acc[1] = MFMA16(av.y, b, acc[1]);
@@ -236,6 +237,12 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
             }
 
             // ---- pass epilogue ---------------------------------------------------------------------
+            if (DBG && tile == 0) {   // development aid: dump the output slab of every pass of tile 0
+                float* dp = a.dbg + ((size_t)(ps * 4 + wave) * 128) * 64 + lane;
+#pragma unroll
+                for (int i = 0; i < 128; ++i) dp[i * 64] = sout[i];
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
 #pragma unroll
             for (int i = 0; i < 128; ++i) sin_[i] = sout[i];
 
@@ -302,24 +309,29 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template __global__ void mlp_kernel<false>(const MlpArgs);
-template __global__ void mlp_kernel<true>(const MlpArgs);
+template __global__ void mlp_kernel<false, false>(const MlpArgs);
+template __global__ void mlp_kernel<true, false>(const MlpArgs);
+template __global__ void mlp_kernel<true, true>(const MlpArgs);
 
 size_t mlp_lds_bytes(bool bwd) { return BIAS_BYTES + (bwd ? MASK_BYTES : 0) + NBUF * CHUNK_BYTES; }
 
 hipError_t launch_mlp(bool bwd, const MlpArgs& args, int n_blocks, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)mlp_lds_bytes(false));
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)mlp_lds_bytes(true));
         attr_set = true;
     }
-    if (bwd)
-        hipLaunchKernelGGL(mlp_kernel<true>, dim3(n_blocks), dim3(256), mlp_lds_bytes(true), stream, args);
+    if (args.dbg) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)mlp_lds_bytes(true));
+        hipLaunchKernelGGL((mlp_kernel<true, true>), dim3(n_blocks), dim3(256), mlp_lds_bytes(true), stream, args);
+    } else if (bwd)
+        hipLaunchKernelGGL((mlp_kernel<true, false>), dim3(n_blocks), dim3(256), mlp_lds_bytes(true), stream, args);
     else
-        hipLaunchKernelGGL(mlp_kernel<false>, dim3(n_blocks), dim3(256), mlp_lds_bytes(false), stream, args);
+        hipLaunchKernelGGL((mlp_kernel<false, false>), dim3(n_blocks), dim3(256), mlp_lds_bytes(false), stream, args);
     return hipGetLastError();
 }
 
