@@ -631,6 +631,7 @@ int dsp_create(const dsp_decoder_desc* decoder, int device, dsp_handle** out) {
         h->device = device;
         h->n_cu = prop.multiProcessorCount;
         HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        HIP_TRY(mlp_prepare_device());
         pack_decoder(h, decoder);
     });
     if (rc != DSP_OK) { delete h; return rc; }

@@ -83,6 +83,7 @@ struct GnParamsDev {
 
 // kernels_mlp / kernels_gn launchers
 size_t mlp_lds_bytes(bool bwd);
+hipError_t mlp_prepare_device();
 hipError_t launch_mlp(bool bwd, const MlpArgs& args, int n_blocks, hipStream_t stream);
 void launch_init_state(ObjState* st, const float* t, const float* codes, const float* scale, int B, int D, int pose_only, hipStream_t s);
 void launch_sample_count(const ObjConst* oc, const ObjState* st, const float* rays, unsigned long long* m, int* c, int D, int maxR, int B, hipStream_t s);

@@ -315,20 +315,22 @@ template __global__ void mlp_kernel<true, true>(const MlpArgs);
 
 size_t mlp_lds_bytes(bool bwd) { return BIAS_BYTES + (bwd ? MASK_BYTES : 0) + NBUF * CHUNK_BYTES; }
 
+// Opt every kernel variant into > 64 KiB of dynamic LDS on the current device (called by dsp_create).
+hipError_t mlp_prepare_device() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_kernel<false, false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlp_lds_bytes(false));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)mlp_lds_bytes(true));
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)mlp_lds_bytes(true));
+}
+
 hipError_t launch_mlp(bool bwd, const MlpArgs& args, int n_blocks, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)mlp_lds_bytes(false));
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)mlp_lds_bytes(true));
-        attr_set = true;
-    }
-    if (args.dbg) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)mlp_lds_bytes(true));
+    if (args.dbg)
         hipLaunchKernelGGL((mlp_kernel<true, true>), dim3(n_blocks), dim3(256), mlp_lds_bytes(true), stream, args);
-    } else if (bwd)
+    else if (bwd)
         hipLaunchKernelGGL((mlp_kernel<true, false>), dim3(n_blocks), dim3(256), mlp_lds_bytes(true), stream, args);
     else
         hipLaunchKernelGGL((mlp_kernel<false, false>), dim3(n_blocks), dim3(256), mlp_lds_bytes(false), stream, args);

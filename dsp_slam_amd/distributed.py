@@ -1,0 +1,69 @@
+"""Multi-GPU scale-out of the Gauss-Newton path: objects are independent, so ranks take contiguous blocks of
+the object list (balanced by estimated work) and the only exchange is ONE gather of the per-object results
+(pose 16 + code 64 + loss + status = 82 float32) to rank 0 -- RCCL over xGMI with backend "nccl", gloo on CPU.
+
+One process per GPU (torch.distributed); nothing here touches the data path of a rank.
+"""
+import numpy as np
+
+RESULT_WIDTH = 82
+
+
+def object_cost(n_pts, n_rays, n_depth=50):
+    """Relative work of one object: forward-only decoder points dominate (R*D), jacobian points cost 2x."""
+    return float(n_rays) * n_depth + 2.0 * float(n_pts)
+
+
+def shard_objects(costs, world_size):
+    """Contiguous block partition of objects 0..n-1 over ranks, balancing the summed cost.
+    Returns a list of (start, stop) per rank; every object belongs to exactly one rank."""
+    costs = np.asarray(costs, np.float64)
+    n = costs.shape[0]
+    bounds = [0]
+    cum = np.concatenate([[0.0], np.cumsum(costs)])
+    total = cum[-1]
+    for r in range(1, world_size):
+        target = total * r / world_size
+        k = int(np.searchsorted(cum, target, side="left"))
+        if k > 0 and abs(cum[k - 1] - target) <= abs(cum[min(k, n)] - target):
+            k -= 1
+        k = min(max(k, bounds[-1]), n)
+        bounds.append(k)
+    bounds.append(n)
+    return [(bounds[r], bounds[r + 1]) for r in range(world_size)]
+
+
+def pack_results(t_cam_obj, codes, loss, status):
+    n = len(loss)
+    out = np.zeros((n, RESULT_WIDTH), np.float32)
+    out[:, :16] = np.asarray(t_cam_obj, np.float32).reshape(n, 16)
+    out[:, 16:80] = np.asarray(codes, np.float32).reshape(n, 64)
+    out[:, 80] = loss
+    out[:, 81] = np.asarray(status, np.float32)
+    return out
+
+
+def unpack_results(packed):
+    packed = np.asarray(packed, np.float32)
+    n = packed.shape[0]
+    return packed[:, :16].reshape(n, 4, 4), packed[:, 16:80], packed[:, 80], packed[:, 81].astype(np.int32)
+
+
+def gather_results(local_packed, shards, dist, device=None, dst=0):
+    """One collective: every rank contributes its (n_local, 82) block; rank `dst` returns the (n_total, 82)
+    array in object order, other ranks return None.  Blocks are padded to the largest shard so that a single
+    dist.gather suffices (uneven shards)."""
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
+    n_max = max(b - a for a, b in shards)
+    pad = np.zeros((n_max, RESULT_WIDTH), np.float32)
+    pad[:local_packed.shape[0]] = local_packed
+    mine = torch.from_numpy(pad)
+    if device is not None:
+        mine = mine.to(device)
+    bufs = [torch.empty_like(mine) for _ in range(world)] if rank == dst else None
+    dist.gather(mine, bufs, dst=dst)
+    if rank != dst:
+        return None
+    parts = [bufs[r][: shards[r][1] - shards[r][0]].cpu().numpy() for r in range(world)]
+    return np.concatenate(parts, 0)

@@ -194,30 +194,25 @@ def test_reconstruct_redwood_each_iteration(eng, oracle_decoder):
     _check_iterations(oracle_decoder, obj, traces, oprm, cfg["optimizer"]["joint_optim"]["k4"])
 
 
-def _self_sensitivity(oracle_decoder, oprm, obj, code=None):
-    """How far the ORACLE's own result moves when the input points move by one float32 ulp: the
-    10-iteration map is discontinuous in its ragged sets, so this -- not round-off -- bounds any
-    end-to-end comparison between two correct float32 implementations."""
-    r1 = O.reconstruct_object(oracle_decoder, oprm, obj["t_cam_obj_init"], obj["pts"], obj["rays"], obj["depth"], code)
-    p2 = (obj["pts"].astype(np.float64) * (1 + 1.2e-7)).astype(np.float32)
-    r2 = O.reconstruct_object(oracle_decoder, oprm, obj["t_cam_obj_init"], p2, obj["rays"], obj["depth"], code)
-    return r1, np.abs(r1["t_cam_obj"] - r2["t_cam_obj"]).max(), np.abs(r1["code"] - r2["code"]).max()
-
-
-@pytest.mark.parametrize("name", ["golden_recon_small.npz", "golden_recon_cfg1.npz"])
-def test_reconstruct_end_to_end(eng, oracle_decoder, name):
+@pytest.mark.parametrize("name", ["golden_recon_small.npz", "golden_recon_cfg1.npz", "golden_recon_redwood.npz", "golden_recon_cfg2.npz"])
+def test_reconstruct_end_to_end(eng, name):
+    """All iterations chained, against the reference's final pose / code.  Tolerance: 1e-4 relative, or 4x the
+    REFERENCE'S OWN movement when its input points move by one float32 ulp (golden ulp_*), whichever is larger:
+    the 10-iteration map is discontinuous in its ragged sets, so round-off is amplified far beyond 1e-4 inside the
+    reference itself (cfg2: 1e-3 relative on the pose) -- DESIGN.md "Parity"."""
     g = golden(name)
     cfg = json.loads(str(g["cfg_json"]))
     prm, oprm = prm_from(cfg)
-    obj = dict(t_cam_obj_init=g["in_t_cam_obj_init"], pts=g["in_pts"], rays=g["in_rays"], depth=g["in_depth"])
-    t, code, loss, status = eng.reconstruct_batch(prm, [obj["t_cam_obj_init"]], [obj["pts"]], [obj["rays"]], [obj["depth"]])
-    assert status[0] == 0
-    r1, sens_t, sens_c = _self_sensitivity(oracle_decoder, oprm, obj)
-    tol_t = max(1e-4 * np.abs(g["t_cam_obj"]).max(), 4 * sens_t)
-    tol_c = max(1e-4, 4 * sens_c)
-    for ref_t, ref_c in ((g["t_cam_obj"], g["code"]), (r1["t_cam_obj"], r1["code"])):   # reference golden, oracle
-        assert np.abs(t[0] - ref_t).max() <= tol_t
-        assert np.abs(code[0] - ref_c).max() <= tol_c
+    code0 = [g["in_code"]] if "in_code" in g.files else None
+    t, code, loss, status = eng.reconstruct_batch(prm, [g["in_t_cam_obj_init"]], [g["in_pts"]], [g["in_rays"]], [g["in_depth"]], code0)
+    assert status[0] == 0 and bool(g["is_good"])
+    sens_t = np.abs(g["ulp_t_cam_obj"] - g["t_cam_obj"]).max()
+    sens_c = np.abs(g["ulp_code"] - g["code"]).max()
+    dt = np.abs(t[0] - g["t_cam_obj"]).max()
+    dc = np.abs(code[0] - g["code"]).max()
+    print("%s: |dT| %.2e (ref ulp-sensitivity %.2e)  |dcode| %.2e (%.2e)" % (name, dt, sens_t, dc, sens_c))
+    assert dt <= max(1e-4 * np.abs(g["t_cam_obj"]).max(), 4 * sens_t)
+    assert dc <= max(1e-4, 4 * sens_c)
 
 
 def test_failure_path_is_good_false(eng_random):

@@ -1,0 +1,111 @@
+"""CPU-only host logic: config objects, decoder loading in the reference's on-disk format, ragged marshalling,
+synthetic-input determinism, sharding."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from dsp_slam_amd import fixtures, synth, engine as E, distributed as D
+from oracle import dsp_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "dsp_slam_amd")
+
+
+@pytest.fixture()
+def mirror():
+    sys.path.insert(0, PKG)
+    for m in [k for k in sys.modules if k.split(".")[0] in ("reconstruct", "deep_sdf")]:
+        del sys.modules[m]
+    yield
+    sys.path.remove(PKG)
+    for m in [k for k in sys.modules if k.split(".")[0] in ("reconstruct", "deep_sdf")]:
+        del sys.modules[m]
+
+
+def test_force_key_error_dict(mirror, tmp_path):
+    from reconstruct.utils import ForceKeyErrorDict, get_configs
+    cfg = {"data_type": "KITTI", "optimizer": {"code_len": 64, "joint_optim": {"k1": 1.0}}}
+    p = tmp_path / "c.json"
+    p.write_text(json.dumps(cfg))
+    c = get_configs(str(p))
+    assert c.optimizer.joint_optim.k1 == 1.0 and c["data_type"] == "KITTI"
+    with pytest.raises(KeyError):
+        c.optimizer.no_such_key
+    d = ForceKeyErrorDict(t_cam_obj=None, is_good=False)
+    assert d.is_good is False and d.t_cam_obj is None
+
+
+def test_reference_disk_format_loader(mirror, tmp_path, cars_state_dict):
+    """specs.json + ModelParameters/latest.pth with DataParallel `module.` keys (deep_sdf/workspace.py:202-223)."""
+    from reconstruct.utils import get_configs, get_decoder
+    ddir = fixtures.materialize_decoder_dir("cars", str(tmp_path / "cars_64"))
+    (tmp_path / "c.json").write_text(json.dumps({"DeepSDF_DIR": ddir}))
+    dec = get_decoder(get_configs(str(tmp_path / "c.json")))
+    ref = O.fold_decoder(cars_state_dict, fixtures.SPECS)
+    assert len(dec.layers) == 9 and dec.latent_in == (4,)
+    for (w, b), (wr, br) in zip(dec.layers, ref.layers):
+        assert w.shape == wr.shape and np.array_equal(w, wr) and np.array_equal(b, br)
+    assert dec.layers[3][0].shape == (445, 512) and dec.layers[4][0].shape == (512, 512) and dec.layers[8][0].shape == (1, 512)
+
+
+def test_optimizer_reads_reference_config_keys(mirror):
+    from reconstruct.utils import ForceKeyErrorDict
+    from reconstruct.optimizer import Optimizer
+    cfg = ForceKeyErrorDict(json.load(open(os.path.join(ROOT, "tests", "golden", "config_kitti_optimizer.json"))))
+    opt = Optimizer(decoder=None, configs=cfg)
+    assert (opt.k1, opt.k2, opt.k3, opt.k4, opt.b1, opt.b2) == (1.0, 100.0, 0.25, 1e7, 0.2, 0.025)
+    assert opt.num_iterations_joint_optim == 10 and opt.num_iterations_pose_only == 5 and opt.code_len == 64
+    p = opt._params()
+    assert p.num_depth_samples == 50 and abs(p.cut_off - 0.01) < 1e-9 and p.s_damp == 1.0
+    bad = ForceKeyErrorDict(json.loads(json.dumps(cfg)))
+    del bad["optimizer"]["joint_optim"]["k3"]
+    with pytest.raises(KeyError):
+        Optimizer(None, bad)
+
+
+def test_params_from_plain_dict():
+    cfg = json.load(open(os.path.join(ROOT, "tests", "golden", "config_kitti_optimizer.json")))
+    p = E.params_from_configs(cfg)
+    assert p.k4 == 1e7 and p.num_iterations == 10 and p.pose_only_iterations == 5
+
+
+def test_ragged_marshalling():
+    off, flat = E._ragged([np.ones((3, 3)), np.zeros((0, 3)), np.asfortranarray(np.arange(12.).reshape(4, 3))], 3)
+    assert list(off) == [0, 3, 3, 7] and flat.shape == (7, 3) and flat.flags["C_CONTIGUOUS"] and flat.dtype == np.float32
+    assert np.array_equal(flat[3:], np.arange(12.).reshape(4, 3))
+    off, flat = E._ragged([np.arange(4.), np.arange(2.)], 0)
+    assert list(off) == [0, 4, 6] and flat.shape == (6,)
+
+
+def test_synth_deterministic_and_consistent():
+    a, b = synth.make_object(5, 100, 30), synth.make_object(5, 100, 30)
+    for k in a:
+        assert np.array_equal(a[k], b[k])
+    assert a["pts"].shape == (100, 3) and a["rays"].shape == (130, 3) and a["depth"].shape == (100,)
+    assert np.allclose(a["rays"][:100] * a["depth"][:, None], a["pts"], atol=1e-5)      # KITTI convention: fg ray * depth = point
+    t_oc = np.linalg.inv(a["t_cam_obj_gt"].astype(np.float64))
+    p_o = a["pts"] @ t_oc[:3, :3].T + t_oc[:3, 3]
+    assert np.abs(synth.rounded_box_sdf(p_o, a["code_gt"][:3])).max() < 1e-4           # points lie on the true surface
+    assert np.linalg.norm(p_o, axis=1).max() < 1.0
+
+
+def test_voxel_grid(mirror):
+    from reconstruct.utils import create_voxel_grid
+    g = create_voxel_grid(4)
+    assert g.shape == (64, 3) and g.dtype == np.float32
+    assert np.allclose(g[0], [-1, -1, -1]) and np.allclose(g[-1], [1, 1, 1]) and np.allclose(g[1], [-1, -1, -1 + 2 / 3])
+
+
+def test_shard_objects_partition():
+    for n, w in [(1024, 8), (10, 4), (3, 8), (64, 1), (7, 2)]:
+        costs = np.random.default_rng(n).uniform(1, 3, size=n)
+        sh = D.shard_objects(costs, w)
+        assert len(sh) == w and sh[0][0] == 0 and sh[-1][1] == n
+        assert all(sh[i][1] == sh[i + 1][0] for i in range(w - 1)) and all(a <= b for a, b in sh)
+    sh = D.shard_objects(np.ones(1024), 8)
+    assert all(b - a == 128 for a, b in sh)
+    t, c, l, s = D.unpack_results(D.pack_results(np.arange(32.).reshape(2, 4, 4), np.ones((2, 64)), [1., 2.], [0, 2]))
+    assert t.shape == (2, 4, 4) and c.shape == (2, 64) and list(l) == [1., 2.] and list(s) == [0, 2]

@@ -1,0 +1,71 @@
+"""CPU-only, world_size 2 over gloo: the multi-GPU path (dsp_slam_amd.distributed -- block sharding of independent
+objects + ONE gather of the 82-float results to rank 0) returns, in object order, exactly what a single process
+computes.  The per-object worker here is the CPU oracle on tiny objects (no GPU in this container); on the GPU box
+bench.py plugs the HIP engine into the same shard/gather code with backend "nccl" (RCCL)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from dsp_slam_amd import distributed as D, fixtures, synth
+
+N_OBJ = 5           # uneven over 2 ranks on purpose
+
+
+def _objects():
+    return [synth.make_object(200 + i, n_surface=24 + 8 * i, n_background=6) for i in range(N_OBJ)]
+
+
+def _solve(objs):
+    from oracle import dsp_oracle as O
+    dec = O.fold_decoder(fixtures.load_decoder_npz(fixtures.fixture_path("cars")), fixtures.SPECS)
+    prm = O.GNParams(num_iterations=2)
+    t, c, l, s = [], [], [], []
+    for o in objs:
+        r = O.reconstruct_object(dec, prm, o["t_cam_obj_init"], o["pts"], o["rays"], o["depth"])
+        good = r["is_good"]
+        t.append(r["t_cam_obj"] if good else np.zeros((4, 4), np.float32))
+        c.append(r["code"] if good else np.zeros(64, np.float32))
+        l.append(r["loss"])
+        s.append(0 if good else 2)
+    return D.pack_results(np.stack(t), np.stack(c), np.array(l, np.float32), np.array(s))
+
+
+def _worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    objs = _objects()
+    shards = D.shard_objects([D.object_cost(o["pts"].shape[0], o["rays"].shape[0]) for o in objs], world)
+    a, b = shards[rank]
+    local = _solve(objs[a:b])
+    full = D.gather_results(local, shards, dist)
+    dist.barrier()
+    if rank == 0:
+        np.save(out_path, full)
+        np.save(out_path + ".shards.npy", np.array(shards))
+    else:
+        assert full is None
+    dist.destroy_process_group()
+
+
+def test_two_rank_shard_and_gather(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "gathered.npy")
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    shards = np.load(out + ".shards.npy")
+    assert shards[0][0] == 0 and shards[-1][1] == N_OBJ and shards[0][1] == shards[1][0]
+    assert 0 < shards[0][1] < N_OBJ                       # both ranks had work
+    torch.set_num_threads(2)
+    want = _solve(_objects())
+    assert got.shape == (N_OBJ, D.RESULT_WIDTH)
+    assert np.array_equal(got, want)

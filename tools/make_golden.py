@@ -121,6 +121,17 @@ def run_recon(Optimizer, ropt, rloss, decoder, cfg_dict, obj, code=None, get_con
         rst = opt.reconstruct_object(obj["t_cam_obj_init"].copy(), obj["pts"].copy(), obj["rays"].copy(),
                                      obj["depth"].copy(), None if code is None else code.copy())
     out = rec.pack()
+    # reference self-sensitivity: the same run with every surface point moved by one float32 ulp.  The 10-iteration
+    # map is discontinuous in its ragged sets (V, m, K), so this is the yardstick for end-to-end comparisons.
+    if rst.is_good:
+        import contextlib, io
+        pts_ulp = (obj["pts"].astype(np.float64) * (1 + 1.2e-7)).astype(np.float32)
+        with contextlib.redirect_stdout(io.StringIO()):
+            rst2 = opt.reconstruct_object(obj["t_cam_obj_init"].copy(), pts_ulp, obj["rays"].copy(), obj["depth"].copy(),
+                                          None if code is None else code.copy())
+        if rst2.is_good:
+            out["ulp_t_cam_obj"] = np.asarray(rst2.t_cam_obj, np.float32)
+            out["ulp_code"] = np.asarray(rst2.code, np.float32)
     out["is_good"] = np.array(bool(rst.is_good))
     out["loss"] = np.array(float(rst.loss), np.float32)
     if rst.is_good:
