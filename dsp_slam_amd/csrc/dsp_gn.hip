@@ -62,6 +62,7 @@ struct dsp_handle {
     DevBuf<float> s_code, s_out;
     DevBuf<int4> s_tiles;
     DevBuf<int> s_ntiles;
+    DevBuf<unsigned long long> s_clk;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -241,6 +242,8 @@ void run_decoder_points(dsp_handle* h, const float* code, const float* pts, int6
     a.code_stride = CODE_LEN;
     a.out_sdf = h->s_out.p;
     a.out_grad = h->s_out.p;
+    h->s_clk.ensure(4);
+    a.clk = h->s_clk.p;
     HIP_TRY(launch_mlp(bwd, a, std::min(nt, h->n_cu), h->stream));
     if (!bwd) {
         HIP_TRY(hipMemcpyAsync(sdf_out, h->s_out.p, n * 4, hipMemcpyDeviceToHost, h->stream));
@@ -560,6 +563,13 @@ void run_terms(dsp_handle* h, const float* pts_cam, int64_t n_pts, const float* 
 extern "C" {
 
 int dsp_abi_version(void) { return 1; }
+
+/* Development aid: {shader-clock ticks, 100 MHz wall ticks} spent by workgroup 0 of the last dsp_decode_sdf /
+ * dsp_sdf_jacobian launch -> effective shader clock under load. */
+int dsp_debug_last_clocks(dsp_handle* h, uint64_t* out4) {
+    if (!h || !out4 || !h->s_clk.p) return DSP_E_ARG;
+    return guarded(h, [&] { HIP_TRY(hipSetDevice(h->device)); HIP_TRY(hipMemcpy(out4, h->s_clk.p, 32, hipMemcpyDeviceToHost)); });
+}
 
 /* Development aid: run forward+gradient on <= 64 points and dump every pass's output slab of the tile:
  * slabs_out[pass][wave][reg 0..127][lane 0..63], n_pass passes. */

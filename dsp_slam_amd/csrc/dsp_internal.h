@@ -46,6 +46,7 @@ struct MlpArgs {
     int code_stride;            // in floats (multiple of 4)
     float* out_sdf;             // FWD: [n_points]
     float* out_grad;            // BWD: [n_points][GRAD_STRIDE]
+    unsigned long long* clk;    // optional: block 0 writes {clock64, wall_clock64} at entry and exit (effective shader clock)
     float* dbg;                 // development aid: [pass][wave][128][64] slab dump of tile 0 (nullptr = off)
 };
 

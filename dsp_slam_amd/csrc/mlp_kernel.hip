@@ -28,18 +28,38 @@ constexpr int GLDS_PER_CHUNK = 4;             // per wave: 4 x 1 KiB pieces of a
 
 #define MFMA16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x4f32((A), (B), (C), 0, 0, 0)
 
-// LDS-DMA of 64 lanes x 16 B: global (per-lane address) -> LDS (wave-uniform base + lane*16).
-// Invisible to hipcc's s_waitcnt bookkeeping by design: completion is counted by hand below.
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+// LDS-DMA of one wave's quarter (4 KiB) of a weight chunk: four global_load_lds_dwordx4, each 64 lanes x 16 B from a
+// per-lane global address to LDS at M0 + lane*16.  The instruction's immediate offset moves BOTH the global source and
+// the LDS destination (measured: tools/probes/hw_probe.hip), so one address VGPR pair and one M0 value serve all four.
+// Invisible to hipcc's s_waitcnt bookkeeping by design: completion is counted by hand (vmcnt) below.
+__device__ __forceinline__ void glds_quarter(const void* gsrc, unsigned lds_dst) {
     unsigned keep;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
         "s_mov_b32 m0, %2\n\t"
         "s_nop 0\n\t"
         "global_load_lds_dwordx4 %1, off\n\t"
+        "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+        "global_load_lds_dwordx4 %1, off offset:2048\n\t"
+        "global_load_lds_dwordx4 %1, off offset:3072\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
         : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+
+// One 1 KiB piece of the quarter: PIECE selects the immediate offset (moves source and destination alike).
+template <int PIECE>
+__device__ __forceinline__ void glds_piece(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off offset:%3\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst), "n"(PIECE * 1024)
         : "memory");
 }
 
@@ -65,6 +85,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
 
     const int n_tiles = *a.n_tiles;
     if ((int)blockIdx.x >= n_tiles) return;
+    if (a.clk && blockIdx.x == 0 && tid == 0) { a.clk[0] = clock64(); a.clk[1] = wall_clock64(); }
     for (int i = tid; i < a.n_bias_rows * WIDTH; i += 256) bias_l[i] = a.bias_tab[i];
     __syncthreads();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -73,15 +94,24 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
     int issue_pos = 0, issue_slot = 0, rd_slot = 0;
     const char* wbase = reinterpret_cast<const char*>(a.wstream) + wave * 4096 + lane * 16;
     const int total_chunks = a.total_chunks;
-    auto issue = [&]() {
-        const char* src = wbase + (size_t)issue_pos * CHUNK_BYTES;
-        const unsigned dst = ring0 + issue_slot * CHUNK_BYTES + wave * 4096;
-        glds16(src, dst);
-        glds16(src + 1024, dst + 1024);
-        glds16(src + 2048, dst + 2048);
-        glds16(src + 3072, dst + 3072);
+    // A chunk refill is four LDS-DMA instructions per wave.  Each costs ~30-60 issue cycles (64 lane addresses through
+    // the address unit), so in the main loop they are spread over four k-steps, one behind an MFMA each, instead of
+    // stalling the matrix pipe for a whole burst (measured: the burst form cost 5 % of the kernel).
+    const char* isrc = wbase;
+    unsigned idst = ring0 + wave * 4096;
+    auto issue_next = [&]() {   // advance to the next chunk of the stream / next ring slot
         issue_pos = (issue_pos + 1 == total_chunks) ? 0 : issue_pos + 1;
         issue_slot = (issue_slot + 1 == NBUF) ? 0 : issue_slot + 1;
+#if defined(ABL_SAMESRC)
+        isrc = wbase;
+#else
+        isrc = wbase + (size_t)issue_pos * CHUNK_BYTES;
+#endif
+        idst = ring0 + issue_slot * CHUNK_BYTES + wave * 4096;
+    };
+    auto issue = [&]() {
+        glds_quarter(isrc, idst);
+        issue_next();
     };
 #pragma unroll
     for (int i = 0; i < NBUF - 1; ++i) issue();
@@ -93,9 +123,11 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
     abuf[1] = *reinterpret_cast<const f32x4*>(ring_ptr + lane * 16 + 1024);
 
     float sin_[128];   // input slab of the current pass:  sin_[4t+r] = row 16t + 4g + r of point pl
-    float sout[128];   // output slab being produced
+    f32x4 acc[32];     // output slab being produced: the MFMA accumulators of all 32 row tiles
 #pragma unroll
-    for (int i = 0; i < 128; ++i) { sin_[i] = 0.f; sout[i] = 0.f; }
+    for (int i = 0; i < 128; ++i) sin_[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int4 td = a.tiles[tile];
@@ -136,115 +168,113 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
                 for (int i = 0; i < 16; ++i) sin_[112 + i] = zr[i];
             }
 
-            for (int og = 0; og < pd.nog; ++og) {
-                f32x4 acc[4];
-                if (pd.bias_row >= 0) {
-                    const float* bp = bias_l + pd.bias_row * WIDTH + 64 * og + 4 * g;
+            // All 32 output tiles of the layer are MFMA accumulators (acc[4*og+j], 128 AGPRs) with static indices: the
+            // group / chunk / k-step loops are fully unrolled and skipped by uniform branches, so no register is ever
+            // indexed dynamically and the MFMA stream runs from one output group into the next without an epilogue.
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[j] = *reinterpret_cast<const f32x4*>(bp + 16 * j);
-                } else {
+            for (int og = 0; og < 8; ++og) {
+                if (og < pd.nog) {
+                    f32x4 bias4[4];
+                    if (pd.bias_row >= 0) {
+                        const float* bp = bias_l + pd.bias_row * WIDTH + 64 * og + 4 * g;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                }
+                        for (int j = 0; j < 4; ++j) bias4[j] = *reinterpret_cast<const f32x4*>(bp + 16 * j);
+                    } else {
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    if (c < pd.nchunks) {
-                        const int nx_slot = (rd_slot + 1 == NBUF) ? 0 : rd_slot + 1;
-                        const char* cb = ring_ptr + rd_slot * CHUNK_BYTES + lane * 16;
-                        const char* nb = ring_ptr + nx_slot * CHUNK_BYTES + lane * 16;
+                        for (int j = 0; j < 4; ++j) bias4[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
 #pragma unroll
-                        for (int s = 0; s < KSTEPS_PER_CHUNK; ++s) {
-                            if (s == KSTEPS_PER_CHUNK / 2) {
-                                // Chunk q+1 has landed for this wave once <= NBUF-3 younger chunks are in flight; the
-                                // barrier publishes every wave's quarter and proves all reads of chunk q-1 retired
-                                // (every wave is inside chunk q), so its slot can be refilled right away.
-                                asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(GLDS_PER_CHUNK * (NBUF - 3)) : "memory");
-                                issue();
+                    for (int c = 0; c < 8; ++c) {
+                        if (c < pd.nchunks) {
+                            const int nx_slot = (rd_slot + 1 == NBUF) ? 0 : rd_slot + 1;
+                            const char* cb = ring_ptr + rd_slot * CHUNK_BYTES + lane * 16;
+                            const char* nb = ring_ptr + nx_slot * CHUNK_BYTES + lane * 16;
+#pragma unroll
+                            for (int s = 0; s < KSTEPS_PER_CHUNK; ++s) {
+                                if (s == KSTEPS_PER_CHUNK / 2) {
+                                    // Chunk q+1 has landed for this wave once <= NBUF-3 younger chunks are in flight; the
+                                    // barrier publishes every wave's quarter and proves all reads of chunk q-1 retired
+                                    // (every wave is inside chunk q), so its slot can be refilled right away.
+#if defined(ABL_NOWAIT)
+                                    asm volatile("s_barrier" ::: "memory");
+#elif defined(ABL_NOBAR)
+                                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GLDS_PER_CHUNK * (NBUF - 3)) : "memory");
+#else
+                                    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(GLDS_PER_CHUNK * (NBUF - 3)) : "memory");
+#endif
+                                }
+                                const int sp = s + 2;
+#if !defined(ABL_NOLDS)
+                                abuf[sp % 4] = (sp < KSTEPS_PER_CHUNK)
+                                                   ? *reinterpret_cast<const f32x4*>(cb + sp * 1024)
+                                                   : *reinterpret_cast<const f32x4*>(nb + (sp - KSTEPS_PER_CHUNK) * 1024);
+#endif
+                                const f32x4 av = abuf[s % 4];
+                                const float b = sin_[16 * c + s];
+                                acc[4 * og + 0] = MFMA16(av.x, b, (c == 0 && s == 0) ? bias4[0] : acc[4 * og + 0]);
+#if !defined(ABL_NOISSUE)
+                                // refill of the slot freed by the barrier above: one DMA piece per k-step, behind an MFMA
+                                if (s == KSTEPS_PER_CHUNK / 2 + 0) glds_piece<0>(isrc, idst);
+                                if (s == KSTEPS_PER_CHUNK / 2 + 1) glds_piece<1>(isrc, idst);
+                                if (s == KSTEPS_PER_CHUNK / 2 + 2) glds_piece<2>(isrc, idst);
+                                if (s == KSTEPS_PER_CHUNK / 2 + 3) { glds_piece<3>(isrc, idst); issue_next(); }
+#endif
+                                acc[4 * og + 1] = MFMA16(av.y, b, (c == 0 && s == 0) ? bias4[1] : acc[4 * og + 1]);
+                                acc[4 * og + 2] = MFMA16(av.z, b, (c == 0 && s == 0) ? bias4[2] : acc[4 * og + 2]);
+                                acc[4 * og + 3] = MFMA16(av.w, b, (c == 0 && s == 0) ? bias4[3] : acc[4 * og + 3]);
+                                // pin "read for k-step s+2, then the four MFMAs of k-step s": left alone, hipcc sinks
+                                // every ds_read next to its use (one A buffer, lgkmcnt(0) before each MFMA quad)
+                                __builtin_amdgcn_sched_barrier(0);
                             }
-                            const int sp = s + 2;
-                            abuf[sp % 4] = (sp < KSTEPS_PER_CHUNK)
-                                               ? *reinterpret_cast<const f32x4*>(cb + sp * 1024)
-                                               : *reinterpret_cast<const f32x4*>(nb + (sp - KSTEPS_PER_CHUNK) * 1024);
-                            const f32x4 av = abuf[s % 4];
-                            const float b = sin_[16 * c + s];
-                            acc[0] = MFMA16(av.x, b, acc[0]);
-                            acc[1] = MFMA16(av.y, b, acc[1]);
-                            acc[2] = MFMA16(av.z, b, acc[2]);
-                            acc[3] = MFMA16(av.w, b, acc[3]);
-                            // pin "read for k-step s+2, then the four MFMAs of k-step s": left alone, hipcc sinks
-                            // every ds_read next to its use (one A buffer, lgkmcnt(0) before each MFMA quad)
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                        rd_slot = nx_slot;
-                    }
-                }
-                // ---- output-group epilogue --------------------------------------------------------
-                float v[16];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    v[4 * j + 0] = acc[j].x; v[4 * j + 1] = acc[j].y; v[4 * j + 2] = acc[j].z; v[4 * j + 3] = acc[j].w;
-                }
-                if (pd.relu) {
-                    unsigned bits = 0;
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        bits |= (v[k] > 0.f ? 1u : 0u) << k;
-                        v[k] = fmaxf(v[k], 0.f);
-                    }
-                    if (BWD) mask_l[(pd.mask_slot * 8 + og) * 256 + tid] = (unsigned short)bits;
-                } else if (BWD && pd.mask_slot >= 0) {
-                    if (pd.kind == 4) {
-                        // latent_in layer: rows 445..447 / 448..511 of its input are the re-injected xyz / code, not
-                        // relu outputs -- keep their gradients (unmasked) for the final d/d[code,xyz] sum
-                        if (og == 6) { skipx[0] = v[13]; skipx[1] = v[14]; skipx[2] = v[15]; }
-                        if (og == 7) {
-#pragma unroll
-                            for (int k = 0; k < 16; ++k) skipc[k] = v[k];
+                            rd_slot = nx_slot;
                         }
                     }
-                    const unsigned bits = mask_l[(pd.mask_slot * 8 + og) * 256 + tid];
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) v[k] = ((bits >> k) & 1u) ? v[k] : 0.f;
                 }
-#define ST(K) sout[BASE + K] = v[K];
-                switch (og) {
-#define BASE 0
-                    case 0: FOR16(ST) break;
-#undef BASE
-#define BASE 16
-                    case 1: FOR16(ST) break;
-#undef BASE
-#define BASE 32
-                    case 2: FOR16(ST) break;
-#undef BASE
-#define BASE 48
-                    case 3: FOR16(ST) break;
-#undef BASE
-#define BASE 64
-                    case 4: FOR16(ST) break;
-#undef BASE
-#define BASE 80
-                    case 5: FOR16(ST) break;
-#undef BASE
-#define BASE 96
-                    case 6: FOR16(ST) break;
-#undef BASE
-#define BASE 112
-                    default: FOR16(ST) break;
-#undef BASE
-                }
-#undef ST
             }
 
-            // ---- pass epilogue ---------------------------------------------------------------------
+            // ---- layer epilogue: relu (+ mask store) or mask apply, accumulators -> next layer's input slab ----------
+#pragma unroll
+            for (int og = 0; og < 8; ++og) {
+                if (og < pd.nog) {
+                    float v[16];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[4 * j + 0] = acc[4 * og + j].x; v[4 * j + 1] = acc[4 * og + j].y;
+                        v[4 * j + 2] = acc[4 * og + j].z; v[4 * j + 3] = acc[4 * og + j].w;
+                    }
+                    if (pd.relu) {
+                        unsigned bits = 0;
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) {
+                            bits |= (v[k] > 0.f ? 1u : 0u) << k;
+                            v[k] = fmaxf(v[k], 0.f);
+                        }
+                        if (BWD) mask_l[(pd.mask_slot * 8 + og) * 256 + tid] = (unsigned short)bits;
+                    } else if (BWD && pd.mask_slot >= 0) {
+                        if (pd.kind == 4) {
+                            // latent_in layer: rows 445..447 / 448..511 of its input are the re-injected xyz / code, not
+                            // relu outputs -- keep their gradients (unmasked) for the final d/d[code,xyz] sum
+                            if (og == 6) { skipx[0] = v[13]; skipx[1] = v[14]; skipx[2] = v[15]; }
+                            if (og == 7) {
+#pragma unroll
+                                for (int k = 0; k < 16; ++k) skipc[k] = v[k];
+                            }
+                        }
+                        const unsigned bits = mask_l[(pd.mask_slot * 8 + og) * 256 + tid];
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) v[k] = ((bits >> k) & 1u) ? v[k] : 0.f;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) sin_[16 * og + k] = v[k];
+                }
+            }
+
             if (DBG && tile == 0) {   // development aid: dump the output slab of every pass of tile 0
                 float* dp = a.dbg + ((size_t)(ps * 4 + wave) * 128) * 64 + lane;
 #pragma unroll
-                for (int i = 0; i < 128; ++i) dp[i * 64] = sout[i];
+                for (int i = 0; i < 128; ++i) dp[i * 64] = sin_[i];
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-#pragma unroll
-            for (int i = 0; i < 128; ++i) sin_[i] = sout[i];
 
             if (ps == a.n_fwd - 1) {
                 // final layer (512 -> 1) on the VALU + tanh  (deep_sdf_decoder.py:93,107-108)
@@ -307,6 +337,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (a.clk && blockIdx.x == 0 && tid == 0) { a.clk[2] = clock64(); a.clk[3] = wall_clock64(); }
 }
 
 template __global__ void mlp_kernel<false, false>(const MlpArgs);

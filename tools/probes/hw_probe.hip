@@ -37,6 +37,22 @@ __global__ void k_glds(const float* src, float* out, int n_slots) {
     if (threadIdx.x == 0) out[n_slots * 4096] = (float)base;
 }
 
+__global__ void k_glds_off(const float* src, float* out) {
+    // does the instruction's immediate offset move the LDS destination too, or only the global source?
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    float* f = (float*)smem;
+    for (int i = threadIdx.x; i < 4096; i += 64) f[i] = -1.f;
+    __syncthreads();
+    const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const char* g = (const char*)src + lane * 16;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:2048\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(base) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int i = threadIdx.x; i < 4096; i += 64) out[i] = f[i];
+}
+
 int main() {
     // (1) MFMA maps: A[i][k] = 100*i + k,  B[k][j] = (k==kk)*... use one-hot probes
     std::vector<float> ha(64), hb(64), hd(256);
@@ -77,6 +93,16 @@ int main() {
             if (v == (float)(s * 4096 + i)) ++ok; else if (v == -1.f) ++untouched; else { if (!other) first_other = v; ++other; }
         }
         printf(" slot %d @%6d: ok %4d untouched %4d other %4d (first other value %.0f)\n", s, s * 16384, ok, untouched, other, first_other);
+    }
+    {
+        float* dout2; hipMalloc(&dout2, 4096 * 4);
+        hipLaunchKernelGGL(k_glds_off, dim3(1), dim3(64), 16384, 0, ds, dout2);
+        std::vector<float> h2(4096);
+        hipMemcpy(h2.data(), dout2, 4096 * 4, hipMemcpyDeviceToHost);
+        int first = -1; for (int i = 0; i < 4096; ++i) if (h2[i] != -1.f) { first = i; break; }
+        printf("glds offset:2048 with M0=base: first written float index %d (LDS byte %d), value %.0f (source float index) -> %s\n",
+               first, first * 4, first >= 0 ? h2[first] : -1.f,
+               first == 0 ? "offset applies to GLOBAL only" : (first == 512 ? "offset applies to BOTH global and LDS" : "other"));
     }
     return 0;
 }
