@@ -283,7 +283,7 @@ struct dsp_batch {
     DevBuf<unsigned char> alive;
     DevBuf<int4> tiles_f, tiles_j;
     DevBuf<int> n_tiles, out_status;
-    DevBuf<double> counters;
+    DevBuf<double> counters, gsum;
     std::vector<hipEvent_t> ev;   // pairs around every decoder launch + [run start, run end]
     std::vector<int> ev_kind;
     dsp_stats stats;
@@ -370,6 +370,7 @@ dsp_batch* batch_build(dsp_handle* h, const dsp_gn_params* prm, int B, const int
     b->n_tiles.alloc(2);
     b->counters.alloc(2);
     b->partials.alloc((size_t)B * 2 * b->n_slices * 72 * 72);
+    b->gsum.alloc((size_t)B * 2 * 72 * 72);
     b->out_t.alloc((size_t)B * 16); b->out_code.alloc((size_t)B * CODE_LEN); b->out_loss.alloc(B); b->out_status.alloc(B);
     memset(&b->stats, 0, sizeof b->stats);
     return b.release();
@@ -452,7 +453,7 @@ void batch_run(dsp_batch* b) {
         iteration_front(b, cursor, !b->pose_only);
         launch_gram(b->oc.p, b->st.p, b->jpts.p, b->jaux.p, b->jgrad.p, b->pose_only ? b->alive.p : nullptr, b->partials.p,
                     b->n_slices, b->prm.b2, b->prm.b1, b->pose_only ? 0 : 1, b->pose_only ? 1 : 2, B, s);
-        launch_solve(b->oc.p, b->st.p, b->partials.p, b->n_slices, dp, e, b->trace_on ? b->trace.p : nullptr, B, s);
+        launch_solve(b->oc.p, b->st.p, b->partials.p, b->gsum.p, b->n_slices, dp, e, b->trace_on ? b->trace.p : nullptr, B, s);
         if (b->pose_only && e == 4) launch_inlier_filter(b->oc.p, b->st.p, b->jgrad.p, b->alive.p, b->maxM, B, s);
     }
     launch_finalize(b->st.p, b->scale_in.p, B, b->pose_only ? 1 : 0, b->out_t.p, b->out_code.p, b->out_loss.p, b->out_status.p, s);

@@ -100,7 +100,8 @@ void launch_sum_m(const ObjConst* oc, ObjState* st, const int* mcnt, int B, hipS
 void launch_gram(const ObjConst* oc, const ObjState* st, const float4* jpts, const float2* jaux, const float* jgrad, const unsigned char* alive,
                  float* partials, int n_slices, float b_sdf, float b_render, int robust, int n_terms, int B, hipStream_t s);
 void launch_jrows(const ObjConst* oc, const ObjState* st, const float4* jpts, const float2* jaux, const float* jgrad, int term, float* rows, int cap, hipStream_t s);
-void launch_solve(const ObjConst* oc, ObjState* st, const float* partials, int n_slices, const GnParamsDev& prm, int iter, float* trace, int B, hipStream_t s);
+void launch_solve(const ObjConst* oc, ObjState* st, const float* partials, double* gsum, int n_slices, const GnParamsDev& prm, int iter,
+                  float* trace, int B, hipStream_t s);
 void launch_inlier_filter(const ObjConst* oc, ObjState* st, const float* jgrad, unsigned char* alive, int maxM, int B, hipStream_t s);
 void launch_finalize(ObjState* st, const float* scale, int B, int pose_only, float* t, float* code, float* loss, int* status, hipStream_t s);
 

@@ -534,32 +534,35 @@ __device__ void rotation_prior(const ObjState& s, float* jrot, float& res) {
 
 constexpr int NSOLVE = 71;
 
-__global__ __launch_bounds__(256) void k_solve(const ObjConst* oc, ObjState* st, const float* partials, int n_slices,
-                                               GnParamsDev prm, int iter, float* trace /*nullable*/, int n_obj) {
+// per-slice Gram partials -> one fp64 Gram matrix per (object, term); fixed summation order
+__global__ __launch_bounds__(256) void k_gram_reduce(const ObjState* st, const float* partials, int n_slices, double* gsum) {
+    const int b = blockIdx.y, term = blockIdx.z;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= 72 * 72 || st[b].status != DSP_STATUS_GOOD) return;
+    const float* p = partials + (((size_t)b * 2 + term) * n_slices) * (72 * 72) + e;
+    double a = 0.0;
+#pragma unroll 8
+    for (int sl = 0; sl < n_slices; ++sl) a += (double)p[(size_t)sl * 72 * 72];
+    gsum[((size_t)b * 2 + term) * (72 * 72) + e] = a;
+}
+
+__global__ __launch_bounds__(256) void k_solve(const ObjConst* oc, ObjState* st, const double* gsum, GnParamsDev prm, int iter,
+                                               float* trace /*nullable*/, int n_obj) {
     __shared__ double A[NSOLVE][NSOLVE + 1];
-    __shared__ int piv;
-    __shared__ double pval;
-    __shared__ float lossv[2];
     const int b = blockIdx.x, tid = threadIdx.x;
     const ObjConst c = oc[b];
     ObjState& s = st[b];
     if (s.status != DSP_STATUS_GOOD) return;
-    // Gram entry (term, i, j) = sum of the per-slice partials (fp64 accumulation, fixed order)
-    auto gram = [&](int term, int i, int j) -> double {
-        const float* p = partials + (((size_t)b * 2 + term) * n_slices) * (72 * 72) + i * 72 + j;
-        double a = 0.0;
-        for (int sl = 0; sl < n_slices; ++sl) a += (double)p[(size_t)sl * 72 * 72];
-        return a;
-    };
+    const double* G0 = gsum + ((size_t)b * 2 + 0) * (72 * 72);
+    const double* G1 = gsum + ((size_t)b * 2 + 1) * (72 * 72);
     const int M = c.n_pts, K = s.K;
     const int pd = prm.pose_only ? 6 : 7;
     const int n = prm.pose_only ? 6 : NSOLVE;
     if (!prm.pose_only) {
         // losses (optimizer.py:134-155): mean of robust residual^2; an empty set gives NaN in the reference
         if (M == 0 || K == 0) { if (tid == 0) s.status = DSP_STATUS_NAN; return; }
-        if (tid < 2) lossv[tid] = (float)gram(tid, 71, 71) / (float)(tid == 0 ? M : K);
-        __syncthreads();
-        const float sdf_loss = lossv[0], ren_loss = lossv[1];
+        const float sdf_loss = (float)G0[71 * 72 + 71] / (float)M;
+        const float ren_loss = (float)G1[71 * 72 + 71] / (float)K;
         if (isnan(sdf_loss) || isnan(ren_loss)) { if (tid == 0) s.status = DSP_STATUS_NAN; return; }
         if (tid == 0) s.loss = prm.k1 * ren_loss + prm.k2 * sdf_loss;
         float jrot[7], res_rot;
@@ -569,13 +572,13 @@ __global__ __launch_bounds__(256) void k_solve(const ObjConst* oc, ObjState* st,
             const int i = e / (n + 1), j = e % (n + 1);
             double v;
             if (j < n) {
-                v = w_s * gram(0, i, j) + w_r * gram(1, i, j);                                  // :161-168
+                v = w_s * G0[i * 72 + j] + w_r * G1[i * 72 + j];                              // :161-168
                 if (i >= pd && i == j) v += (double)prm.k3;                                    // :170
                 if (i < pd && j < pd) v += (double)prm.k4 * (double)jrot[i] * (double)jrot[j]; // :176,178
                 if (i < pd && i == j) v += 1.0;                                                // :183
                 if (i == pd - 1 && j == pd - 1) v += (double)prm.s_damp;                       // :184
             } else {
-                v = -(w_s * gram(0, i, 71) + w_r * gram(1, i, 71));                            // b = -J^T r~
+                v = -(w_s * G0[i * 72 + 71] + w_r * G1[i * 72 + 71]);                          // b = -J^T r~
                 if (i >= pd) v -= (double)prm.k3 * (double)s.code[i - pd];                     // :172
                 if (i < pd) v += (double)prm.k4 * (double)jrot[i] * (double)res_rot;           // :177,179 (sign as written)
             }
@@ -588,8 +591,8 @@ __global__ __launch_bounds__(256) void k_solve(const ObjConst* oc, ObjState* st,
         for (int e = tid; e < n * (n + 1); e += 256) {
             const int i = e / (n + 1), j = e % (n + 1);
             double v;
-            if (j < n) { v = gram(0, i, j) / (double)Ma; if (i == j) v += 1e-2; }
-            else v = -gram(0, i, 71) / (double)Ma;
+            if (j < n) { v = G0[i * 72 + j] / (double)Ma; if (i == j) v += 1e-2; }
+            else v = -G0[i * 72 + 71] / (double)Ma;
             A[i][j] = v;
         }
     }
@@ -605,35 +608,25 @@ __global__ __launch_bounds__(256) void k_solve(const ObjConst* oc, ObjState* st,
             tr[NSOLVE * NSOLVE + 2 * NSOLVE + 81] = (float)s.m;
             tr[NSOLVE * NSOLVE + 2 * NSOLVE + 82] = (float)s.K;
         }
+        __syncthreads();
     }
-    __syncthreads();
-    // 2. Gaussian elimination with partial pivoting on [H | b] in fp64 (the reference inverts H in fp32, :186)
+    // 2. Gauss-Jordan elimination of [H | b] in fp64.  H = sum w J^T J + positive diagonal is symmetric positive
+    //    definite, so no pivoting is needed (the reference inverts H with fp32 LU, optimizer.py:186); eliminating above
+    //    and below the diagonal leaves x_i = A[i][n] / A[i][i] with no serial back-substitution.  Column k itself is
+    //    never rewritten (it is not read again), so one barrier per step suffices.
     for (int k = 0; k < n; ++k) {
-        if (tid == 0) {
-            int p = k; double best = fabs(A[k][k]);
-            for (int r = k + 1; r < n; ++r) { const double v = fabs(A[r][k]); if (v > best) { best = v; p = r; } }
-            piv = p; pval = A[p][k];
-        }
-        __syncthreads();
-        if (piv != k) {
-            for (int j = tid; j <= n; j += 256) { const double t = A[k][j]; A[k][j] = A[piv][j]; A[piv][j] = t; }
-            __syncthreads();
-        }
-        if (pval == 0.0 || isnan(pval)) { if (tid == 0) s.status = DSP_STATUS_NAN; return; }
-        const int rows = n - k - 1, cols = n - k;   // columns k+1..n
-        for (int e = tid; e < rows * cols; e += 256) {
-            const int r = k + 1 + e / cols, j = k + 1 + e % cols;
-            A[r][j] -= (A[r][k] / pval) * A[k][j];
+        const double pv = A[k][k];
+        if (!(fabs(pv) > 0.0) || isnan(pv)) { if (tid == 0) s.status = DSP_STATUS_NAN; return; }
+        const int cols = n - k;   // columns k+1 .. n
+        for (int e = tid; e < (n - 1) * cols; e += 256) {
+            int r = e / cols;
+            if (r >= k) ++r;
+            const int j = k + 1 + e % cols;
+            A[r][j] -= (A[r][k] / pv) * A[k][j];
         }
         __syncthreads();
     }
-    if (tid == 0) {
-        for (int i = n - 1; i >= 0; --i) {
-            double v = A[i][n];
-            for (int j = i + 1; j < n; ++j) v -= A[i][j] * A[j][n];
-            A[i][n] = v / A[i][i];
-        }
-    }
+    if (tid < n) A[tid][n] = A[tid][n] / A[tid][tid];
     __syncthreads();
     if (trace) {
         float* tr = trace + ((size_t)iter * n_obj + b) * TRACE_STRIDE;
@@ -743,8 +736,10 @@ void launch_gram(const ObjConst* oc, const ObjState* st, const float4* jpts, con
 void launch_jrows(const ObjConst* oc, const ObjState* st, const float4* jpts, const float2* jaux, const float* jgrad, int term, float* rows, int cap, hipStream_t s) {
     hipLaunchKernelGGL(k_jrows, dim3((cap + 255) / 256), dim3(256), 0, s, oc, st, jpts, jaux, jgrad, term, rows);
 }
-void launch_solve(const ObjConst* oc, ObjState* st, const float* partials, int n_slices, const GnParamsDev& prm, int iter, float* trace, int B, hipStream_t s) {
-    hipLaunchKernelGGL(k_solve, dim3(B), dim3(256), 0, s, oc, st, partials, n_slices, prm, iter, trace, B);
+void launch_solve(const ObjConst* oc, ObjState* st, const float* partials, double* gsum, int n_slices, const GnParamsDev& prm, int iter,
+                  float* trace, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_gram_reduce, dim3((72 * 72 + 255) / 256, B, prm.pose_only ? 1 : 2), dim3(256), 0, s, st, partials, n_slices, gsum);
+    hipLaunchKernelGGL(k_solve, dim3(B), dim3(256), 0, s, oc, st, gsum, prm, iter, trace, B);
 }
 void launch_inlier_filter(const ObjConst* oc, ObjState* st, const float* jgrad, unsigned char* alive, int maxM, int B, hipStream_t s) {
     hipLaunchKernelGGL(k_inlier_filter, GRID2(maxM, B), dim3(256), 0, s, oc, st, jgrad, alive);
