@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Per-kernel PMC sums from a rocprofv3 (ROCm 7.2 rocpd sqlite) counter-collection run:
+   python tools/rocpd_pmc.py <results.db> [kernel-name-substring]"""
+import sqlite3
+import sys
+
+
+def main():
+    db = sqlite3.connect(sys.argv[1])
+    cur = db.cursor()
+    sub = sys.argv[2] if len(sys.argv) > 2 else ""
+    # pmc_event.event_id -> rocpd_event.id ; kernel dispatch rows carry event_id too
+    cols = [c[1] for c in cur.execute("pragma table_info('rocpd_kernel_dispatch')")]
+    key = "event_id" if "event_id" in cols else "id"
+    q = ("select s.kernel_name, p.name, count(distinct d.id), sum(e.value), sum(d.end - d.start) / count(distinct p.name || e.id) * 1.0 "
+         "from rocpd_pmc_event e join rocpd_info_pmc p on e.pmc_id = p.id "
+         "join rocpd_kernel_dispatch d on d.%s = e.event_id join rocpd_info_kernel_symbol s on d.kernel_id = s.id "
+         "where s.kernel_name like ? group by s.kernel_name, p.name order by s.kernel_name, p.name" % key)
+    rows = cur.execute(q, ("%" + sub + "%",)).fetchall()
+    print("| kernel | counter | dispatches | sum | per dispatch |")
+    print("|---|---|---|---|---|")
+    for name, pmc, n, total, _ in rows:
+        short = name if len(name) < 60 else name[:57] + "..."
+        print("| %s | %s | %d | %.6g | %.6g |" % (short, pmc, n, total, total / max(n, 1)))
+    # durations per kernel for rate computations
+    rows = cur.execute("select s.kernel_name, count(*), sum(d.end - d.start) from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s "
+                       "on d.kernel_id = s.id where s.kernel_name like ? group by s.kernel_name", ("%" + sub + "%",)).fetchall()
+    for name, n, ns in rows:
+        print("duration: %s  dispatches %d  total %.3f ms" % (name[:60], n, ns / 1e6))
+
+
+if __name__ == "__main__":
+    main()
