@@ -1,0 +1,63 @@
+"""GPU: DSP-SLAM's C++ call surface replayed by a real pybind11-embed program (tests/embed/embed_harness.cpp) from a
+non-main std::thread under PyGILState_Ensure, with Fortran-ordered float32 arrays like pybind11's Eigen caster makes.
+The values C++ reads back must equal what the Python API returns for the same inputs, bit for bit."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import golden
+from dsp_slam_amd import fixtures
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HARNESS = os.path.join(ROOT, "tests", "embed", "embed_harness")
+
+
+def _build():
+    if not os.path.exists(HARNESS) or os.path.getmtime(HARNESS) < os.path.getmtime(HARNESS + ".cpp"):
+        subprocess.check_call([os.path.join(ROOT, "tests", "embed", "build.sh")])
+
+
+def test_harness_builds_cpu():
+    """CPU-only part: the harness compiles against pybind11/embed.h + numpy.h (no Eigen needed)."""
+    _build()
+    assert os.access(HARNESS, os.X_OK)
+
+
+@pytest.mark.gpu
+def test_cpp_embed_call_surface(tmp_path):
+    _build()
+    ddir = fixtures.materialize_decoder_dir("cars", str(tmp_path / "cars_64"))
+    cfg = json.load(open(os.path.join(ROOT, "tests", "golden", "config_kitti_optimizer.json")))
+    cfg["DeepSDF_DIR"] = ddir
+    cfg["voxels_dim"] = 16
+    (tmp_path / "cfg.json").write_text(json.dumps(cfg))
+    g = golden("golden_recon_small.npz")
+    gp = golden("golden_pose_only.npz")
+    np.savez(tmp_path / "in.npz", t_cam_obj=g["in_t_cam_obj_init"], pts=g["in_pts"], rays=g["in_rays"], depth=g["in_depth"],
+             pose_t_co_se3=gp["t_co_se3"], pose_scale=gp["scale"], pose_pts=gp["pts"], pose_code=gp["code"])
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    out = subprocess.run([HARNESS, os.path.join(ROOT, "dsp_slam_amd"), str(tmp_path / "cfg.json"), str(tmp_path / "in.npz")],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = {}
+    for line in out.stdout.splitlines():
+        k, *v = line.split()
+        res[k] = np.array([float(x) for x in v], np.float32)
+    assert res["is_good"][0] == 1 and res["keyerror"][0] == 1 and res["code_len"][0] == 64 and res["grid_size"][0] == 16 ** 3
+    # same numbers as the direct Python / C-ABI path
+    from oracle import dsp_oracle as O
+    from dsp_slam_amd import engine as E
+    dec = O.fold_decoder(fixtures.load_decoder_npz(fixtures.fixture_path("cars")), fixtures.SPECS)
+    eng = E.Engine(dec.layers, dec.latent_in, dec.code_len, device=0)
+    prm = E.params_from_configs(cfg)
+    t, code, loss, status = eng.reconstruct_batch(prm, [g["in_t_cam_obj_init"]], [g["in_pts"]], [g["in_rays"]], [g["in_depth"]])
+    assert np.array_equal(res["t_cam_obj"].reshape(4, 4), t[0]) and np.array_equal(res["code"], code[0])
+    t2, code2, loss2, _ = eng.reconstruct_batch(prm, [g["in_t_cam_obj_init"]], [g["in_pts"]], [g["in_rays"]], [g["in_depth"]], [code[0]])
+    assert np.array_equal(res["t_cam_obj2"].reshape(4, 4), t2[0]) and res["loss2"][0] == loss2[0]
+    pose = eng.estimate_pose_batch(prm, [gp["t_co_se3"]], [float(gp["scale"])], [gp["pts"]], [gp["code"]])
+    assert np.array_equal(res["pose_only"].reshape(4, 4), pose[0])
+    assert np.abs(pose[0] - gp["out"]).max() < 1e-4 * np.abs(gp["out"]).max()      # and the reference's golden pose
+    eng.close()
