@@ -337,7 +337,7 @@ dsp_batch* batch_build(dsp_handle* h, const dsp_gn_params* prm, int B, const int
     b->sum_pts = pts_off[B];
     b->sum_rays = pose_only ? 0 : ray_off[B];
     b->sum_depth = pose_only ? 0 : depth_off[B];
-    b->n_slices = std::max(2, std::min(32, 2048 / B));
+    b->n_slices = 16;   // fixed: the Gram summation order (hence every bit of the result) must not depend on the batch
     b->oc.alloc(B);
     b->st.alloc(B);
     HIP_TRY(hipMemcpy(b->oc.p, b->oc_host.data(), B * sizeof(ObjConst), hipMemcpyHostToDevice));
@@ -718,7 +718,7 @@ int dsp_batch_enable_trace(dsp_batch* b, int on) {
 }
 
 int dsp_batch_trace(dsp_batch* b, int32_t iteration, float* H, float* bvec, float* dx, int64_t* V, int64_t* m, int64_t* K,
-                    float* t_obj_cam, float* code) {
+                    float* t_obj_cam, float* code, uint32_t* set_sums, float* depths) {
     if (!b || !b->trace_on || iteration < 0 || iteration >= b->iters_run) return DSP_E_STATE;
     return guarded(b->h, [&] {
         const int B = b->B;
@@ -736,6 +736,11 @@ int dsp_batch_trace(dsp_batch* b, int32_t iteration, float* H, float* bvec, floa
             if (V) V[i] = (int64_t)t[71 * 71 + 142 + 80];
             if (m) m[i] = (int64_t)t[71 * 71 + 142 + 81];
             if (K) K[i] = (int64_t)t[71 * 71 + 142 + 82];
+            if (depths) memcpy(depths + (size_t)i * 64, t + 5280, 64 * 4);
+            if (set_sums) {
+                set_sums[2 * i + 0] = (uint32_t)t[71 * 71 + 142 + 83] | ((uint32_t)t[71 * 71 + 142 + 84] << 16);
+                set_sums[2 * i + 1] = (uint32_t)t[71 * 71 + 142 + 85] | ((uint32_t)t[71 * 71 + 142 + 86] << 16);
+            }
         }
     });
 }

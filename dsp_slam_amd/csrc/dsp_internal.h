@@ -55,7 +55,7 @@ constexpr int DSP_STATUS_GOOD = 0;
 constexpr int DSP_STATUS_FEW = 1;    // < 10 in-sphere samples (loss.py:73-74)
 constexpr int DSP_STATUS_NAN = 2;    // NaN loss / singular system (optimizer.py:135-136,149-150)
 constexpr int MAX_DEPTH_SAMPLES = 64;
-constexpr int TRACE_STRIDE = 5272;   // 71*71 H | 71 b | 71 dx | 16 t_oc | 64 code | V m K (+pad)
+constexpr int TRACE_STRIDE = 5344;   // 71*71 H | 71 b | 71 dx | 16 t_oc | 64 code | V m K | vsum lo,hi | ksum lo,hi | pad | 64 depths
 
 struct ObjConst {           // static layout of one object inside the batch arrays
     int pts_off, n_pts;     // surface points (camera frame)
@@ -74,7 +74,9 @@ struct ObjState {           // per-object optimiser state, lives on the device f
     float depths[MAX_DEPTH_SAMPLES];
     float scale, dmin, dmax, loss;
     int status, V, m, K;
-    int n_alive, pad0, pad1, pad2;
+    int n_alive;
+    unsigned vsum, ksum;    // order-independent checksums of the in-sphere set and of the kept (jacobian) sample set
+    int pad2;
 };
 
 struct GnParamsDev {
@@ -87,12 +89,12 @@ size_t mlp_lds_bytes(bool bwd);
 hipError_t mlp_prepare_device();
 hipError_t launch_mlp(bool bwd, const MlpArgs& args, int n_blocks, hipStream_t stream);
 void launch_init_state(ObjState* st, const float* t, const float* codes, const float* scale, int B, int D, int pose_only, hipStream_t s);
-void launch_sample_count(const ObjConst* oc, const ObjState* st, const float* rays, unsigned long long* m, int* c, int D, int maxR, int B, hipStream_t s);
+void launch_sample_count(const ObjConst* oc, ObjState* st, const float* rays, unsigned long long* m, int* c, int D, int maxR, int B, hipStream_t s);
 void launch_scan_rays(const ObjConst* oc, ObjState* st, const int* cnt, int* off, int which, int B, hipStream_t s);
 void launch_sample_write(const ObjConst* oc, const ObjState* st, const float* rays, const unsigned long long* m, const int* off, float4* spts, int D, int maxR, int B, hipStream_t s);
 void launch_surface(const ObjConst* oc, const ObjState* st, const float* pts, float4* jpts, float2* jaux, int maxM, int B, hipStream_t s);
 void launch_build_tiles(const ObjConst* oc, const ObjState* st, int B, int mode, int4* tiles, int* n_tiles, double* counters, hipStream_t s);
-void launch_render_scan(const ObjConst* oc, const ObjState* st, const unsigned long long* m, const int* off, const float* ssdf, const float* depth,
+void launch_render_scan(const ObjConst* oc, ObjState* st, const unsigned long long* m, const int* off, const float* ssdf, const float* depth,
                         float* sdeds, float* ray_res, int* kcnt, int* mcnt, int D, float th, int maxR, int B, hipStream_t s);
 void launch_render_write(const ObjConst* oc, const ObjState* st, const int* raycnt, const int* rayoff, const int* koff, const float4* spts,
                          const float* sdeds, const float* ray_res, float4* jpts, float2* jaux, int maxR, int B, hipStream_t s);

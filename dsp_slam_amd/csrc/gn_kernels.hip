@@ -87,14 +87,19 @@ __global__ void k_init_state(ObjState* st, const float* t_cam_obj, const float* 
     if (!inv4(tco, toc)) { s.status = DSP_STATUS_NAN; for (int i = 0; i < 16; ++i) toc[i] = (i % 5 == 0); }
     for (int i = 0; i < 16; ++i) s.t_oc[i] = (float)toc[i];
     for (int i = 0; i < CODE_LEN; ++i) s.code[i] = codes ? codes[CODE_LEN * b + i] : 0.f;
-    s.loss = 0.f; s.V = 0; s.m = 0; s.K = 0; s.n_alive = -1;
+    s.loss = 0.f; s.V = 0; s.m = 0; s.K = 0; s.n_alive = -1; s.vsum = 0; s.ksum = 0;
     if (!pose_only) derive_iter_state(s, n_depth);
 }
+
+// membership checksum of a sample id (ray << 6 | depth index): wrap-around sum of a per-id hash, so two runs agree on it
+// iff (up to 2^-32) they selected the same SET of samples -- equal counts alone do not show that (tests compare it with
+// the oracle's).
+__device__ __forceinline__ unsigned id_hash(unsigned id) { return (id * 2654435761u) ^ (id >> 7); }
 
 // ------------------------------------------------------------------------------------------------
 // ray sampling: in-sphere mask + count per ray  (loss.py:60-70)
 // ------------------------------------------------------------------------------------------------
-__global__ void k_sample_count(const ObjConst* oc, const ObjState* st, const float* rays, unsigned long long* raymask,
+__global__ void k_sample_count(const ObjConst* oc, ObjState* st, const float* rays, unsigned long long* raymask,
                                int* raycnt, int n_depth) {
     const int b = blockIdx.y;
     const ObjConst c = oc[b];
@@ -114,6 +119,9 @@ __global__ void k_sample_count(const ObjConst* oc, const ObjState* st, const flo
     }
     raymask[c.ray_off + r] = mask;
     raycnt[c.ray_off + r] = __popcll(mask);
+    unsigned h = 0;
+    for (unsigned long long m = mask; m; m &= m - 1) h += id_hash(((unsigned)r << 6) | (unsigned)(__ffsll((long long)m) - 1));
+    if (h) atomicAdd(&st[b].vsum, h);
 }
 
 // exclusive scan of per-ray counts inside each object (one workgroup per object)
@@ -226,7 +234,7 @@ __global__ __launch_bounds__(256) void k_build_tiles(const ObjConst* oc, const O
 // One thread per ray, the 50-sample row kept in registers.  Pass 1 (count): occupancy o_j, T_l =
 // prod_{i<=l}(1-o_i), rendered depth d_u, suffix sums for de_do, keeps samples with |sdf| < th and
 // de_do > 1e-2; stores de_ds per compact sample (0 = dropped), d_u per ray and the kept count.
-__global__ void k_render_scan(const ObjConst* oc, const ObjState* st, const unsigned long long* raymask, const int* rayoff,
+__global__ void k_render_scan(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff,
                               const float* ssdf, const float* depth_fg, float* sdeds, float* ray_res, int* kcnt, int* mcnt,
                               int n_depth, float th) {
     const int b = blockIdx.y;
@@ -286,13 +294,14 @@ __global__ void k_render_scan(const ObjConst* oc, const ObjState* st, const unsi
         }
     }
     int kept = 0, k = 0;
+    unsigned khash = 0;
 #pragma unroll
     for (int j = 0; j < 64; ++j) {
         if (j < n_depth && ((mask >> j) & 1ull)) {
             float deds = 0.f;
             if ((wg >> j) & 1ull) {
                 const float dedo = __fdiv_rn(suf[j], __fsub_rn(1.f, o[j]));
-                if (dedo > 1e-2f) { deds = __fmul_rn(__fmul_rn(dedo, delta_d), do_ds); ++kept; }
+                if (dedo > 1e-2f) { deds = __fmul_rn(__fmul_rn(dedo, delta_d), do_ds); ++kept; khash += id_hash(((unsigned)r << 6) | (unsigned)j); }
             }
             sdeds[base + k] = deds;   // never exactly 0 for a kept sample (dedo > 0.01, delta_d > 0)
             ++k;
@@ -300,6 +309,7 @@ __global__ void k_render_scan(const ObjConst* oc, const ObjState* st, const unsi
     }
     kcnt[gr] = kept;
     mcnt[gr] = __popcll(wg);
+    if (khash) atomicAdd(&st[b].ksum, khash);
 }
 
 __global__ void k_render_write(const ObjConst* oc, const ObjState* st, const int* raycnt, const int* rayoff, const int* koff,
@@ -603,10 +613,15 @@ __global__ __launch_bounds__(256) void k_solve(const ObjConst* oc, ObjState* st,
         for (int e = tid; e < n; e += 256) tr[NSOLVE * NSOLVE + e] = (float)A[e][n];
         if (tid < 16) tr[NSOLVE * NSOLVE + 2 * NSOLVE + tid] = s.t_oc[tid];
         if (tid < 64) tr[NSOLVE * NSOLVE + 2 * NSOLVE + 16 + tid] = s.code[tid];
+        if (tid < 64) tr[5280 + tid] = s.depths[tid];
         if (tid == 0) {
             tr[NSOLVE * NSOLVE + 2 * NSOLVE + 80] = (float)s.V;
             tr[NSOLVE * NSOLVE + 2 * NSOLVE + 81] = (float)s.m;
             tr[NSOLVE * NSOLVE + 2 * NSOLVE + 82] = (float)s.K;
+            tr[NSOLVE * NSOLVE + 2 * NSOLVE + 83] = (float)(s.vsum & 0xffffu);
+            tr[NSOLVE * NSOLVE + 2 * NSOLVE + 84] = (float)(s.vsum >> 16);
+            tr[NSOLVE * NSOLVE + 2 * NSOLVE + 85] = (float)(s.ksum & 0xffffu);
+            tr[NSOLVE * NSOLVE + 2 * NSOLVE + 86] = (float)(s.ksum >> 16);
         }
         __syncthreads();
     }
@@ -650,6 +665,7 @@ __global__ __launch_bounds__(256) void k_solve(const ObjConst* oc, ObjState* st,
                 nt[4 * r + cc] = a;
             }
         for (int i = 0; i < 16; ++i) s.t_oc[i] = nt[i];
+        s.vsum = 0; s.ksum = 0;
         if (!prm.pose_only) derive_iter_state(s, prm.n_depth);
     }
 }
@@ -703,7 +719,7 @@ __global__ void k_finalize(ObjState* st, const float* scale_in, int n_obj, int p
 void launch_init_state(ObjState* st, const float* t, const float* codes, const float* scale, int B, int D, int pose_only, hipStream_t s) {
     hipLaunchKernelGGL(k_init_state, dim3((B + 63) / 64), dim3(64), 0, s, st, t, codes, scale, B, D, pose_only);
 }
-void launch_sample_count(const ObjConst* oc, const ObjState* st, const float* rays, unsigned long long* m, int* c, int D, int maxR, int B, hipStream_t s) {
+void launch_sample_count(const ObjConst* oc, ObjState* st, const float* rays, unsigned long long* m, int* c, int D, int maxR, int B, hipStream_t s) {
     hipLaunchKernelGGL(k_sample_count, GRID2(maxR, B), dim3(256), 0, s, oc, st, rays, m, c, D);
 }
 void launch_scan_rays(const ObjConst* oc, ObjState* st, const int* cnt, int* off, int which, int B, hipStream_t s) {
@@ -718,7 +734,7 @@ void launch_surface(const ObjConst* oc, const ObjState* st, const float* pts, fl
 void launch_build_tiles(const ObjConst* oc, const ObjState* st, int B, int mode, int4* tiles, int* n_tiles, double* counters, hipStream_t s) {
     hipLaunchKernelGGL(k_build_tiles, dim3(1), dim3(256), 0, s, oc, st, B, mode, tiles, n_tiles, counters);
 }
-void launch_render_scan(const ObjConst* oc, const ObjState* st, const unsigned long long* m, const int* off, const float* ssdf, const float* depth,
+void launch_render_scan(const ObjConst* oc, ObjState* st, const unsigned long long* m, const int* off, const float* ssdf, const float* depth,
                         float* sdeds, float* ray_res, int* kcnt, int* mcnt, int D, float th, int maxR, int B, hipStream_t s) {
     hipLaunchKernelGGL(k_render_scan, GRID2(maxR, B), dim3(256), 0, s, oc, st, m, off, ssdf, depth, sdeds, ray_res, kcnt, mcnt, D, th);
 }

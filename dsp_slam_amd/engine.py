@@ -83,10 +83,12 @@ class Batch(object):
         n = self.n
         out = dict(H=np.zeros((n, 71, 71), np.float32), b=np.zeros((n, 71), np.float32), dx=np.zeros((n, 71), np.float32),
                    V=np.zeros(n, np.int64), m=np.zeros(n, np.int64), K=np.zeros(n, np.int64),
-                   t_obj_cam=np.zeros((n, 4, 4), np.float32), code=np.zeros((n, L.CODE_LEN), np.float32))
+                   t_obj_cam=np.zeros((n, 4, 4), np.float32), code=np.zeros((n, L.CODE_LEN), np.float32),
+                   set_sums=np.zeros((n, 2), np.uint32), depths=np.zeros((n, 64), np.float32))
         L.check(L.load().dsp_batch_trace(self._h, int(iteration), L.ptr(out["H"]), L.ptr(out["b"]), L.ptr(out["dx"]),
                                          L.ptr(out["V"], L.c_i64p), L.ptr(out["m"], L.c_i64p), L.ptr(out["K"], L.c_i64p),
-                                         L.ptr(out["t_obj_cam"]), L.ptr(out["code"])), self.engine._h, "dsp_batch_trace")
+                                         L.ptr(out["t_obj_cam"]), L.ptr(out["code"]), L.ptr(out["set_sums"], C.POINTER(C.c_uint32)), L.ptr(out["depths"])),
+                self.engine._h, "dsp_batch_trace")
         return out
 
     def close(self):

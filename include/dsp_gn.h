@@ -133,9 +133,11 @@ int dsp_batch_stats(dsp_batch* b, dsp_stats* out);
 /* Record per-iteration traces during the following runs (testing; costs ~21 KB per object-iteration). */
 int dsp_batch_enable_trace(dsp_batch* b, int on);
 /* Per-iteration trace of the last run (testing): for iteration e < num_iterations and object i,
- * H (71x71), b (71), dx (71), V, m, K.  Any pointer may be NULL. */
+ * H (71x71), b (71), dx (71), V, m, K, the state the iteration started from, and set_sums[2*i + {0,1}] = order-
+ * independent checksums of the in-sphere sample set and of the kept (jacobian) sample set: sum over members of
+ * hash(ray << 6 | depth_index), hash(x) = (x * 2654435761) ^ (x >> 7), mod 2^32.  Any pointer may be NULL. */
 int dsp_batch_trace(dsp_batch* b, int32_t iteration, float* H, float* bvec, float* dx, int64_t* V, int64_t* m,
-                    int64_t* K, float* t_obj_cam, float* code);
+                    int64_t* K, float* t_obj_cam, float* code, uint32_t* set_sums, float* depths /* 64 per object */);
 void dsp_batch_destroy(dsp_batch* b);
 
 #ifdef __cplusplus

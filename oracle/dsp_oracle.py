@@ -301,7 +301,7 @@ def sdf_to_occupancy(sdf, th):
 
 
 def compute_render_loss(dec, ray_directions, depth_obs, t_obj_cam, sampled_ray_depth, code, th=0.01,
-                        stats=None):
+                        stats=None, sdf_jitter=0.0):
     """loss.py:46-152 -> (J_pose (K,7), J_code (K,C), residual (K,)) or None (<10 in-sphere samples).
 
     stats (optional dict) receives the ragged set sizes V, m, K and the index sets.
@@ -320,6 +320,8 @@ def compute_render_loss(dec, ray_directions, depth_obs, t_obj_cam, sampled_ray_d
     if query.shape[0] < 10:                                                 # :73-74
         return None
     sdf = decode_sdf(dec, code, query)                                      # :77-78
+    if sdf_jitter:   # tests only: +-jitter on the decoded values, to measure how round-off in the decoder propagates
+        sdf = (sdf + F32(sdf_jitter) * np.where(np.arange(sdf.shape[0]) % 2 == 0, F32(1), F32(-1))).astype(F32)
     occ = np.zeros((n_rays, n_d), F32)
     occ[vx, vy] = sdf_to_occupancy(sdf, th)                                 # :84-86
     wg = (sdf > -th) & (sdf < th)                                           # :88
@@ -401,13 +403,22 @@ class GNParams(object):
                    o["cut_off_threshold"], p["num_iterations"])
 
 
+def set_checksum(ray_idx, depth_idx):
+    """Order-independent checksum of a sample set, same definition as the device's (include/dsp_gn.h, dsp_batch_trace)."""
+    ids = (np.asarray(ray_idx, np.uint64) << np.uint64(6)) | np.asarray(depth_idx, np.uint64)
+    ids = ids & np.uint64(0xFFFFFFFF)
+    h = ((ids * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)) ^ (ids >> np.uint64(7))
+    return int(h.sum() & np.uint64(0xFFFFFFFF)) if ids.size else 0
+
+
 def _gram(j, r):
     """sum_n J_n^T J_n and sum_n J_n^T r_n for row Jacobians (optimizer.py:162-167)."""
     j = np.ascontiguousarray(j, F32)
     return (j.T @ j).astype(F32), (j.T @ np.asarray(r, F32)).astype(F32)
 
 
-def reconstruct_object(dec, prm, t_cam_obj, pts, rays, depth, code=None, trace=None, t_obj_cam0=None):
+def reconstruct_object(dec, prm, t_cam_obj, pts, rays, depth, code=None, trace=None, t_obj_cam0=None, sdf_jitter=0.0,
+                       scale_jitter=0.0, sampled_override=None):
     """Optimizer.reconstruct_object (optimizer.py:88-203).
 
     Returns dict(t_cam_obj (4,4) f32 | None, code (C,) f32 | None, is_good bool, loss float).
@@ -428,16 +439,22 @@ def reconstruct_object(dec, prm, t_cam_obj, pts, rays, depth, code=None, trace=N
     for e in range(prm.num_iterations):
         t_co = _inv(t_obj_cam)                                               # :120
         scale = _det3_cuberoot(t_co[:3, :3])                                 # :122
+        if scale_jitter:   # tests only: the derived scale moved by a relative round-off (fp32 det/pow vs other exact paths)
+            scale = F32(scale * F32(1.0 + scale_jitter))
         d_min = F32(t_co[2, 3] - F32(1.0) * scale)
         d_max = F32(t_co[2, 3] + F32(1.0) * scale)
         sampled = linspace_f32(d_min, d_max, prm.num_depth_samples)          # :125
+        if sampled_override is not None:   # tests only: linearise on exactly these depth samples (single-iteration runs)
+            sampled = np.asarray(sampled_override, F32)[:prm.num_depth_samples].copy()
+            d_max = sampled[-1]
+        derived_depths = sampled.copy()
         depth_obs[n_fg:] = F32(1.1) * d_max                                  # :126
         j7_s, jc_s, r_s = compute_sdf_loss(dec, pts, t_obj_cam, z)           # :129
         rr_s, sdf_loss, _ = get_robust_res(r_s, prm.b2)                      # :134
         if math.isnan(sdf_loss):
             return fail()
         st = {}
-        rend = compute_render_loss(dec, rays, depth_obs, t_obj_cam, sampled, z, th=prm.cut_off, stats=st)
+        rend = compute_render_loss(dec, rays, depth_obs, t_obj_cam, sampled, z, th=prm.cut_off, stats=st, sdf_jitter=sdf_jitter)
         if rend is None:                                                     # :142-143
             return fail()
         j7_r, jc_r, r_r = rend
@@ -468,7 +485,8 @@ def reconstruct_object(dec, prm, t_cam_obj, pts, rays, depth, code=None, trace=N
         dx = (_inv(h) @ b).astype(F32)                                       # :186
         delta_t = exp_sim3(F32(prm.lr) * dx[:pd])                            # :190
         if trace is not None:
-            trace.append(dict(V=st["V"], m=st["m"], K=st["K"], H=h.copy(), b=b.copy(), dx=dx.copy(),
+            trace.append(dict(V=st["V"], m=st["m"], K=st["K"], vsum=set_checksum(*st["valid"]), ksum=set_checksum(*st["kept"]),
+                              H=h.copy(), b=b.copy(), dx=dx.copy(), depths=derived_depths,
                               t_obj_cam=t_obj_cam.copy(), code=z.copy(), loss=loss,
                               sdf_loss=float(sdf_loss), render_loss=float(render_loss)))
         t_obj_cam = (delta_t @ t_obj_cam).astype(F32)                        # :191

