@@ -53,6 +53,7 @@ SYMBOLS = [
     ("dsp_destroy", None, [_VP]),
     ("dsp_last_error", C.c_char_p, [_VP]),
     ("dsp_decode_sdf", C.c_int, [_VP, c_f32p, c_f32p, C.c_int64, c_f32p]),
+    ("dsp_decode_sdf_multi", C.c_int, [_VP, c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p]),
     ("dsp_sdf_jacobian", C.c_int, [_VP, c_f32p, c_f32p, C.c_int64, c_f32p, c_f32p]),
     ("dsp_compute_sdf_loss", C.c_int, [_VP, c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p]),
     ("dsp_compute_render_loss", C.c_int, [_VP, c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_int32, c_f32p, C.c_float,

@@ -216,22 +216,28 @@ MlpArgs make_mlp_args(const dsp_handle* h, bool bwd) {
     return a;
 }
 
-// one object, n points already in the object frame: forward or forward+gradient
-void run_decoder_points(dsp_handle* h, const float* code, const float* pts, int64_t n, bool bwd, float* sdf_out, float* grad_out) {
-    if (n <= 0) return;
+// n_codes objects x the same n points (object frame): forward or forward+gradient.  Output row = code * n + point.
+void run_decoder_points(dsp_handle* h, const float* codes, int64_t n_codes, const float* pts, int64_t n, bool bwd, float* sdf_out,
+                        float* grad_out) {
+    if (n <= 0 || n_codes <= 0) return;
     HIP_TRY(hipSetDevice(h->device));
-    const int nt = (int)((n + TILE_PTS - 1) / TILE_PTS);
+    const int64_t ntile = (n + TILE_PTS - 1) / TILE_PTS;
+    if (ntile * n_codes > (int64_t)1 << 30 || n * n_codes > (int64_t)1 << 31) throw std::invalid_argument("decode request too large");
+    const int nt = (int)(ntile * n_codes);
     std::vector<float4> p4((size_t)n);
     for (int64_t i = 0; i < n; ++i) p4[i] = make_float4(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], 0.f);
     std::vector<int4> tiles(nt);
-    for (int i = 0; i < nt; ++i) tiles[i] = make_int4(i * TILE_PTS, (int)std::min<int64_t>(TILE_PTS, n - (int64_t)i * TILE_PTS), 0, 0);
+    for (int64_t c = 0; c < n_codes; ++c)
+        for (int64_t i = 0; i < ntile; ++i)
+            tiles[c * ntile + i] = make_int4((int)(i * TILE_PTS), (int)std::min<int64_t>(TILE_PTS, n - i * TILE_PTS), (int)c, (int)(c * n));
+    const size_t n_out = (size_t)n * n_codes;
     h->s_pts.ensure(n);
-    h->s_code.ensure(CODE_LEN);
+    h->s_code.ensure((size_t)CODE_LEN * n_codes);
     h->s_tiles.ensure(nt);
     h->s_ntiles.ensure(1);
-    h->s_out.ensure(bwd ? (size_t)n * GRAD_STRIDE : (size_t)n);
+    h->s_out.ensure(bwd ? n_out * GRAD_STRIDE : n_out);
     HIP_TRY(hipMemcpyAsync(h->s_pts.p, p4.data(), n * sizeof(float4), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(h->s_code.p, code, CODE_LEN * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->s_code.p, codes, (size_t)CODE_LEN * n_codes * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->s_tiles.p, tiles.data(), nt * sizeof(int4), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->s_ntiles.p, &nt, 4, hipMemcpyHostToDevice, h->stream));
     MlpArgs a = make_mlp_args(h, bwd);
@@ -246,13 +252,13 @@ void run_decoder_points(dsp_handle* h, const float* code, const float* pts, int6
     a.clk = h->s_clk.p;
     HIP_TRY(launch_mlp(bwd, a, std::min(nt, h->n_cu), h->stream));
     if (!bwd) {
-        HIP_TRY(hipMemcpyAsync(sdf_out, h->s_out.p, n * 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(sdf_out, h->s_out.p, n_out * 4, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
     } else {
-        std::vector<float> tmp((size_t)n * GRAD_STRIDE);
+        std::vector<float> tmp(n_out * GRAD_STRIDE);
         HIP_TRY(hipMemcpyAsync(tmp.data(), h->s_out.p, tmp.size() * 4, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
-        for (int64_t i = 0; i < n; ++i) {
+        for (size_t i = 0; i < n_out; ++i) {
             if (grad_out) memcpy(grad_out + i * DSP_GRAD_DIM, tmp.data() + i * GRAD_STRIDE, DSP_GRAD_DIM * 4);
             if (sdf_out) sdf_out[i] = tmp[i * GRAD_STRIDE + 67];
         }
@@ -661,12 +667,17 @@ const char* dsp_last_error(const dsp_handle* h) { return h ? h->err.c_str() : g_
 
 int dsp_decode_sdf(dsp_handle* h, const float* code, const float* pts, int64_t n, float* sdf_out) {
     if (!h || !code || (n > 0 && (!pts || !sdf_out)) || n < 0) return DSP_E_ARG;
-    return guarded(h, [&] { run_decoder_points(h, code, pts, n, false, sdf_out, nullptr); });
+    return guarded(h, [&] { run_decoder_points(h, code, 1, pts, n, false, sdf_out, nullptr); });
+}
+
+int dsp_decode_sdf_multi(dsp_handle* h, const float* codes, int64_t n_codes, const float* pts, int64_t n, float* sdf_out) {
+    if (!h || !codes || n_codes < 0 || n < 0 || (n > 0 && n_codes > 0 && (!pts || !sdf_out))) return DSP_E_ARG;
+    return guarded(h, [&] { run_decoder_points(h, codes, n_codes, pts, n, false, sdf_out, nullptr); });
 }
 
 int dsp_sdf_jacobian(dsp_handle* h, const float* code, const float* pts, int64_t n, float* sdf_out, float* grad_out) {
     if (!h || !code || (n > 0 && !pts) || n < 0) return DSP_E_ARG;
-    return guarded(h, [&] { run_decoder_points(h, code, pts, n, true, sdf_out, grad_out); });
+    return guarded(h, [&] { run_decoder_points(h, code, 1, pts, n, true, sdf_out, grad_out); });
 }
 
 int dsp_compute_sdf_loss(dsp_handle* h, const float* pts_cam, int64_t n, const float* t_obj_cam, const float* code,

@@ -40,7 +40,7 @@ struct MlpArgs {
     PassDesc pass[MAX_PASSES];
     // work list (device memory, produced on device)
     const int* n_tiles;         // [1]
-    const int4* tiles;          // [n_tiles] {first point, n points, object, unused}
+    const int4* tiles;          // [n_tiles] {first point, n points, object (code index), output offset added to the point index}
     const float4* pts;          // object-frame points (xyz, w unused)
     const float* codes;         // code of object o at codes + o * code_stride
     int code_stride;            // in floats (multiple of 4)

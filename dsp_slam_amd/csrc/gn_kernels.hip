@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void k_build_tiles(const ObjConst* oc, const O
             for (int i = threadIdx.x; i < nt1; i += 256)
                 tiles[b0 + i] = make_int4(c.jsdf_off + i * TILE_PTS, min(TILE_PTS, n1 - i * TILE_PTS), b, 0);
             for (int i = threadIdx.x; i < nt2; i += 256)
-                tiles[b0 + nt1 + i] = make_int4(c.jren_off + i * TILE_PTS, min(TILE_PTS, n2 - i * TILE_PTS), b, 1);
+                tiles[b0 + nt1 + i] = make_int4(c.jren_off + i * TILE_PTS, min(TILE_PTS, n2 - i * TILE_PTS), b, 0);
             if (threadIdx.x == 0) { base = b0 + nt1 + nt2; cnt += n1 + n2; }
         }
         __syncthreads();

@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
                 part += __shfl_xor(part, 32);
                 y = tanhf(part + a.b_last);
                 if (!BWD) {
-                    if (valid && g == 0) a.out_sdf[pidx] = y;
+                    if (valid && g == 0) a.out_sdf[pidx + td.w] = y;
                 } else {
                     // seed of the backward sweep: d tanh * W_last, masked by the last hidden relu
                     const float d = 1.f - y * y;
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
 
         if (BWD) {
             // sin_ now holds d y / d [code rows 0..63 | xyz at rows 64,68,72]  (first-layer part)
-            float* orow = a.out_grad + (size_t)pidx * GRAD_STRIDE;
+            float* orow = a.out_grad + (size_t)(pidx + td.w) * GRAD_STRIDE;
             if (valid) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {

@@ -126,6 +126,15 @@ class Engine(object):
         L.check(L.load().dsp_decode_sdf(self._h, L.ptr(code), L.ptr(pts), pts.shape[0], L.ptr(out)), self._h, "dsp_decode_sdf")
         return out
 
+    def decode_sdf_multi(self, codes, pts):
+        """(n_codes, 64) codes x one shared (n, 3) point set -> (n_codes, n) sdf, one kernel launch."""
+        pts = L.f32(pts).reshape(-1, 3)
+        codes = L.f32(np.asarray(codes, np.float32).reshape(-1, L.CODE_LEN))
+        out = np.zeros((codes.shape[0], pts.shape[0]), np.float32)
+        L.check(L.load().dsp_decode_sdf_multi(self._h, L.ptr(codes), codes.shape[0], L.ptr(pts), pts.shape[0], L.ptr(out)),
+                self._h, "dsp_decode_sdf_multi")
+        return out
+
     def sdf_jacobian(self, code, pts):
         pts = L.f32(pts).reshape(-1, 3)
         code = L.f32(code).reshape(-1)[:L.CODE_LEN]

@@ -120,6 +120,13 @@ class MeshExtractor(object):
         sdf = self.decoder.engine.decode_sdf(_f32(code)[:self.code_len], self.voxel_points)
         return sdf.reshape(self.voxels_dim, self.voxels_dim, self.voxels_dim)
 
+    def decode_grids(self, codes):
+        """Batched grid decode: (n, code_len) codes -> (n, D, D, D) SDF volumes in one kernel launch (the loop of
+        extract_map_objects.py:46-63 over a whole map)."""
+        codes = np.stack([_f32(c)[:self.code_len] for c in codes])
+        sdf = self.decoder.engine.decode_sdf_multi(codes, self.voxel_points)
+        return sdf.reshape(codes.shape[0], self.voxels_dim, self.voxels_dim, self.voxels_dim)
+
     def extract_mesh_from_code(self, code):
         start = get_time()
         vertices, faces = convert_sdf_voxels_to_mesh(self.decode_grid(code))

@@ -86,6 +86,9 @@ int dsp_abi_version(void);
 /* ---- decoder ---------------------------------------------------------------------------------- */
 /* decode_sdf(decoder, lat_vec, x)  -- reconstruct/loss_utils.py:51-79.  pts (n,3) object frame -> sdf (n). */
 int dsp_decode_sdf(dsp_handle* h, const float* code, const float* pts, int64_t n, float* sdf_out);
+/* The same point set decoded for n_codes shape codes in ONE launch: sdf_out[c * n + i].  Batched form of the
+ * MeshExtractor grid decode (reconstruct/optimizer.py:217-218) / the per-object loop of extract_map_objects.py:46-63. */
+int dsp_decode_sdf_multi(dsp_handle* h, const float* codes, int64_t n_codes, const float* pts, int64_t n, float* sdf_out);
 /* get_batch_sdf_jacobian(decoder, lat_vec, x, 1) -- reconstruct/loss_utils.py:82-103.
  * sdf_out (n), grad_out (n, 67) = d sdf / d [code, xyz]. */
 int dsp_sdf_jacobian(dsp_handle* h, const float* code, const float* pts, int64_t n, float* sdf_out, float* grad_out);

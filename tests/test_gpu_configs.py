@@ -149,3 +149,17 @@ def test_pose_only_batch_ragged(eng, oracle_decoder):
         assert np.abs(out[i] - ref).max() < 1e-4 * np.abs(ref).max()
         one = eng.estimate_pose_batch(prm, [t_se3[i]], [scales[i]], [o["pts"]], [codes[i]])
         assert np.array_equal(one[0], out[i])
+
+
+def test_multi_code_grid_decode_equals_single(eng, oracle_decoder):
+    """MeshExtractor-style grid decode for a whole map in one launch == one launch per object, bit for bit, and == oracle."""
+    rng = np.random.default_rng(3)
+    codes = (rng.normal(size=(5, 64)) * 0.2).astype(np.float32)
+    n = 17
+    lin = np.linspace(-1, 1, n, dtype=np.float32)
+    grid = np.stack(np.meshgrid(lin, lin, lin, indexing="ij"), -1).reshape(-1, 3)
+    multi = eng.decode_sdf_multi(codes, grid)
+    assert multi.shape == (5, n ** 3)
+    for c in range(5):
+        assert np.array_equal(multi[c], eng.decode_sdf(codes[c], grid))
+    assert np.abs(multi[2] - O.decode_sdf(oracle_decoder, codes[2], grid)).max() < 5e-6

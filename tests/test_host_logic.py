@@ -109,3 +109,26 @@ def test_shard_objects_partition():
     assert all(b - a == 128 for a, b in sh)
     t, c, l, s = D.unpack_results(D.pack_results(np.arange(32.).reshape(2, 4, 4), np.ones((2, 64)), [1., 2.], [0, 2]))
     assert t.shape == (2, 4, 4) and c.shape == (2, 64) and list(l) == [1., 2.] and list(s) == [0, 2]
+
+
+def test_map_objects_roundtrip(tmp_path):
+    """MapObjects.txt as System::SaveMapCurrentFrame writes it (src/System_util.cc:123-146)."""
+    from dsp_slam_amd.map_objects import read_map_objects, write_map_objects
+    rng = np.random.default_rng(0)
+    objs = []
+    for i in (7, 2, 11):
+        pose = np.eye(4)
+        pose[:3, :4] = rng.normal(size=(3, 4))
+        objs.append(dict(id=i, pose=pose, code=rng.normal(size=64).astype(np.float32) * 0.1))
+    p = str(tmp_path / "MapObjects.txt")
+    write_map_objects(p, objs)
+    lines = open(p).read().splitlines()
+    assert len(lines) == 9 and lines[0] == "2" and len(lines[1].split()) == 12 and len(lines[2].split()) == 64
+    back = read_map_objects(p)
+    assert [o["id"] for o in back] == [2, 7, 11]
+    by_id = {o["id"]: o for o in objs}
+    for o in back:
+        assert np.allclose(o["pose"], by_id[o["id"]]["pose"], atol=1e-9) and np.allclose(o["code"], by_id[o["id"]]["code"], atol=1e-8)
+    # the reference's own reader logic (extract_map_objects.py:46-63) accepts the file
+    N = int(len(lines) / 3)
+    assert N == 3 and np.asarray([float(x) for x in lines[1].strip().split(" ")]).reshape(3, 4).shape == (3, 4)
