@@ -53,13 +53,15 @@ struct dsp_handle {
     std::string err;
     int n_cu = 256;
     // packed decoder
-    DevBuf<float> wstream, bias_tab;
+    DevBuf<float> wstream, bias_tab, codew, b0, blat;
+    std::vector<float> h_codew, h_b0, h_blat;   // host copies for the single-shot decoder calls
     float b_last = 0.f;
+    int wlast_row = 0, w0_row = 0;
     int n_bias_rows = 0, n_fwd = 0, n_pass_all = 0, chunks_fwd = 0, chunks_all = 0;
     PassDesc pass[MAX_PASSES];
     // scratch of the single-shot decoder calls
     DevBuf<float4> s_pts;
-    DevBuf<float> s_code, s_out;
+    DevBuf<float> s_code, s_out, s_cbias;
     DevBuf<int4> s_tiles;
     DevBuf<int> s_ntiles;
     DevBuf<unsigned long long> s_clk;
@@ -74,17 +76,18 @@ struct NetView {
     int n_layers, hidden, lat;
     std::vector<int> out_dims, in_dims;
     std::vector<const float*> w, b;
-    // forward layer k: slab row -> original weight column (or -1)
-    std::vector<int> colmap(int k) const {
+    // layer k: input-slab row -> original weight column (or -1).  The code columns of the latent_in layer are not part
+    // of the forward stream (they are a per-object bias, k_code_bias) but their gradient rows 448..511 are produced by the
+    // backward pass; layer 0 never goes through the forward stream at all and only its 64 code rows through the backward one.
+    std::vector<int> colmap(int k, bool backward) const {
         std::vector<int> m(WIDTH, -1);
         if (k == 0) {
-            for (int r = 0; r < CODE_LEN; ++r) m[r] = r;
-            m[64] = CODE_LEN; m[68] = CODE_LEN + 1; m[72] = CODE_LEN + 2;   // xyz on lane groups 0,1,2 of k-step 16
+            if (backward) for (int r = 0; r < CODE_LEN; ++r) m[r] = r;
         } else if (k == lat) {
             const int p = WIDTH - IN_DIM;                                  // 445
             for (int r = 0; r < p; ++r) m[r] = r;
             for (int r = 0; r < 3; ++r) m[p + r] = p + CODE_LEN + r;         // xyz re-injected at rows 445..447
-            for (int r = 0; r < CODE_LEN; ++r) m[p + 3 + r] = p + r;         // code re-injected at rows 448..511
+            if (backward) for (int r = 0; r < CODE_LEN; ++r) m[p + 3 + r] = p + r;   // code gradient rows 448..511
         } else {
             for (int r = 0; r < in_dims[k]; ++r) m[r] = r;
         }
@@ -113,7 +116,10 @@ void pack_pass(std::vector<float>& stream, int nog, int nchunks, F value) {
 
 struct PackedNet {
     std::vector<float> stream, bias;
+    std::vector<float> codew;   // [2][512][64]: W0[:, :64] and W_lat[:, code columns], row-major
+    std::vector<float> b0, blat;
     float b_last = 0.f;
+    int wlast_row = 0, w0_row = 0;
     int n_bias_rows = 0, n_fwd = 0, n_pass_all = 0, chunks_fwd = 0, chunks_all = 0;
     PassDesc pass[MAX_PASSES];
 };
@@ -139,41 +145,54 @@ void pack_decoder_host(PackedNet* h, const dsp_decoder_desc* d) {
     std::vector<float>& stream = h->stream;
     std::vector<float>& bias = h->bias;
     stream.clear();
-    bias.assign((size_t)(nv.hidden + 1) * WIDTH, 0.f);
+    bias.assign((size_t)(nv.hidden + 3) * WIDTH, 0.f);
     memset(h->pass, 0, sizeof h->pass);
     int np = 0, chunk = 0;
-    // forward passes
-    for (int k = 0; k < nv.hidden; ++k) {
-        const std::vector<int> cm = nv.colmap(k);
+    // forward passes (layer 0 is evaluated on the VALU from the per-object code bias + the xyz columns)
+    for (int k = 1; k < nv.hidden; ++k) {
+        const std::vector<int> cm = nv.colmap(k, false);
         const int od = nv.out_dims[k], id = nv.in_dims[k];
         const float* W = nv.w[k];
         PassDesc& p = h->pass[np++];
         p.nog = (int16_t)((od + 63) / 64);
-        p.nchunks = (int16_t)(k == 0 ? 2 : 8);
-        p.bias_row = (int16_t)k;
+        p.nchunks = (int16_t)(k == nv.lat ? 7 : 8);          // latent_in: K = 445 + 3 rows
+        p.bias_row = (int16_t)(k == nv.lat ? -2 : k - 1);    // -2: per-object bias (code contribution + b_lat)
         p.relu = 1;
         p.mask_slot = (int16_t)k;
-        p.kind = (int16_t)(k == 0 ? 0 : (k == nv.lat ? 2 : 1));
+        p.kind = (int16_t)(k == nv.lat ? 2 : 1);
         p.chunk_base = chunk;
         pack_pass(stream, p.nog, p.nchunks, [&](int orow, int krow) -> float {
             if (orow >= od || krow >= WIDTH || cm[krow] < 0) return 0.f;
             return W[(size_t)orow * id + cm[krow]];
         });
         chunk += p.nog * p.nchunks;
-        for (int o = 0; o < od; ++o) bias[(size_t)k * WIDTH + o] = nv.b[k][o];
+        if (k != nv.lat) for (int o = 0; o < od; ++o) bias[(size_t)(k - 1) * WIDTH + o] = nv.b[k][o];
     }
     h->n_fwd = np;
     h->chunks_fwd = chunk;
-    for (int o = 0; o < WIDTH; ++o) bias[(size_t)nv.hidden * WIDTH + o] = nv.w[nv.hidden][o];
+    h->wlast_row = nv.hidden - 1;
+    h->w0_row = nv.hidden;
+    for (int o = 0; o < WIDTH; ++o) bias[(size_t)h->wlast_row * WIDTH + o] = nv.w[nv.hidden][o];
+    for (int c3 = 0; c3 < 3; ++c3)
+        for (int o = 0; o < WIDTH; ++o) bias[(size_t)(h->w0_row + c3) * WIDTH + o] = nv.w[0][(size_t)o * IN_DIM + CODE_LEN + c3];
     h->b_last = nv.b[nv.hidden][0];
-    h->n_bias_rows = nv.hidden + 1;
+    h->n_bias_rows = nv.hidden + 3;
+    // code columns of layer 0 and of the latent_in layer, for the per-object bias
+    h->codew.assign((size_t)2 * WIDTH * CODE_LEN, 0.f);
+    h->b0.assign(nv.b[0], nv.b[0] + WIDTH);
+    h->blat.assign(nv.b[nv.lat], nv.b[nv.lat] + WIDTH);
+    for (int o = 0; o < WIDTH; ++o)
+        for (int c = 0; c < CODE_LEN; ++c) {
+            h->codew[(size_t)o * CODE_LEN + c] = nv.w[0][(size_t)o * IN_DIM + c];
+            h->codew[(size_t)(WIDTH + o) * CODE_LEN + c] = nv.w[nv.lat][(size_t)o * WIDTH + (WIDTH - IN_DIM) + c];
+        }
     // backward passes (transposed weights): output rows = the forward layer's INPUT slab rows
     for (int k = nv.hidden - 1; k >= 0; --k) {
-        const std::vector<int> cm = nv.colmap(k);
+        const std::vector<int> cm = nv.colmap(k, true);
         const int od = nv.out_dims[k], id = nv.in_dims[k];
         const float* W = nv.w[k];
         PassDesc& p = h->pass[np++];
-        p.nog = (int16_t)(k == 0 ? 2 : 8);
+        p.nog = (int16_t)(k == 0 ? 1 : 8);                   // layer 0: only the 64 code rows (xyz on the VALU)
         p.nchunks = (int16_t)((od + 63) / 64);
         p.bias_row = -1;
         p.relu = 0;
@@ -195,11 +214,30 @@ void pack_decoder(dsp_handle* h, const dsp_decoder_desc* d) {
     pack_decoder_host(&pn, d);
     h->b_last = pn.b_last; h->n_bias_rows = pn.n_bias_rows; h->n_fwd = pn.n_fwd; h->n_pass_all = pn.n_pass_all;
     h->chunks_fwd = pn.chunks_fwd; h->chunks_all = pn.chunks_all;
+    h->wlast_row = pn.wlast_row; h->w0_row = pn.w0_row;
+    h->h_codew = pn.codew; h->h_b0 = pn.b0; h->h_blat = pn.blat;
+    h->codew.alloc(pn.codew.size());
+    HIP_TRY(hipMemcpy(h->codew.p, pn.codew.data(), pn.codew.size() * 4, hipMemcpyHostToDevice));
+    h->b0.alloc(WIDTH); h->blat.alloc(WIDTH);
+    HIP_TRY(hipMemcpy(h->b0.p, pn.b0.data(), WIDTH * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->blat.p, pn.blat.data(), WIDTH * 4, hipMemcpyHostToDevice));
     memcpy(h->pass, pn.pass, sizeof h->pass);
     h->wstream.alloc(pn.stream.size());
     HIP_TRY(hipMemcpy(h->wstream.p, pn.stream.data(), pn.stream.size() * 4, hipMemcpyHostToDevice));
     h->bias_tab.alloc(pn.bias.size());
     HIP_TRY(hipMemcpy(h->bias_tab.p, pn.bias.data(), pn.bias.size() * 4, hipMemcpyHostToDevice));
+}
+
+// per-object code bias on the host (single-shot calls); same arithmetic as k_code_bias
+void code_bias_host(const std::vector<float>& codew, const std::vector<float>& b0, const std::vector<float>& blat, const float* code,
+                    float* out /*1024*/) {
+    for (int which = 0; which < 2; ++which)
+        for (int o = 0; o < WIDTH; ++o) {
+            float acc = which == 0 ? b0[o] : blat[o];
+            const float* w = codew.data() + ((size_t)which * WIDTH + o) * CODE_LEN;
+            for (int c = 0; c < CODE_LEN; ++c) acc = fmaf(w[c], code[c], acc);
+            out[which * WIDTH + o] = acc;
+        }
 }
 
 MlpArgs make_mlp_args(const dsp_handle* h, bool bwd) {
@@ -209,6 +247,8 @@ MlpArgs make_mlp_args(const dsp_handle* h, bool bwd) {
     a.bias_tab = h->bias_tab.p;
     a.b_last = h->b_last;
     a.n_bias_rows = h->n_bias_rows;
+    a.wlast_row = h->wlast_row;
+    a.w0_row = h->w0_row;
     a.n_fwd = h->n_fwd;
     a.n_pass = bwd ? h->n_pass_all : h->n_fwd;
     a.total_chunks = bwd ? h->chunks_all : h->chunks_fwd;
@@ -233,6 +273,10 @@ void run_decoder_points(dsp_handle* h, const float* codes, int64_t n_codes, cons
     const size_t n_out = (size_t)n * n_codes;
     h->s_pts.ensure(n);
     h->s_code.ensure((size_t)CODE_LEN * n_codes);
+    h->s_cbias.ensure((size_t)2 * WIDTH * n_codes);
+    std::vector<float> cb((size_t)2 * WIDTH * n_codes);
+    for (int64_t c = 0; c < n_codes; ++c) code_bias_host(h->h_codew, h->h_b0, h->h_blat, codes + c * CODE_LEN, cb.data() + c * 2 * WIDTH);
+    HIP_TRY(hipMemcpyAsync(h->s_cbias.p, cb.data(), cb.size() * 4, hipMemcpyHostToDevice, h->stream));
     h->s_tiles.ensure(nt);
     h->s_ntiles.ensure(1);
     h->s_out.ensure(bwd ? n_out * GRAD_STRIDE : n_out);
@@ -246,6 +290,8 @@ void run_decoder_points(dsp_handle* h, const float* codes, int64_t n_codes, cons
     a.pts = h->s_pts.p;
     a.codes = h->s_code.p;
     a.code_stride = CODE_LEN;
+    a.code_bias = h->s_cbias.p;
+    a.code_bias_stride = 2 * WIDTH;
     a.out_sdf = h->s_out.p;
     a.out_grad = h->s_out.p;
     h->s_clk.ensure(4);
@@ -290,6 +336,7 @@ struct dsp_batch {
     DevBuf<int4> tiles_f, tiles_j;
     DevBuf<int> n_tiles, out_status;
     DevBuf<double> counters, gsum;
+    DevBuf<float> cbias;
     std::vector<hipEvent_t> ev;   // pairs around every decoder launch + [run start, run end]
     std::vector<int> ev_kind;
     dsp_stats stats;
@@ -377,6 +424,7 @@ dsp_batch* batch_build(dsp_handle* h, const dsp_gn_params* prm, int B, const int
     b->counters.alloc(2);
     b->partials.alloc((size_t)B * 2 * b->n_slices * 72 * 72);
     b->gsum.alloc((size_t)B * 2 * 72 * 72);
+    b->cbias.alloc((size_t)B * 2 * WIDTH);
     b->out_t.alloc((size_t)B * 16); b->out_code.alloc((size_t)B * CODE_LEN); b->out_loss.alloc(B); b->out_status.alloc(B);
     memset(&b->stats, 0, sizeof b->stats);
     return b.release();
@@ -407,6 +455,8 @@ void launch_decoder(dsp_batch* b, bool bwd, size_t& cursor) {
     a.pts = bwd ? b->jpts.p : b->spts.p;
     a.codes = reinterpret_cast<const float*>(reinterpret_cast<const char*>(b->st.p) + offsetof(ObjState, code));
     a.code_stride = sizeof(ObjState) / 4;
+    a.code_bias = b->cbias.p;
+    a.code_bias_stride = 2 * WIDTH;
     a.out_sdf = b->ssdf.p;
     a.out_grad = b->jgrad.p;
     hipEvent_t e0 = next_event(b, cursor), e1 = next_event(b, cursor);
@@ -416,11 +466,18 @@ void launch_decoder(dsp_batch* b, bool bwd, size_t& cursor) {
     HIP_TRY(hipEventRecord(e1, h->stream));
 }
 
+void batch_code_bias(dsp_batch* b) {
+    dsp_handle* h = b->h;
+    const float* codes = reinterpret_cast<const float*>(reinterpret_cast<const char*>(b->st.p) + offsetof(ObjState, code));
+    launch_code_bias(h->codew.p, h->b0.p, h->blat.p, codes, (int)(sizeof(ObjState) / 4), b->cbias.p, b->B, h->stream);
+}
+
 // the first half of an iteration up to and including the J rows' inputs (shared with the stand-alone terms)
 void iteration_front(dsp_batch* b, size_t& cursor, bool do_render) {
     dsp_handle* h = b->h;
     hipStream_t s = h->stream;
     const int B = b->B;
+    batch_code_bias(b);   // the code changed in the previous solve (or was just initialised)
     if (do_render) {
         launch_sample_count(b->oc.p, b->st.p, b->rays.p, b->raymask.p, b->raycnt.p, b->D, b->maxR, B, s);
         launch_scan_rays(b->oc.p, b->st.p, b->raycnt.p, b->rayoff.p, 0, B, s);
@@ -598,7 +655,12 @@ int dsp_debug_slabs(dsp_handle* h, const float* code, const float* pts, int n, f
         HIP_TRY(hipMemcpy(h->s_tiles.p, &tile, sizeof tile, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(h->s_ntiles.p, &nt, 4, hipMemcpyHostToDevice));
         MlpArgs a = make_mlp_args(h, true);
+        std::vector<float> cb(2 * WIDTH);
+        code_bias_host(h->h_codew, h->h_b0, h->h_blat, code, cb.data());
+        h->s_cbias.ensure(2 * WIDTH);
+        HIP_TRY(hipMemcpy(h->s_cbias.p, cb.data(), cb.size() * 4, hipMemcpyHostToDevice));
         a.n_tiles = h->s_ntiles.p; a.tiles = h->s_tiles.p; a.pts = h->s_pts.p; a.codes = h->s_code.p; a.code_stride = CODE_LEN;
+        a.code_bias = h->s_cbias.p; a.code_bias_stride = 2 * WIDTH;
         a.out_sdf = out.p; a.out_grad = out.p; a.dbg = dbg.p;
         HIP_TRY(launch_mlp(true, a, 1, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
@@ -607,9 +669,20 @@ int dsp_debug_slabs(dsp_handle* h, const float* code, const float* pts, int n, f
     });
 }
 
+/* Host-only: the per-object code bias (layer 0 and latent_in layer) exactly as the library computes it for single-shot
+ * calls; out = 1024 floats. */
+int dsp_debug_code_bias(const dsp_decoder_desc* decoder, const float* code, float* out) {
+    if (!decoder || !code || !out) return DSP_E_ARG;
+    return guarded(nullptr, [&] {
+        PackedNet pn;
+        pack_decoder_host(&pn, decoder);
+        code_bias_host(pn.codew, pn.b0, pn.blat, code, out);
+    });
+}
+
 /* Host-only: pack a decoder exactly as dsp_create does and copy the result out (tests emulate the kernel's
  * data flow on it without a GPU).  pass_out receives n_pass x 8 int32 {nog,nchunks,bias_row,relu,mask_slot,kind,chunk_base,0};
- * meta_out = {n_fwd, n_pass, chunks_fwd, chunks_all, n_bias_rows}.  Call with NULL buffers to query sizes. */
+ * meta_out = {n_fwd, n_pass, chunks_fwd, chunks_all, n_bias_rows, wlast_row, w0_row}.  Call with NULL buffers to query sizes. */
 int dsp_debug_pack(const dsp_decoder_desc* decoder, float* stream_out, int64_t* stream_len, float* bias_out,
                    int64_t* bias_len, int32_t* pass_out, int32_t* meta_out, float* b_last_out) {
     if (!decoder || !stream_len || !bias_len || !meta_out) return DSP_E_ARG;
@@ -620,6 +693,7 @@ int dsp_debug_pack(const dsp_decoder_desc* decoder, float* stream_out, int64_t* 
         *bias_len = (int64_t)pn.bias.size();
         meta_out[0] = pn.n_fwd; meta_out[1] = pn.n_pass_all; meta_out[2] = pn.chunks_fwd; meta_out[3] = pn.chunks_all; meta_out[4] = pn.n_bias_rows;
         if (b_last_out) *b_last_out = pn.b_last;
+        meta_out[5] = pn.wlast_row; meta_out[6] = pn.w0_row;
         if (stream_out) memcpy(stream_out, pn.stream.data(), pn.stream.size() * 4);
         if (bias_out) memcpy(bias_out, pn.bias.data(), pn.bias.size() * 4);
         if (pass_out)

@@ -22,10 +22,10 @@ constexpr int GRAD_STRIDE = 68;     // per-point output row: d/dcode[64], d/dxyz
 struct PassDesc {
     int16_t nog;        // number of 64-row output groups
     int16_t nchunks;    // number of 64-row K chunks per output group
-    int16_t bias_row;   // row of the LDS bias table to start the accumulators from, -1 = zero
+    int16_t bias_row;   // row of the LDS bias table to start the accumulators from, -1 = zero, -2 = per-object code bias
     int16_t relu;       // 1: relu + store mask (forward hidden layer)
     int16_t mask_slot;  // forward: slot the relu mask is stored to; backward: slot applied; -1 none
-    int16_t kind;       // 0 fwd first layer, 1 fwd hidden, 2 fwd latent_in layer, 3 bwd, 4 bwd latent_in, 5 bwd first
+    int16_t kind;       // 1 fwd hidden, 2 fwd latent_in layer, 3 bwd, 4 bwd latent_in, 5 bwd first layer (code rows only)
     int32_t chunk_base; // first chunk of this pass in the packed stream
 };
 
@@ -33,7 +33,8 @@ struct MlpArgs {
     const float* wstream;       // packed weight stream (fwd passes then bwd passes), chunk-major
     const float* bias_tab;      // [n_bias_rows][512]: hidden biases, last row = final layer weights
     float b_last;               // final layer bias
-    int n_bias_rows;
+    int n_bias_rows;            // hidden biases b1.., final-layer weights (row wlast_row), first-layer xyz columns (rows w0_row..+2)
+    int wlast_row, w0_row;
     int n_fwd;                  // number of forward passes (hidden layers)
     int n_pass;                 // fwd (+ bwd when BWD)
     int total_chunks;           // chunks consumed per tile
@@ -44,6 +45,8 @@ struct MlpArgs {
     const float4* pts;          // object-frame points (xyz, w unused)
     const float* codes;         // code of object o at codes + o * code_stride
     int code_stride;            // in floats (multiple of 4)
+    const float* code_bias;     // per object: [0..511] = W0[:, :64] code + b0, [512..1023] = W_lat[:, code cols] code + b_lat
+    int code_bias_stride;       // in floats (multiple of 4)
     float* out_sdf;             // FWD: [n_points]
     float* out_grad;            // BWD: [n_points][GRAD_STRIDE]
     unsigned long long* clk;    // optional: block 0 writes {clock64, wall_clock64} at entry and exit (effective shader clock)
@@ -86,6 +89,7 @@ struct GnParamsDev {
 
 // kernels_mlp / kernels_gn launchers
 size_t mlp_lds_bytes(bool bwd);
+void launch_code_bias(const float* codew, const float* b0, const float* blat, const float* codes, int code_stride, float* out, int n_obj, hipStream_t s);
 hipError_t mlp_prepare_device();
 hipError_t launch_mlp(bool bwd, const MlpArgs& args, int n_blocks, hipStream_t stream);
 void launch_init_state(ObjState* st, const float* t, const float* codes, const float* scale, int B, int D, int pose_only, hipStream_t s);

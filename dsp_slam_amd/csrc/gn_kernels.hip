@@ -711,11 +711,31 @@ __global__ void k_finalize(ObjState* st, const float* scale_in, int n_obj, int p
     out_status[b] = s.status;
 }
 
+// per-object code contribution to layer 0 and to the latent_in layer (one workgroup per object):
+// out[b][0][o] = b0[o] + W0[o, :64] . code_b,  out[b][1][o] = b_lat[o] + W_lat[o, code cols] . code_b  (k-ordered fmaf chain)
+__global__ __launch_bounds__(256) void k_code_bias(const float* codew, const float* b0, const float* blat, const float* codes,
+                                                   int code_stride, float* out) {
+    __shared__ float z[CODE_LEN];
+    const int b = blockIdx.x;
+    if (threadIdx.x < CODE_LEN) z[threadIdx.x] = codes[(size_t)b * code_stride + threadIdx.x];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * WIDTH; e += 256) {
+        const int which = e / WIDTH, o = e % WIDTH;
+        float acc = which == 0 ? b0[o] : blat[o];
+        const float* w = codew + (size_t)e * CODE_LEN;
+        for (int c = 0; c < CODE_LEN; ++c) acc = fmaf(w[c], z[c], acc);
+        out[(size_t)b * 2 * WIDTH + e] = acc;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host-side launchers (used by dsp_gn.hip)
 // ------------------------------------------------------------------------------------------------
 #define GRID2(n, B) dim3((unsigned)std::max(1, ((n) + 255) / 256), (unsigned)(B))
 
+void launch_code_bias(const float* codew, const float* b0, const float* blat, const float* codes, int code_stride, float* out, int n_obj, hipStream_t s) {
+    hipLaunchKernelGGL(k_code_bias, dim3(n_obj), dim3(256), 0, s, codew, b0, blat, codes, code_stride, out);
+}
 void launch_init_state(ObjState* st, const float* t, const float* codes, const float* scale, int B, int D, int pose_only, hipStream_t s) {
     hipLaunchKernelGGL(k_init_state, dim3((B + 63) / 64), dim3(64), 0, s, st, t, codes, scale, B, D, pose_only);
 }

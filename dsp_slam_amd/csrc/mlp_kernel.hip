@@ -20,8 +20,9 @@ namespace dsp {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int NBUF = 6;                       // LDS ring depth (chunks)
-constexpr int BIAS_ROWS_MAX = 9;              // 8 hidden biases + final-layer weights
-constexpr int BIAS_BYTES = BIAS_ROWS_MAX * WIDTH * 4;      // 18 KiB
+constexpr int BIAS_ROWS_MAX = 11;             // 7 hidden biases, final-layer weights, 3 first-layer xyz columns
+constexpr int BIAS_BYTES = BIAS_ROWS_MAX * WIDTH * 4;      // 22 KiB
+constexpr int CODEBIAS_BYTES = 2 * WIDTH * 4;              // per-object code contribution of layer 0 and of the latent_in layer
 constexpr int MASK_SLOTS = 8;
 constexpr int MASK_BYTES = MASK_SLOTS * 8 * 256 * 2;       // [slot][og][tid] u16 = 32 KiB
 constexpr int GLDS_PER_CHUNK = 4;             // per wave: 4 x 1 KiB pieces of a 16 KiB chunk
@@ -79,8 +80,9 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
     const int pl = lane & 15;   // point of this lane inside the wave
 
     float* bias_l = reinterpret_cast<float*>(smem);
-    unsigned short* mask_l = reinterpret_cast<unsigned short*>(smem + BIAS_BYTES);
-    char* ring_ptr = smem + BIAS_BYTES + (BWD ? MASK_BYTES : 0);
+    float* cb_l = reinterpret_cast<float*>(smem + BIAS_BYTES);   // [0..511] layer-0 code bias, [512..1023] latent_in code bias
+    unsigned short* mask_l = reinterpret_cast<unsigned short*>(smem + BIAS_BYTES + CODEBIAS_BYTES);
+    char* ring_ptr = smem + BIAS_BYTES + CODEBIAS_BYTES + (BWD ? MASK_BYTES : 0);
     const unsigned ring0 = lds_addr(ring_ptr);
 
     const int n_tiles = *a.n_tiles;
@@ -136,36 +138,68 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
         const int pidx = td.x + (valid ? local : 0);
         float4 pt = a.pts[pidx];
         if (!valid) pt = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float pcoord = (g == 0) ? pt.x : (g == 1) ? pt.y : (g == 2) ? pt.z : 0.f;
-        float zr[16];   // zr[4t+r] = code[16t + 4g + r]
+        // The shape code is the same for every point of the tile, so its contribution to layer 0 and to the latent_in
+        // layer is a per-object bias vector (k_code_bias): stage both into LDS.  What is left of layer 0 is three
+        // multiply-adds per row (W0[:, xyz] . p) -- done on the VALU below instead of 16 mostly-empty MFMA chunks.
+        reinterpret_cast<float4*>(cb_l)[tid] = reinterpret_cast<const float4*>(a.code_bias + (size_t)td.z * a.code_bias_stride)[tid];
+        __syncthreads();
         {
-            const float4* cz = reinterpret_cast<const float4*>(a.codes + (size_t)td.z * a.code_stride);
+            const float* w0 = bias_l + a.w0_row * WIDTH + 4 * g;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float4 v = cz[4 * t + g];
-                zr[4 * t + 0] = v.x; zr[4 * t + 1] = v.y; zr[4 * t + 2] = v.z; zr[4 * t + 3] = v.w;
+            for (int o = 0; o < 8; ++o) {
+                unsigned bits = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = 16 * (4 * o + j);
+                    const f32x4 c0 = *reinterpret_cast<const f32x4*>(cb_l + row + 4 * g);
+                    const f32x4 wx = *reinterpret_cast<const f32x4*>(w0 + row);
+                    const f32x4 wy = *reinterpret_cast<const f32x4*>(w0 + WIDTH + row);
+                    const f32x4 wz = *reinterpret_cast<const f32x4*>(w0 + 2 * WIDTH + row);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pre = fmaf(wz[r], pt.z, fmaf(wy[r], pt.y, fmaf(wx[r], pt.x, c0[r])));
+                        bits |= (pre > 0.f ? 1u : 0u) << (4 * j + r);
+                        sin_[16 * o + 4 * j + r] = fmaxf(pre, 0.f);
+                    }
+                }
+                if (BWD) mask_l[(0 * 8 + o) * 256 + tid] = (unsigned short)bits;
             }
         }
         float skipc[16];
         float skipx[3];
         float y = 0.f;
+        float gfirst = 0.f;   // d y / d (x|y|z by lane group) through the first layer
 #pragma unroll
         for (int i = 0; i < 16; ++i) skipc[i] = 0.f;
         skipx[0] = skipx[1] = skipx[2] = 0.f;
 
         for (int ps = 0; ps < a.n_pass; ++ps) {
             const PassDesc pd = a.pass[ps];
-            // ---- pass prologue: inject code / xyz rows -------------------------------------------
-            if (pd.kind == 0) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) sin_[i] = zr[i];
-                sin_[16] = pcoord;
-#pragma unroll
-                for (int i = 17; i < 32; ++i) sin_[i] = 0.f;
-            } else if (pd.kind == 2) {
+            // ---- pass prologue ------------------------------------------------------------------------------------
+            if (pd.kind == 2) {
+                // latent_in layer: xyz re-enters at rows 445..447 (lane group 3); the code part is in the bias (cb_l + 512)
                 if (g == 3) { sin_[109] = pt.x; sin_[110] = pt.y; sin_[111] = pt.z; }
+            } else if (BWD && pd.kind == 5) {
+                // first layer, backward: d y / d xyz = W0[:, xyz]^T ga0 on the VALU (ga0 = the input slab of this pass,
+                // which the pass epilogue overwrites); the MFMA pass itself only produces the 64 code rows
+                const float* w0 = bias_l + a.w0_row * WIDTH + 4 * g;
+                float gx = 0.f, gy = 0.f, gz = 0.f;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) sin_[112 + i] = zr[i];
+                for (int t = 0; t < 32; ++t) {
+                    const f32x4 wx = *reinterpret_cast<const f32x4*>(w0 + 16 * t);
+                    const f32x4 wy = *reinterpret_cast<const f32x4*>(w0 + WIDTH + 16 * t);
+                    const f32x4 wz = *reinterpret_cast<const f32x4*>(w0 + 2 * WIDTH + 16 * t);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        gx = fmaf(wx[r], sin_[4 * t + r], gx);
+                        gy = fmaf(wy[r], sin_[4 * t + r], gy);
+                        gz = fmaf(wz[r], sin_[4 * t + r], gz);
+                    }
+                }
+                gx += __shfl_xor(gx, 16); gx += __shfl_xor(gx, 32);
+                gy += __shfl_xor(gy, 16); gy += __shfl_xor(gy, 32);
+                gz += __shfl_xor(gz, 16); gz += __shfl_xor(gz, 32);
+                gfirst = (g == 0) ? gx : (g == 1) ? gy : gz;
             }
 
             // All 32 output tiles of the layer are MFMA accumulators (acc[4*og+j], 128 AGPRs) with static indices: the
@@ -175,8 +209,8 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
             for (int og = 0; og < 8; ++og) {
                 if (og < pd.nog) {
                     f32x4 bias4[4];
-                    if (pd.bias_row >= 0) {
-                        const float* bp = bias_l + pd.bias_row * WIDTH + 64 * og + 4 * g;
+                    if (pd.bias_row != -1) {
+                        const float* bp = (pd.bias_row == -2 ? cb_l + WIDTH : bias_l + pd.bias_row * WIDTH) + 64 * og + 4 * g;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) bias4[j] = *reinterpret_cast<const f32x4*>(bp + 16 * j);
                     } else {
@@ -278,7 +312,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
 
             if (ps == a.n_fwd - 1) {
                 // final layer (512 -> 1) on the VALU + tanh  (deep_sdf_decoder.py:93,107-108)
-                const float* wl = bias_l + (a.n_bias_rows - 1) * WIDTH + 4 * g;
+                const float* wl = bias_l + a.wlast_row * WIDTH + 4 * g;
                 float part = 0.f;
 #pragma unroll
                 for (int t = 0; t < 32; ++t) {
@@ -314,7 +348,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
         }
 
         if (BWD) {
-            // sin_ now holds d y / d [code rows 0..63 | xyz at rows 64,68,72]  (first-layer part)
+            // sin_[0..15] now holds d y / d code through the first layer (rows 16t + 4g + r); gfirst the xyz part
             float* orow = a.out_grad + (size_t)(pidx + td.w) * GRAD_STRIDE;
             if (valid) {
 #pragma unroll
@@ -331,7 +365,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
             const float s1 = __shfl(skipx[1], pl + 48);
             const float s2 = __shfl(skipx[2], pl + 48);
             const float sk = (g == 0) ? s0 : (g == 1) ? s1 : s2;
-            if (valid) orow[64 + g] = (g < 3) ? (sin_[16] + sk) : y;
+            if (valid) orow[64 + g] = (g < 3) ? (gfirst + sk) : y;
         }
         // stores and LDS-DMA share vmcnt and may retire out of order: drain before counting again
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -344,7 +378,7 @@ template __global__ void mlp_kernel<false, false>(const MlpArgs);
 template __global__ void mlp_kernel<true, false>(const MlpArgs);
 template __global__ void mlp_kernel<true, true>(const MlpArgs);
 
-size_t mlp_lds_bytes(bool bwd) { return BIAS_BYTES + (bwd ? MASK_BYTES : 0) + NBUF * CHUNK_BYTES; }
+size_t mlp_lds_bytes(bool bwd) { return BIAS_BYTES + CODEBIAS_BYTES + (bwd ? MASK_BYTES : 0) + NBUF * CHUNK_BYTES; }
 
 // Opt every kernel variant into > 64 KiB of dynamic LDS on the current device (called by dsp_create).
 hipError_t mlp_prepare_device() {

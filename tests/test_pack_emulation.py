@@ -20,14 +20,18 @@ def packed():
 
 def test_pass_table(packed):
     dec, pk = packed
-    assert pk["n_fwd"] == 8 and pk["n_pass"] == 16 and pk["n_bias_rows"] == 9
+    # layer 0 runs on the VALU (code folded into a per-object bias), so 7 forward + 8 backward passes stream weights
+    assert pk["n_fwd"] == 7 and pk["n_pass"] == 15 and pk["n_bias_rows"] == 11
+    assert pk["wlast_row"] == 7 and pk["w0_row"] == 8
     p = pk["passes"]
-    assert list(p[:8, 0]) == [8, 8, 8, 7, 8, 8, 8, 8]          # 445-wide layer 3 -> 7 groups
-    assert list(p[:8, 1]) == [2, 8, 8, 8, 8, 8, 8, 8]
-    assert list(p[8:, 5]) == [3, 3, 3, 4, 3, 3, 3, 5]          # backward kinds, latent_in at layer 4
-    assert list(p[8:, 1]) == [8, 8, 8, 8, 7, 8, 8, 8]          # K = 448 for the 445-wide layer
-    assert pk["chunks_fwd"] == 16 + 64 * 2 + 56 + 64 * 4
-    assert pk["stream"].shape[0] == pk["chunks_all"]
+    assert list(p[:7, 0]) == [8, 8, 7, 8, 8, 8, 8]             # 445-wide layer 3 -> 7 output groups
+    assert list(p[:7, 1]) == [8, 8, 8, 7, 8, 8, 8]             # latent_in layer: K = 445 + 3 -> 7 chunks
+    assert list(p[:7, 2]) == [0, 1, 2, -2, 4, 5, 6]            # bias rows; -2 = per-object code bias
+    assert list(p[7:, 5]) == [3, 3, 3, 4, 3, 3, 3, 5]          # backward kinds, latent_in at layer 4
+    assert list(p[7:, 1]) == [8, 8, 8, 8, 7, 8, 8, 8]          # K = 448 for the 445-wide layer
+    assert list(p[7:, 0]) == [8, 8, 8, 8, 8, 8, 8, 1]          # first layer backward: the 64 code rows only
+    assert pk["chunks_fwd"] == 64 * 2 + 56 + 56 + 64 * 3
+    assert pk["stream"].shape[0] == pk["chunks_all"] == pk["chunks_fwd"] + 64 * 3 + 64 + 56 + 64 * 2 + 8
 
 
 def test_emulated_forward_matches_oracle(packed):

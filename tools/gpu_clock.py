@@ -27,4 +27,4 @@ for n_rounds, bwd in ((24, False), (24, False), (12, True)):
     flop = n * (7.34208e6 if bwd else 3.67104e6)
     print("%s %d tiles/CU: WG0 %d shader cycles in %.3f ms -> %.0f MHz effective; kernel %.1f TFLOP/s = %.1f%% of 157.3; "
           "cycles per tile %.0f (ideal MFMA-bound %d)" % ("jac" if bwd else "fwd", n_rounds, cyc, secs * 1e3, cyc / secs / 1e6, flop / secs / 1e12,
-          100 * flop / secs / 157.3e12, cyc / n_rounds, (29184 if not bwd else 29184 + 29696) * 32), flush=True)
+          100 * flop / secs / 157.3e12, cyc / n_rounds, (26624 if not bwd else 26624 + 28672) * 32), flush=True)
