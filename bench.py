@@ -149,7 +149,7 @@ def main():
             "unit": "TFLOP/s",
             "frac": round(fwd_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
             "traffic": None,
-            "traffic_note": "PMC pass (profiles/r01_pmc.md): 1.5 GB/launch L2-fabric reads = Infinity-Cache-served weight re-reads, 134 GB/s; algorithmic 20 B/point",
+            "traffic_note": "PMC pass (profiles/r01_final_pmc.md): 1.46 GB/launch L2-fabric reads = Infinity-Cache-served weight re-reads, 133 GB/s; algorithmic 20 B/point",
             "avg_launch_ms": round(fwd_ms / max(n_fwd, 1), 4),
             "alg_flop_per_launch": round(fwd_pts * F_FWD / max(n_fwd, 1)),
             "jac_kernel_tflops": round(jac_tflops, 2),
