@@ -25,6 +25,7 @@ constexpr int BIAS_BYTES = BIAS_ROWS_MAX * WIDTH * 4;      // 22 KiB
 constexpr int CODEBIAS_BYTES = 2 * WIDTH * 4;              // per-object code contribution of layer 0 and of the latent_in layer
 constexpr int MASK_SLOTS = 8;
 constexpr int MASK_BYTES = MASK_SLOTS * 8 * 256 * 2;       // [slot][og][tid] u16 = 32 KiB
+constexpr int PREFETCH = 2;                   // A operands are read this many k-steps ahead of their MFMAs (<= 3 with 4 buffers)
 constexpr int GLDS_PER_CHUNK = 4;             // per wave: 4 x 1 KiB pieces of a 16 KiB chunk
 
 #define MFMA16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x4f32((A), (B), (C), 0, 0, 0)
@@ -66,6 +67,13 @@ __device__ __forceinline__ void glds_piece(const void* gsrc, unsigned lds_dst) {
 
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
+}
+
+// relu as ONE instruction: fmaxf() on an MFMA result makes hipcc emit a canonicalising v_max before the real one
+__device__ __forceinline__ float relu1(float x) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
 }
 
 #define FOR16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
@@ -119,10 +127,11 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
     for (int i = 0; i < NBUF - 1; ++i) issue();
     // chunk 0 visible to every wave; from here on the barrier for chunk q+1 sits in the middle of chunk q
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(GLDS_PER_CHUNK * (NBUF - 2)) : "memory");
-    f32x4 abuf[4];   // A operands run two k-steps ahead of the MFMAs, across chunk / group / pass seams
+    f32x4 abuf[4];   // A operands run PREFETCH k-steps ahead of the MFMAs, across chunk / group / pass seams
                      // (4 slots, not 3: 16 k-steps per chunk must be a multiple of the rotation length)
     abuf[0] = *reinterpret_cast<const f32x4*>(ring_ptr + lane * 16);
     abuf[1] = *reinterpret_cast<const f32x4*>(ring_ptr + lane * 16 + 1024);
+    if (PREFETCH > 2) abuf[2] = *reinterpret_cast<const f32x4*>(ring_ptr + lane * 16 + 2048);
 
     float sin_[128];   // input slab of the current pass:  sin_[4t+r] = row 16t + 4g + r of point pl
     f32x4 acc[32];     // output slab being produced: the MFMA accumulators of all 32 row tiles
@@ -159,7 +168,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
                     for (int r = 0; r < 4; ++r) {
                         const float pre = fmaf(wz[r], pt.z, fmaf(wy[r], pt.y, fmaf(wx[r], pt.x, c0[r])));
                         bits |= (pre > 0.f ? 1u : 0u) << (4 * j + r);
-                        sin_[16 * o + 4 * j + r] = fmaxf(pre, 0.f);
+                        sin_[16 * o + 4 * j + r] = relu1(pre);
                     }
                 }
                 if (BWD) mask_l[(0 * 8 + o) * 256 + tid] = (unsigned short)bits;
@@ -237,7 +246,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
                                     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(GLDS_PER_CHUNK * (NBUF - 3)) : "memory");
 #endif
                                 }
-                                const int sp = s + 2;
+                                const int sp = s + PREFETCH;
 #if !defined(ABL_NOLDS)
                                 abuf[sp % 4] = (sp < KSTEPS_PER_CHUNK)
                                                    ? *reinterpret_cast<const f32x4*>(cb + sp * 1024)
@@ -281,7 +290,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
 #pragma unroll
                         for (int k = 0; k < 16; ++k) {
                             bits |= (v[k] > 0.f ? 1u : 0u) << k;
-                            v[k] = fmaxf(v[k], 0.f);
+                            v[k] = relu1(v[k]);
                         }
                         if (BWD) mask_l[(pd.mask_slot * 8 + og) * 256 + tid] = (unsigned short)bits;
                     } else if (BWD && pd.mask_slot >= 0) {
