@@ -13,7 +13,9 @@ ranks shard them with no other collective: weak scaling, value = objects of all 
 
 The JSON line also carries
   roofline      fp32-MFMA roofline of the dominant kernel (forward-only decoder, mlp_kernel<false>): algorithmic
-                FLOPs = V in-sphere samples x 3 671 040 FLOP (SURVEY.md 8(d)) / HIP-event time of those launches;
+                FLOPs = points the launches actually decode x 3 671 040 FLOP / HIP-event time of those
+                launches.  The path decodes fewer points than the reference's V in-sphere samples: samples behind the
+                first solid sample of a ray have exactly zero transmittance and are skipped (results identical);
   cpu_baseline  the CPU oracle (oracle/dsp_oracle.py, torch-CPU sgemm) timed on this box's host cores on ONE cfg2
                 object (rank 0, N=1 only) -- a reported baseline, not a target.
 """
@@ -97,13 +99,13 @@ def main():
         step()
     sync()
     t0 = time.perf_counter()
-    fwd_ms = jac_ms = fwd_pts = jac_pts = 0.0
+    fwd_ms = jac_ms = fwd_pts = jac_pts = insphere_pts = 0.0
     n_fwd = n_jac = 0
     for _ in range(args.steps):
         step()
         st = batch.stats()
         fwd_ms += st["ms_mlp_fwd"]; jac_ms += st["ms_mlp_jac"]
-        fwd_pts += st["n_fwd_points"]; jac_pts += st["n_jac_points"]
+        fwd_pts += st["n_fwd_points"]; jac_pts += st["n_jac_points"]; insphere_pts += st["n_insphere_points"]
         n_fwd += st["n_mlp_fwd_launches"]; n_jac += st["n_mlp_jac_launches"]
     sync()
     elapsed = time.perf_counter() - t0
@@ -152,6 +154,7 @@ def main():
             "traffic_note": "PMC pass (profiles/r01_final_pmc.md): 1.46 GB/launch L2-fabric reads = Infinity-Cache-served weight re-reads, 133 GB/s; algorithmic 20 B/point",
             "avg_launch_ms": round(fwd_ms / max(n_fwd, 1), 4),
             "alg_flop_per_launch": round(fwd_pts * F_FWD / max(n_fwd, 1)),
+            "fwd_points_evaluated_over_insphere": round(fwd_pts / max(insphere_pts, 1.0), 4),
             "jac_kernel_tflops": round(jac_tflops, 2),
             "jac_kernel_frac": round(jac_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
             "jac_avg_launch_ms": round(jac_ms / max(n_jac, 1), 4),

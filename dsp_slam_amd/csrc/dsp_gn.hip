@@ -328,7 +328,9 @@ struct dsp_batch {
     DevBuf<float> pts, rays, depth, t_in, codes_in, scale_in;
     bool have_codes = false;
     DevBuf<unsigned long long> raymask;
-    DevBuf<int> raycnt, rayoff, kcnt, koff, mcnt;
+    DevBuf<int> raycnt, rayoff, kcnt, koff, mcnt, pcnt, poff, plist;
+    DevBuf<unsigned char> ray_alive;
+    int n_ray_passes = 0;     // front-to-back forward passes per iteration (0 = pick from the batch size)
     DevBuf<float> ray_res, ssdf, sdeds, jgrad, partials, trace, out_t, out_code, out_loss, rows;
     DevBuf<float4> spts, jpts;
     DevBuf<float2> jaux;
@@ -411,6 +413,7 @@ dsp_batch* batch_build(dsp_handle* h, const dsp_gn_params* prm, int B, const int
         b->raymask.alloc(b->sum_rays);
         b->raycnt.alloc(b->sum_rays); b->rayoff.alloc(b->sum_rays);
         b->kcnt.alloc(b->sum_rays); b->koff.alloc(b->sum_rays); b->mcnt.alloc(b->sum_rays);
+        b->pcnt.alloc(b->sum_rays); b->poff.alloc(b->sum_rays); b->plist.alloc(cap_s); b->ray_alive.alloc(b->sum_rays);
         b->ray_res.alloc(b->sum_rays);
         b->spts.alloc(cap_s); b->ssdf.alloc(cap_s); b->sdeds.alloc(cap_s);
         b->tiles_f.alloc(cap_s / TILE_PTS + B);
@@ -421,7 +424,7 @@ dsp_batch* batch_build(dsp_handle* h, const dsp_gn_params* prm, int B, const int
     b->jgrad.alloc((size_t)cap_j * GRAD_STRIDE);
     b->tiles_j.alloc(cap_j / TILE_PTS + 2 * B);
     b->n_tiles.alloc(2);
-    b->counters.alloc(2);
+    b->counters.alloc(3);
     b->partials.alloc((size_t)B * 2 * b->n_slices * 72 * 72);
     b->gsum.alloc((size_t)B * 2 * 72 * 72);
     b->cbias.alloc((size_t)B * 2 * WIDTH);
@@ -453,6 +456,7 @@ void launch_decoder(dsp_batch* b, bool bwd, size_t& cursor) {
     a.n_tiles = b->n_tiles.p + (bwd ? 1 : 0);
     a.tiles = bwd ? b->tiles_j.p : b->tiles_f.p;
     a.pts = bwd ? b->jpts.p : b->spts.p;
+    a.index = bwd ? nullptr : b->plist.p;
     a.codes = reinterpret_cast<const float*>(reinterpret_cast<const char*>(b->st.p) + offsetof(ObjState, code));
     a.code_stride = sizeof(ObjState) / 4;
     a.code_bias = b->cbias.p;
@@ -481,9 +485,29 @@ void iteration_front(dsp_batch* b, size_t& cursor, bool do_render) {
     if (do_render) {
         launch_sample_count(b->oc.p, b->st.p, b->rays.p, b->raymask.p, b->raycnt.p, b->D, b->maxR, B, s);
         launch_scan_rays(b->oc.p, b->st.p, b->raycnt.p, b->rayoff.p, 0, B, s);
-        launch_sample_write(b->oc.p, b->st.p, b->rays.p, b->raymask.p, b->rayoff.p, b->spts.p, b->D, b->maxR, B, s);
-        launch_build_tiles(b->oc.p, b->st.p, B, 0, b->tiles_f.p, b->n_tiles.p, b->counters.p, s);
-        launch_decoder(b, false, cursor);
+        launch_sample_write(b->oc.p, b->st.p, b->rays.p, b->raymask.p, b->rayoff.p, b->spts.p, b->ssdf.p, b->ray_alive.p, b->D, b->maxR, B, s);
+        // Forward decoder, front to back in depth-index ranges with exact early ray termination (gn_kernels.hip,
+        // "front-to-back ray passes").  More passes skip more samples behind surfaces but cost launches and tile-granularity
+        // tails, so small batches use fewer.
+        // automatic: about five tile rounds of the 256 CUs per pass (measured optimum: 2 passes for one cfg2 object,
+        // 3-5 for four, ~10 from eight objects up -- tools/gpu_pass_sweep.py)
+        int n_passes = b->n_ray_passes;
+        if (n_passes <= 0) {
+            const double tiles = 0.75 * (double)b->cap_s / TILE_PTS;
+            n_passes = (int)std::lround(tiles / (5.0 * h->n_cu));
+            n_passes = std::max(2, std::min(n_passes, 10));
+        }
+        n_passes = std::max(1, std::min(n_passes, b->D));
+        for (int p = 0; p < n_passes; ++p) {
+            const int j0 = (int)((long long)b->D * p / n_passes), j1 = (int)((long long)b->D * (p + 1) / n_passes);
+            launch_pass_select(b->oc.p, b->st.p, b->raymask.p, b->rayoff.p, b->ray_alive.p, b->pcnt.p, j0, j1, b->maxR, B, s);
+            launch_scan_rays(b->oc.p, b->st.p, b->pcnt.p, b->poff.p, 2, B, s);
+            launch_pass_write(b->oc.p, b->st.p, b->raymask.p, b->rayoff.p, b->ray_alive.p, b->poff.p, b->plist.p, j0, j1, b->maxR, B, s);
+            launch_build_tiles(b->oc.p, b->st.p, B, 2, b->tiles_f.p, b->n_tiles.p, b->counters.p, p == 0 ? 1 : 0, s);
+            launch_decoder(b, false, cursor);
+            if (p + 1 < n_passes)
+                launch_pass_update(b->oc.p, b->st.p, b->raymask.p, b->rayoff.p, b->ray_alive.p, b->ssdf.p, b->prm.cut_off, j0, j1, b->maxR, B, s);
+        }
         launch_render_scan(b->oc.p, b->st.p, b->raymask.p, b->rayoff.p, b->ssdf.p, b->depth.p, b->sdeds.p, b->ray_res.p,
                            b->kcnt.p, b->mcnt.p, b->D, b->prm.cut_off, b->maxR, B, s);
         launch_scan_rays(b->oc.p, b->st.p, b->kcnt.p, b->koff.p, 1, B, s);
@@ -492,7 +516,7 @@ void iteration_front(dsp_batch* b, size_t& cursor, bool do_render) {
                             b->jpts.p, b->jaux.p, b->maxR, B, s);
     }
     launch_surface(b->oc.p, b->st.p, b->pts.p, b->jpts.p, b->jaux.p, b->maxM, B, s);
-    launch_build_tiles(b->oc.p, b->st.p, B, 1, b->tiles_j.p, b->n_tiles.p + 1, b->counters.p, s);
+    launch_build_tiles(b->oc.p, b->st.p, B, 1, b->tiles_j.p, b->n_tiles.p + 1, b->counters.p, 0, s);
     launch_decoder(b, true, cursor);
 }
 
@@ -507,7 +531,7 @@ void batch_run(dsp_batch* b) {
     b->ev_kind.clear();
     hipEvent_t e_start = next_event(b, cursor);
     HIP_TRY(hipEventRecord(e_start, s));
-    HIP_TRY(hipMemsetAsync(b->counters.p, 0, 2 * sizeof(double), s));
+    HIP_TRY(hipMemsetAsync(b->counters.p, 0, 3 * sizeof(double), s));
     HIP_TRY(hipMemsetAsync(b->st.p, 0, (size_t)B * sizeof(ObjState), s));
     launch_init_state(b->st.p, b->t_in.p, b->have_codes ? b->codes_in.p : nullptr, b->scale_in.p, B, b->D, b->pose_only ? 1 : 0, s);
     if (b->pose_only) HIP_TRY(hipMemsetAsync(b->alive.p, 1, b->cap_j, s));
@@ -528,10 +552,11 @@ void batch_run(dsp_batch* b) {
     // stats
     dsp_stats st;
     memset(&st, 0, sizeof st);
-    double cnt[2];
+    double cnt[3];
     HIP_TRY(hipMemcpy(cnt, b->counters.p, sizeof cnt, hipMemcpyDeviceToHost));
     st.n_fwd_points = cnt[0];
     st.n_jac_points = cnt[1];
+    st.n_insphere_points = cnt[2];
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, e_start, e_end));
     st.ms_total = ms;
@@ -592,7 +617,7 @@ void run_terms(dsp_handle* h, const float* pts_cam, int64_t n_pts, const float* 
     }
     st.n_alive = -1;
     HIP_TRY(hipMemcpyAsync(b->st.p, &st, sizeof st, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemsetAsync(b->counters.p, 0, 2 * sizeof(double), h->stream));
+    HIP_TRY(hipMemsetAsync(b->counters.p, 0, 3 * sizeof(double), h->stream));
     size_t cursor = 0;
     b->ev_kind.clear();
     (void)next_event(b.get(), cursor);
@@ -793,6 +818,12 @@ int dsp_batch_results(dsp_batch* b, float* t_cam_obj_out, float* codes_out, floa
 int dsp_batch_stats(dsp_batch* b, dsp_stats* out) {
     if (!b || !out) return DSP_E_ARG;
     *out = b->stats;
+    return DSP_OK;
+}
+
+int dsp_batch_set_ray_passes(dsp_batch* b, int n_passes) {
+    if (!b || n_passes < 0 || n_passes > MAX_DEPTH_SAMPLES) return DSP_E_ARG;
+    b->n_ray_passes = n_passes;
     return DSP_OK;
 }
 

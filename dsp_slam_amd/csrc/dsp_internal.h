@@ -43,6 +43,8 @@ struct MlpArgs {
     const int* n_tiles;         // [1]
     const int4* tiles;          // [n_tiles] {first point, n points, object (code index), output offset added to the point index}
     const float4* pts;          // object-frame points (xyz, w unused)
+    const int* index;           // forward kernel, optional: point i of a tile is pts[index[first + i]] and its sdf goes to
+                                // out_sdf[index[first + i]] (front-to-back ray passes evaluate a subset of the sample list)
     const float* codes;         // code of object o at codes + o * code_stride
     int code_stride;            // in floats (multiple of 4)
     const float* code_bias;     // per object: [0..511] = W0[:, :64] code + b0, [512..1023] = W_lat[:, code cols] code + b_lat
@@ -78,8 +80,8 @@ struct ObjState {           // per-object optimiser state, lives on the device f
     float scale, dmin, dmax, loss;
     int status, V, m, K;
     int n_alive;
+    int P;                  // samples selected for the current front-to-back pass
     unsigned vsum, ksum;    // order-independent checksums of the in-sphere set and of the kept (jacobian) sample set
-    int pad2;
 };
 
 struct GnParamsDev {
@@ -95,13 +97,20 @@ hipError_t launch_mlp(bool bwd, const MlpArgs& args, int n_blocks, hipStream_t s
 void launch_init_state(ObjState* st, const float* t, const float* codes, const float* scale, int B, int D, int pose_only, hipStream_t s);
 void launch_sample_count(const ObjConst* oc, ObjState* st, const float* rays, unsigned long long* m, int* c, int D, int maxR, int B, hipStream_t s);
 void launch_scan_rays(const ObjConst* oc, ObjState* st, const int* cnt, int* off, int which, int B, hipStream_t s);
-void launch_sample_write(const ObjConst* oc, const ObjState* st, const float* rays, const unsigned long long* m, const int* off, float4* spts, int D, int maxR, int B, hipStream_t s);
+void launch_sample_write(const ObjConst* oc, const ObjState* st, const float* rays, const unsigned long long* m, const int* off, float4* spts,
+                         float* ssdf, unsigned char* alive, int D, int maxR, int B, hipStream_t s);
 void launch_surface(const ObjConst* oc, const ObjState* st, const float* pts, float4* jpts, float2* jaux, int maxM, int B, hipStream_t s);
-void launch_build_tiles(const ObjConst* oc, const ObjState* st, int B, int mode, int4* tiles, int* n_tiles, double* counters, hipStream_t s);
+void launch_build_tiles(const ObjConst* oc, const ObjState* st, int B, int mode, int4* tiles, int* n_tiles, double* counters, int add_v, hipStream_t s);
 void launch_render_scan(const ObjConst* oc, ObjState* st, const unsigned long long* m, const int* off, const float* ssdf, const float* depth,
                         float* sdeds, float* ray_res, int* kcnt, int* mcnt, int D, float th, int maxR, int B, hipStream_t s);
 void launch_render_write(const ObjConst* oc, const ObjState* st, const int* raycnt, const int* rayoff, const int* koff, const float4* spts,
                          const float* sdeds, const float* ray_res, float4* jpts, float2* jaux, int maxR, int B, hipStream_t s);
+void launch_pass_select(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff, const unsigned char* alive,
+                        int* pcnt, int j0, int j1, int maxR, int B, hipStream_t s);
+void launch_pass_write(const ObjConst* oc, const ObjState* st, const unsigned long long* raymask, const int* rayoff, const unsigned char* alive,
+                       const int* poff, int* plist, int j0, int j1, int maxR, int B, hipStream_t s);
+void launch_pass_update(const ObjConst* oc, const ObjState* st, const unsigned long long* raymask, const int* rayoff, unsigned char* alive,
+                        const float* ssdf, float th, int j0, int j1, int maxR, int B, hipStream_t s);
 void launch_sum_m(const ObjConst* oc, ObjState* st, const int* mcnt, int B, hipStream_t s);
 void launch_gram(const ObjConst* oc, const ObjState* st, const float4* jpts, const float2* jaux, const float* jgrad, const unsigned char* alive,
                  float* partials, int n_slices, float b_sdf, float b_render, int robust, int n_terms, int B, hipStream_t s);

@@ -150,14 +150,16 @@ __global__ __launch_bounds__(256) void k_scan_rays(const ObjConst* oc, ObjState*
         if (which == 0) {
             s.V = total;
             if (s.status == DSP_STATUS_GOOD && total < 10) s.status = DSP_STATUS_FEW;   // loss.py:73-74
-        } else {
+        } else if (which == 1) {
             s.K = total;
+        } else {
+            s.P = total;
         }
     }
 }
 
 __global__ void k_sample_write(const ObjConst* oc, const ObjState* st, const float* rays, const unsigned long long* raymask,
-                               const int* rayoff, float4* spts, int n_depth) {
+                               const int* rayoff, float4* spts, float* ssdf, unsigned char* alive, int n_depth) {
     const int b = blockIdx.y;
     const ObjConst c = oc[b];
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -167,14 +169,80 @@ __global__ void k_sample_write(const ObjConst* oc, const ObjState* st, const flo
     unsigned long long mask = raymask[c.ray_off + r];
     const float* d3 = rays + 3 * (size_t)(c.ray_off + r);
     const float dx = d3[0], dy = d3[1], dz = d3[2];
+    alive[c.ray_off + r] = mask ? 1 : 0;
     float4* dst = spts + c.samp_off + rayoff[c.ray_off + r];
+    float* sd = ssdf + c.samp_off + rayoff[c.ray_off + r];
     while (mask) {
         const int j = __ffsll((long long)mask) - 1;
         mask &= mask - 1;
         const float d = s.depths[j];
         const float3 p = xform(s.t_oc, __fmul_rn(dx, d), __fmul_rn(dy, d), __fmul_rn(dz, d));
         *dst++ = make_float4(p.x, p.y, p.z, __int_as_float((r << 6) | j));
+        *sd++ = 1.0f;   // "not evaluated": free space (o = 0).  Only samples BEHIND a solid one stay unevaluated, where the
+                        // transmittance is exactly 0, so the value cannot reach d_u, de_do, H or b (see k_pass_update).
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// front-to-back ray passes (exact early ray termination)
+// ------------------------------------------------------------------------------------------------
+// occupancy is exactly 1 for sdf <= -th (0.5 + th/(2 th) in fp32), so T_l = prod(1 - o_i) is exactly 0 behind the first
+// such sample: every term those samples could contribute to the rendered depth (o_l * T_{l-1}), to any suffix sum of T and
+// hence to any kept row is 0 -- their decoder values are never needed.  The forward decoder therefore runs in passes over
+// depth-index ranges [j0, j1), front to back, and a ray drops out after the pass in which it first reports a solid sample.
+__device__ __forceinline__ unsigned long long range_mask(int j0, int j1) {
+    const unsigned long long hi = (j1 >= 64) ? ~0ull : ((1ull << j1) - 1ull);
+    return hi & ~((1ull << j0) - 1ull);
+}
+
+__global__ void k_pass_select(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff,
+                              const unsigned char* alive, int* pcnt, int j0, int j1) {
+    const int b = blockIdx.y;
+    const ObjConst c = oc[b];
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= c.n_rays) return;
+    const int gr = c.ray_off + r;
+    const bool on = st[b].status == DSP_STATUS_GOOD && alive[gr];
+    pcnt[gr] = on ? __popcll(raymask[gr] & range_mask(j0, j1)) : 0;
+}
+
+__global__ void k_pass_write(const ObjConst* oc, const ObjState* st, const unsigned long long* raymask, const int* rayoff,
+                             const unsigned char* alive, const int* poff, int* plist, int j0, int j1) {
+    const int b = blockIdx.y;
+    const ObjConst c = oc[b];
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= c.n_rays) return;
+    const int gr = c.ray_off + r;
+    if (st[b].status != DSP_STATUS_GOOD || !alive[gr]) return;
+    const unsigned long long mask = raymask[gr];
+    unsigned long long sel = mask & range_mask(j0, j1);
+    int* dst = plist + c.samp_off + poff[gr];
+    const int base = c.samp_off + rayoff[gr];
+    while (sel) {
+        const int j = __ffsll((long long)sel) - 1;
+        sel &= sel - 1;
+        *dst++ = base + __popcll(mask & ((1ull << j) - 1ull));   // position of sample (r, j) in the compact sample list
+    }
+}
+
+__global__ void k_pass_update(const ObjConst* oc, const ObjState* st, const unsigned long long* raymask, const int* rayoff,
+                              unsigned char* alive, const float* ssdf, float th, int j0, int j1) {
+    const int b = blockIdx.y;
+    const ObjConst c = oc[b];
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= c.n_rays) return;
+    const int gr = c.ray_off + r;
+    if (st[b].status != DSP_STATUS_GOOD || !alive[gr]) return;
+    const unsigned long long mask = raymask[gr];
+    unsigned long long sel = mask & range_mask(j0, j1);
+    const int base = c.samp_off + rayoff[gr];
+    bool solid = false;
+    while (sel) {
+        const int j = __ffsll((long long)sel) - 1;
+        sel &= sel - 1;
+        solid |= ssdf[base + __popcll(mask & ((1ull << j) - 1ull))] <= -th;
+    }
+    if (solid) alive[gr] = 0;
 }
 
 // surface points -> object frame (loss.py:31-32); also the pose-only inlier bookkeeping (optimizer.py:76-78)
@@ -195,24 +263,25 @@ __global__ void k_surface(const ObjConst* oc, const ObjState* st, const float* p
 // tile lists for the decoder kernels (single workgroup; counts live on the device)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_build_tiles(const ObjConst* oc, const ObjState* st, int n_obj, int mode, int4* tiles,
-                                                     int* n_tiles, double* counters) {
-    // mode 0: forward tiles over the V in-sphere samples; mode 1: jacobian tiles over M surface + K render points
+                                                     int* n_tiles, double* counters, int add_v) {
+    // mode 0: forward tiles over the V in-sphere samples; mode 1: jacobian tiles over M surface + K render points;
+    // mode 2: forward tiles over the P samples selected for the current front-to-back pass (indexed through plist)
     __shared__ int base;
     if (threadIdx.x == 0) base = 0;
     __syncthreads();
-    double cnt = 0.0;
+    double cnt = 0.0, vtot = 0.0;
     for (int b = 0; b < n_obj; ++b) {
         const ObjConst c = oc[b];
         const ObjState& s = st[b];
         const bool good = s.status == DSP_STATUS_GOOD;
         const int b0 = base;
         __syncthreads();
-        if (mode == 0) {
-            const int n = good ? s.V : 0;
+        if (mode == 0 || mode == 2) {
+            const int n = good ? (mode == 0 ? s.V : s.P) : 0;
             const int nt = (n + TILE_PTS - 1) / TILE_PTS;
             for (int i = threadIdx.x; i < nt; i += 256)
                 tiles[b0 + i] = make_int4(c.samp_off + i * TILE_PTS, min(TILE_PTS, n - i * TILE_PTS), b, 0);
-            if (threadIdx.x == 0) { base = b0 + nt; cnt += n; }
+            if (threadIdx.x == 0) { base = b0 + nt; cnt += n; if (good) vtot += s.V; }
         } else {
             const int n1 = good ? c.n_pts : 0;
             const int n2 = good ? s.K : 0;
@@ -225,7 +294,7 @@ __global__ __launch_bounds__(256) void k_build_tiles(const ObjConst* oc, const O
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { *n_tiles = base; counters[mode] += cnt; }
+    if (threadIdx.x == 0) { *n_tiles = base; counters[mode == 2 ? 0 : mode] += cnt; if (add_v) counters[2] += vtot; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -745,14 +814,27 @@ void launch_sample_count(const ObjConst* oc, ObjState* st, const float* rays, un
 void launch_scan_rays(const ObjConst* oc, ObjState* st, const int* cnt, int* off, int which, int B, hipStream_t s) {
     hipLaunchKernelGGL(k_scan_rays, dim3(B), dim3(256), 0, s, oc, st, cnt, off, which);
 }
-void launch_sample_write(const ObjConst* oc, const ObjState* st, const float* rays, const unsigned long long* m, const int* off, float4* spts, int D, int maxR, int B, hipStream_t s) {
-    hipLaunchKernelGGL(k_sample_write, GRID2(maxR, B), dim3(256), 0, s, oc, st, rays, m, off, spts, D);
+void launch_sample_write(const ObjConst* oc, const ObjState* st, const float* rays, const unsigned long long* m, const int* off, float4* spts,
+                         float* ssdf, unsigned char* alive, int D, int maxR, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_sample_write, GRID2(maxR, B), dim3(256), 0, s, oc, st, rays, m, off, spts, ssdf, alive, D);
+}
+void launch_pass_select(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff, const unsigned char* alive,
+                        int* pcnt, int j0, int j1, int maxR, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_pass_select, GRID2(maxR, B), dim3(256), 0, s, oc, st, raymask, rayoff, alive, pcnt, j0, j1);
+}
+void launch_pass_write(const ObjConst* oc, const ObjState* st, const unsigned long long* raymask, const int* rayoff, const unsigned char* alive,
+                       const int* poff, int* plist, int j0, int j1, int maxR, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_pass_write, GRID2(maxR, B), dim3(256), 0, s, oc, st, raymask, rayoff, alive, poff, plist, j0, j1);
+}
+void launch_pass_update(const ObjConst* oc, const ObjState* st, const unsigned long long* raymask, const int* rayoff, unsigned char* alive,
+                        const float* ssdf, float th, int j0, int j1, int maxR, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_pass_update, GRID2(maxR, B), dim3(256), 0, s, oc, st, raymask, rayoff, alive, ssdf, th, j0, j1);
 }
 void launch_surface(const ObjConst* oc, const ObjState* st, const float* pts, float4* jpts, float2* jaux, int maxM, int B, hipStream_t s) {
     hipLaunchKernelGGL(k_surface, GRID2(maxM, B), dim3(256), 0, s, oc, st, pts, jpts, jaux);
 }
-void launch_build_tiles(const ObjConst* oc, const ObjState* st, int B, int mode, int4* tiles, int* n_tiles, double* counters, hipStream_t s) {
-    hipLaunchKernelGGL(k_build_tiles, dim3(1), dim3(256), 0, s, oc, st, B, mode, tiles, n_tiles, counters);
+void launch_build_tiles(const ObjConst* oc, const ObjState* st, int B, int mode, int4* tiles, int* n_tiles, double* counters, int add_v, hipStream_t s) {
+    hipLaunchKernelGGL(k_build_tiles, dim3(1), dim3(256), 0, s, oc, st, B, mode, tiles, n_tiles, counters, add_v);
 }
 void launch_render_scan(const ObjConst* oc, ObjState* st, const unsigned long long* m, const int* off, const float* ssdf, const float* depth,
                         float* sdeds, float* ray_res, int* kcnt, int* mcnt, int D, float th, int maxR, int B, hipStream_t s) {

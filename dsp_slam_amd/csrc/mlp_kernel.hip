@@ -145,7 +145,8 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
         const int local = wave * WAVE_PTS + pl;
         const bool valid = local < td.y;
         const int pidx = td.x + (valid ? local : 0);
-        float4 pt = a.pts[pidx];
+        const int src = (!BWD && a.index) ? a.index[pidx] : pidx;
+        float4 pt = a.pts[src];
         if (!valid) pt = make_float4(0.f, 0.f, 0.f, 0.f);
         // The shape code is the same for every point of the tile, so its contribution to layer 0 and to the latent_in
         // layer is a per-object bias vector (k_code_bias): stage both into LDS.  What is left of layer 0 is three
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
                 part += __shfl_xor(part, 32);
                 y = tanhf(part + a.b_last);
                 if (!BWD) {
-                    if (valid && g == 0) a.out_sdf[pidx + td.w] = y;
+                    if (valid && g == 0) a.out_sdf[a.index ? src : pidx + td.w] = y;
                 } else {
                     // seed of the backward sweep: d tanh * W_last, masked by the last hidden relu
                     const float d = 1.f - y * y;

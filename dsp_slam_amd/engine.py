@@ -61,6 +61,10 @@ class Batch(object):
         if trace:
             L.check(lib.dsp_batch_enable_trace(self._h, 1), engine._h, "dsp_batch_enable_trace")
 
+    def set_ray_passes(self, n):
+        """0 = automatic, 1 = decode every in-sphere sample (reference behaviour), n = n front-to-back depth ranges."""
+        L.check(L.load().dsp_batch_set_ray_passes(self._h, int(n)), self.engine._h, "dsp_batch_set_ray_passes")
+
     def run(self):
         L.check(L.load().dsp_batch_run(self._h), self.engine._h, "dsp_batch_run")
 

@@ -68,13 +68,14 @@ typedef struct dsp_gn_params {
 
 /* Counters and device timings of the last run of a batch. */
 typedef struct dsp_stats {
-    double n_fwd_points;         /* sum over iterations and objects of V (forward-only decoder points) */
+    double n_fwd_points;         /* forward-only decoder points actually evaluated (<= sum of V: samples behind a solid sample are skipped) */
     double n_jac_points;         /* sum of M + K (forward + input-gradient points) */
     double ms_total;             /* HIP-event time of the whole run on the handle's stream */
     double ms_mlp_fwd;           /* summed time of the forward-only decoder kernel launches */
     double ms_mlp_jac;           /* summed time of the forward+gradient decoder kernel launches */
     int32_t n_mlp_fwd_launches;
     int32_t n_mlp_jac_launches;
+    double n_insphere_points;    /* sum over iterations and objects of V, the in-sphere sample count the reference decodes */
 } dsp_stats;
 
 /* ---- lifetime --------------------------------------------------------------------------------- */
@@ -133,6 +134,11 @@ int dsp_batch_create(dsp_handle* h, const dsp_gn_params* prm, int32_t n_objects,
 int dsp_batch_run(dsp_batch* b);        /* resets the state to the uploaded initial estimate, runs, synchronises */
 int dsp_batch_results(dsp_batch* b, float* t_cam_obj_out, float* codes_out, float* loss_out, int32_t* status_out);
 int dsp_batch_stats(dsp_batch* b, dsp_stats* out);
+/* Number of front-to-back depth ranges the forward decoder is run in per iteration (exact early ray termination: a ray
+ * stops being sampled behind its first solid sample, where the transmittance is exactly 0).  0 = automatic (2..10, about five
+ * rounds of tiles per pass); 1 = decode every in-sphere sample like the reference does.  Results are identical
+ * for every setting. */
+int dsp_batch_set_ray_passes(dsp_batch* b, int n_passes);
 /* Record per-iteration traces during the following runs (testing; costs ~21 KB per object-iteration). */
 int dsp_batch_enable_trace(dsp_batch* b, int on);
 /* Per-iteration trace of the last run (testing): for iteration e < num_iterations and object i,

@@ -185,3 +185,35 @@ def test_degenerate_objects_do_not_poison_the_batch(eng):
     alone = _run(eng, prm, [good])
     assert np.array_equal(alone[0][0], t[1]) and np.array_equal(alone[1][0], c[1])
     assert np.isfinite(t[1]).all()
+
+
+def test_early_ray_termination_is_exact(eng):
+    """Front-to-back ray passes skip decoder evaluations behind the first solid sample of a ray (transmittance exactly 0).
+    Every pass count gives bit-identical results to decoding all in-sphere samples (1 pass), and it does skip work."""
+    prm = E.gn_params(num_iterations=4)
+    objs = synth.make_batch(3, first_seed=950, n_surface=400, n_background=120)
+    args = ([o["t_cam_obj_init"] for o in objs], [o["pts"] for o in objs], [o["rays"] for o in objs], [o["depth"] for o in objs])
+    ref = None
+    evaluated = {}
+    for n_passes in (1, 2, 5, 10, 50):
+        b = eng.batch(prm, *args, trace=True)
+        b.set_ray_passes(n_passes)
+        b.run()
+        res = b.results()
+        tr = [b.trace(e) for e in range(4)]
+        st = b.stats()
+        evaluated[n_passes] = st["n_fwd_points"]
+        b.close()
+        if ref is None:
+            ref = (res, tr)
+            assert st["n_fwd_points"] == st["n_insphere_points"]
+        else:
+            for a, c in zip(res, ref[0]):
+                assert np.array_equal(a, c)
+            for ta, tc in zip(tr, ref[1]):
+                for k in ("H", "b", "dx", "V", "K", "set_sums"):
+                    assert np.array_equal(ta[k], tc[k]), k
+            assert st["n_insphere_points"] == ref_v
+        ref_v = st["n_insphere_points"]
+    assert evaluated[50] < evaluated[5] < evaluated[2] < evaluated[1]
+    assert evaluated[5] < 0.85 * evaluated[1]

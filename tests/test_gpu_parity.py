@@ -164,7 +164,8 @@ def compare_linearisation(tr, i, its, k4):
     assert np.abs(tr["depths"][i][:nd] - own_depths).max() <= 2.5 * np.spacing(np.abs(own_depths).max())
     same_sets = int(tr["set_sums"][i][0]) == it["vsum"] and int(tr["set_sums"][i][1]) == it["ksum"]
     jitter_same = it["vsum"] == itj["vsum"] and it["ksum"] == itj["ksum"]
-    flips = abs(int(tr["V"][i]) - it["V"]) + abs(int(tr["K"][i]) - it["K"]) + abs(int(tr["m"][i]) - it["m"])
+    # (m is not compared: the device does not decode samples behind a solid one, where the transmittance is exactly 0)
+    flips = abs(int(tr["V"][i]) - it["V"]) + abs(int(tr["K"][i]) - it["K"])
     hs, bs = np.abs(it["H"]).max(), np.abs(it["b"]).max()
     mask = np.ones(it["b"].shape[0], bool)
     mask[3:6] = False
@@ -182,7 +183,7 @@ def compare_linearisation(tr, i, its, k4):
             assert np.abs(tr["dx"][i] - it["dx"]).max() < 2e-4 * np.abs(it["dx"]).max() + 4 * np.abs(itj["dx"] - it["dx"]).max()
         return amp_h < 1e-3 * hs
     assert flips <= max(4, it["K"] // 250), "too many threshold flips: V %d/%d m %d/%d K %d/%d" % (
-        tr["V"][i], it["V"], tr["m"][i], it["m"], tr["K"][i], it["K"])
+        tr["V"][i], it["V"], tr["m"][i], it["m"], tr["K"][i], it["K"])   # m informational
     loose = 8.0 * max(flips, 2) / max(it["K"], 1)
     assert np.abs(tr["H"][i] - it["H"]).max() < loose * hs + 4 * np.abs(itj["H"] - it["H"]).max()
     assert np.abs(tr["b"][i][mask] - it["b"][mask]).max() < loose * bs + 4 * np.abs(itj["b"] - it["b"])[mask].max()
