@@ -331,6 +331,7 @@ struct dsp_batch {
     DevBuf<int> raycnt, rayoff, kcnt, koff, mcnt, pcnt, poff, plist;
     DevBuf<unsigned char> ray_alive;
     int n_ray_passes = 0;     // front-to-back forward passes per iteration (0 = pick from the batch size)
+    std::vector<int> pass_bounds;   // optional explicit depth-index boundaries (n_passes + 1 entries, 0 .. D)
     DevBuf<float> ray_res, ssdf, sdeds, jgrad, partials, trace, out_t, out_code, out_loss, rows;
     DevBuf<float4> spts, jpts;
     DevBuf<float2> jaux;
@@ -498,14 +499,21 @@ void iteration_front(dsp_batch* b, size_t& cursor, bool do_render) {
             n_passes = std::max(2, std::min(n_passes, 10));
         }
         n_passes = std::max(1, std::min(n_passes, b->D));
+        // Depth-index ranges: uniform unless given explicitly (non-uniform spacings measured no better: tools/gpu_bounds_sweep.py)
+        std::vector<int> bounds = b->pass_bounds;
+        if ((int)bounds.size() != n_passes + 1) {
+            bounds.assign(n_passes + 1, 0);
+            for (int p = 0; p <= n_passes; ++p) bounds[p] = (int)((long long)b->D * p / n_passes);
+        }
         for (int p = 0; p < n_passes; ++p) {
-            const int j0 = (int)((long long)b->D * p / n_passes), j1 = (int)((long long)b->D * (p + 1) / n_passes);
+            const int j0 = bounds[p], j1 = bounds[p + 1];
+            if (j1 <= j0) continue;
             launch_pass_select(b->oc.p, b->st.p, b->raymask.p, b->rayoff.p, b->ray_alive.p, b->pcnt.p, j0, j1, b->maxR, B, s);
             launch_scan_rays(b->oc.p, b->st.p, b->pcnt.p, b->poff.p, 2, B, s);
             launch_pass_write(b->oc.p, b->st.p, b->raymask.p, b->rayoff.p, b->ray_alive.p, b->poff.p, b->plist.p, j0, j1, b->maxR, B, s);
             launch_build_tiles(b->oc.p, b->st.p, B, 2, b->tiles_f.p, b->n_tiles.p, b->counters.p, p == 0 ? 1 : 0, s);
             launch_decoder(b, false, cursor);
-            if (p + 1 < n_passes)
+            if (j1 < b->D)
                 launch_pass_update(b->oc.p, b->st.p, b->raymask.p, b->rayoff.p, b->ray_alive.p, b->ssdf.p, b->prm.cut_off, j0, j1, b->maxR, B, s);
         }
         launch_render_scan(b->oc.p, b->st.p, b->raymask.p, b->rayoff.p, b->ssdf.p, b->depth.p, b->sdeds.p, b->ray_res.p,
@@ -824,6 +832,16 @@ int dsp_batch_stats(dsp_batch* b, dsp_stats* out) {
 int dsp_batch_set_ray_passes(dsp_batch* b, int n_passes) {
     if (!b || n_passes < 0 || n_passes > MAX_DEPTH_SAMPLES) return DSP_E_ARG;
     b->n_ray_passes = n_passes;
+    b->pass_bounds.clear();
+    return DSP_OK;
+}
+
+int dsp_batch_set_ray_pass_bounds(dsp_batch* b, const int32_t* bounds, int n_passes) {
+    if (!b || !bounds || n_passes < 1 || n_passes > MAX_DEPTH_SAMPLES) return DSP_E_ARG;
+    if (bounds[0] != 0 || bounds[n_passes] != b->D) return DSP_E_ARG;
+    for (int p = 0; p < n_passes; ++p) if (bounds[p + 1] < bounds[p]) return DSP_E_ARG;
+    b->n_ray_passes = n_passes;
+    b->pass_bounds.assign(bounds, bounds + n_passes + 1);
     return DSP_OK;
 }
 

@@ -65,6 +65,11 @@ class Batch(object):
         """0 = automatic, 1 = decode every in-sphere sample (reference behaviour), n = n front-to-back depth ranges."""
         L.check(L.load().dsp_batch_set_ray_passes(self._h, int(n)), self.engine._h, "dsp_batch_set_ray_passes")
 
+    def set_ray_pass_bounds(self, bounds):
+        bounds = np.ascontiguousarray(bounds, np.int32)
+        L.check(L.load().dsp_batch_set_ray_pass_bounds(self._h, L.ptr(bounds, L.c_i32p), bounds.shape[0] - 1), self.engine._h,
+                "dsp_batch_set_ray_pass_bounds")
+
     def run(self):
         L.check(L.load().dsp_batch_run(self._h), self.engine._h, "dsp_batch_run")
 

@@ -139,6 +139,8 @@ int dsp_batch_stats(dsp_batch* b, dsp_stats* out);
  * rounds of tiles per pass); 1 = decode every in-sphere sample like the reference does.  Results are identical
  * for every setting. */
 int dsp_batch_set_ray_passes(dsp_batch* b, int n_passes);
+/* The same with explicit depth-index boundaries: bounds[0] = 0 <= ... <= bounds[n_passes] = num_depth_samples. */
+int dsp_batch_set_ray_pass_bounds(dsp_batch* b, const int32_t* bounds, int n_passes);
 /* Record per-iteration traces during the following runs (testing; costs ~21 KB per object-iteration). */
 int dsp_batch_enable_trace(dsp_batch* b, int on);
 /* Per-iteration trace of the last run (testing): for iteration e < num_iterations and object i,
