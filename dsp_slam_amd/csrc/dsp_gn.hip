@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -329,9 +330,10 @@ struct dsp_batch {
     bool have_codes = false;
     DevBuf<unsigned long long> raymask;
     DevBuf<int> raycnt, rayoff, kcnt, koff, mcnt, pcnt, poff, plist;
-    DevBuf<unsigned char> ray_alive;
+    DevBuf<unsigned char> ray_alive, ray_hint, ray_plo;
     int n_ray_passes = 0;     // front-to-back forward passes per iteration (0 = pick from the batch size)
     std::vector<int> pass_bounds;   // optional explicit depth-index boundaries (n_passes + 1 entries, 0 .. D)
+    int hint_margin = 2, hint_step = 8;   // adaptive passes: pass 0 = [0, hint + margin), middle pass = next `step` indices
     DevBuf<float> ray_res, ssdf, sdeds, jgrad, partials, trace, out_t, out_code, out_loss, rows;
     DevBuf<float4> spts, jpts;
     DevBuf<float2> jaux;
@@ -415,6 +417,7 @@ dsp_batch* batch_build(dsp_handle* h, const dsp_gn_params* prm, int B, const int
         b->raycnt.alloc(b->sum_rays); b->rayoff.alloc(b->sum_rays);
         b->kcnt.alloc(b->sum_rays); b->koff.alloc(b->sum_rays); b->mcnt.alloc(b->sum_rays);
         b->pcnt.alloc(b->sum_rays); b->poff.alloc(b->sum_rays); b->plist.alloc(cap_s); b->ray_alive.alloc(b->sum_rays);
+        b->ray_hint.alloc(b->sum_rays); b->ray_plo.alloc(b->sum_rays);
         b->ray_res.alloc(b->sum_rays);
         b->spts.alloc(cap_s); b->ssdf.alloc(cap_s); b->sdeds.alloc(cap_s);
         b->tiles_f.alloc(cap_s / TILE_PTS + B);
@@ -487,34 +490,39 @@ void iteration_front(dsp_batch* b, size_t& cursor, bool do_render) {
         launch_sample_count(b->oc.p, b->st.p, b->rays.p, b->raymask.p, b->raycnt.p, b->D, b->maxR, B, s);
         launch_scan_rays(b->oc.p, b->st.p, b->raycnt.p, b->rayoff.p, 0, B, s);
         launch_sample_write(b->oc.p, b->st.p, b->rays.p, b->raymask.p, b->rayoff.p, b->spts.p, b->ssdf.p, b->ray_alive.p, b->D, b->maxR, B, s);
-        // Forward decoder, front to back in depth-index ranges with exact early ray termination (gn_kernels.hip,
-        // "front-to-back ray passes").  More passes skip more samples behind surfaces but cost launches and tile-granularity
-        // tails, so small batches use fewer.
-        // automatic: about five tile rounds of the 256 CUs per pass (measured optimum: 2 passes for one cfg2 object,
-        // 3-5 for four, ~10 from eight objects up -- tools/gpu_pass_sweep.py)
-        int n_passes = b->n_ray_passes;
-        if (n_passes <= 0) {
-            const double tiles = 0.75 * (double)b->cap_s / TILE_PTS;
-            n_passes = (int)std::lround(tiles / (5.0 * h->n_cu));
-            n_passes = std::max(2, std::min(n_passes, 10));
+        // Forward decoder, front to back with exact early ray termination (gn_kernels.hip, "front-to-back ray passes").
+        //  * explicit pass count / boundaries (dsp_batch_set_ray_passes / _bounds): fixed depth-index ranges for all rays;
+        //  * automatic (default): per-ray ranges steered by where each ray terminated in the previous GN iteration -- pass 0
+        //    decodes [0, hint + 2), a middle pass the next 8 indices (only with enough tiles to fill the chip), the last
+        //    pass the rest.  Fewer launches than fixed ranges and less overshoot behind the surface.
+        std::vector<PassSpec> specs;
+        const double tiles = 0.75 * (double)b->cap_s / TILE_PTS;     // expected forward tiles per iteration
+        int fixed_passes = b->n_ray_passes;
+        if (fixed_passes <= 0 && tiles >= 100.0 * h->n_cu) fixed_passes = 10;   // large batches: ten uniform ranges measured best
+        if (fixed_passes > 0) {
+            const int n_passes = std::max(1, std::min(fixed_passes, b->D));
+            std::vector<int> bounds = b->pass_bounds;
+            if ((int)bounds.size() != n_passes + 1) {
+                bounds.assign(n_passes + 1, 0);
+                for (int p = 0; p <= n_passes; ++p) bounds[p] = (int)((long long)b->D * p / n_passes);
+            }
+            for (int p = 0; p < n_passes; ++p)
+                if (bounds[p + 1] > bounds[p]) specs.push_back(PassSpec{bounds[p], bounds[p + 1], b->D, p, bounds[p + 1] >= b->D, nullptr, nullptr});
+        } else {
+            // small and medium batches: few launches matter more than the last few % of skipped samples
+            // (tools/gpu_auto_probe.py: 1 object 32.3 ms vs 32.9 fixed-2; 8 objects 45.4 obj/s vs 43.1 fixed-10)
+            const int n_passes = tiles >= 12.0 * h->n_cu ? 3 : 2;
+            for (int p = 0; p < n_passes; ++p)
+                specs.push_back(PassSpec{b->hint_margin, b->hint_step, b->D, p, p == n_passes - 1, b->ray_hint.p, b->ray_plo.p});
         }
-        n_passes = std::max(1, std::min(n_passes, b->D));
-        // Depth-index ranges: uniform unless given explicitly (non-uniform spacings measured no better: tools/gpu_bounds_sweep.py)
-        std::vector<int> bounds = b->pass_bounds;
-        if ((int)bounds.size() != n_passes + 1) {
-            bounds.assign(n_passes + 1, 0);
-            for (int p = 0; p <= n_passes; ++p) bounds[p] = (int)((long long)b->D * p / n_passes);
-        }
-        for (int p = 0; p < n_passes; ++p) {
-            const int j0 = bounds[p], j1 = bounds[p + 1];
-            if (j1 <= j0) continue;
-            launch_pass_select(b->oc.p, b->st.p, b->raymask.p, b->rayoff.p, b->ray_alive.p, b->pcnt.p, j0, j1, b->maxR, B, s);
+        for (const PassSpec& ps : specs) {
+            launch_pass_select(b->oc.p, b->st.p, b->raymask.p, b->rayoff.p, b->ray_alive.p, b->pcnt.p, ps, b->maxR, B, s);
             launch_scan_rays(b->oc.p, b->st.p, b->pcnt.p, b->poff.p, 2, B, s);
-            launch_pass_write(b->oc.p, b->st.p, b->raymask.p, b->rayoff.p, b->ray_alive.p, b->poff.p, b->plist.p, j0, j1, b->maxR, B, s);
-            launch_build_tiles(b->oc.p, b->st.p, B, 2, b->tiles_f.p, b->n_tiles.p, b->counters.p, p == 0 ? 1 : 0, s);
+            launch_pass_write(b->oc.p, b->st.p, b->raymask.p, b->rayoff.p, b->ray_alive.p, b->poff.p, b->plist.p, ps, b->maxR, B, s);
+            launch_build_tiles(b->oc.p, b->st.p, B, 2, b->tiles_f.p, b->n_tiles.p, b->counters.p, ps.pass == 0 ? 1 : 0, s);
             launch_decoder(b, false, cursor);
-            if (j1 < b->D)
-                launch_pass_update(b->oc.p, b->st.p, b->raymask.p, b->rayoff.p, b->ray_alive.p, b->ssdf.p, b->prm.cut_off, j0, j1, b->maxR, B, s);
+            if (!ps.last || ps.hint)
+                launch_pass_update(b->oc.p, b->st.p, b->raymask.p, b->rayoff.p, b->ray_alive.p, b->ssdf.p, b->prm.cut_off, ps, b->maxR, B, s);
         }
         launch_render_scan(b->oc.p, b->st.p, b->raymask.p, b->rayoff.p, b->ssdf.p, b->depth.p, b->sdeds.p, b->ray_res.p,
                            b->kcnt.p, b->mcnt.p, b->D, b->prm.cut_off, b->maxR, B, s);
@@ -543,6 +551,7 @@ void batch_run(dsp_batch* b) {
     HIP_TRY(hipMemsetAsync(b->st.p, 0, (size_t)B * sizeof(ObjState), s));
     launch_init_state(b->st.p, b->t_in.p, b->have_codes ? b->codes_in.p : nullptr, b->scale_in.p, B, b->D, b->pose_only ? 1 : 0, s);
     if (b->pose_only) HIP_TRY(hipMemsetAsync(b->alive.p, 1, b->cap_j, s));
+    else HIP_TRY(hipMemsetAsync(b->ray_hint.p, b->D / 2, b->sum_rays, s));   // no history yet: first guess = object centre
     const GnParamsDev dp = dev_params(b);
     for (int e = 0; e < iters; ++e) {
         iteration_front(b, cursor, !b->pose_only);
@@ -625,6 +634,7 @@ void run_terms(dsp_handle* h, const float* pts_cam, int64_t n_pts, const float* 
     }
     st.n_alive = -1;
     HIP_TRY(hipMemcpyAsync(b->st.p, &st, sizeof st, hipMemcpyHostToDevice, h->stream));
+    if (render) HIP_TRY(hipMemsetAsync(b->ray_hint.p, b->D, b->sum_rays, h->stream));   // no history: decode whole rays in pass 0
     HIP_TRY(hipMemsetAsync(b->counters.p, 0, 3 * sizeof(double), h->stream));
     size_t cursor = 0;
     b->ev_kind.clear();

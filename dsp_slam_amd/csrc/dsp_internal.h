@@ -105,12 +105,19 @@ void launch_render_scan(const ObjConst* oc, ObjState* st, const unsigned long lo
                         float* sdeds, float* ray_res, int* kcnt, int* mcnt, int D, float th, int maxR, int B, hipStream_t s);
 void launch_render_write(const ObjConst* oc, const ObjState* st, const int* raycnt, const int* rayoff, const int* koff, const float4* spts,
                          const float* sdeds, const float* ray_res, float4* jpts, float2* jaux, int maxR, int B, hipStream_t s);
+// one front-to-back forward pass: fixed depth-index range [j0, j1) (hint == nullptr), or per-ray adaptive ranges where
+// j0 = margin added to the hint in pass 0 and j1 = step of the middle passes
+struct PassSpec {
+    int j0, j1, n_depth, pass, last;
+    unsigned char* hint;   // per ray: depth index of the first solid sample in the previous GN iteration
+    unsigned char* plo;    // per ray: end of the range decoded so far in this iteration
+};
 void launch_pass_select(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff, const unsigned char* alive,
-                        int* pcnt, int j0, int j1, int maxR, int B, hipStream_t s);
+                        int* pcnt, const PassSpec& ps, int maxR, int B, hipStream_t s);
 void launch_pass_write(const ObjConst* oc, const ObjState* st, const unsigned long long* raymask, const int* rayoff, const unsigned char* alive,
-                       const int* poff, int* plist, int j0, int j1, int maxR, int B, hipStream_t s);
+                       const int* poff, int* plist, const PassSpec& ps, int maxR, int B, hipStream_t s);
 void launch_pass_update(const ObjConst* oc, const ObjState* st, const unsigned long long* raymask, const int* rayoff, unsigned char* alive,
-                        const float* ssdf, float th, int j0, int j1, int maxR, int B, hipStream_t s);
+                        const float* ssdf, float th, const PassSpec& ps, int maxR, int B, hipStream_t s);
 void launch_sum_m(const ObjConst* oc, ObjState* st, const int* mcnt, int B, hipStream_t s);
 void launch_gram(const ObjConst* oc, const ObjState* st, const float4* jpts, const float2* jaux, const float* jgrad, const unsigned char* alive,
                  float* partials, int n_slices, float b_sdf, float b_render, int robust, int n_terms, int B, hipStream_t s);

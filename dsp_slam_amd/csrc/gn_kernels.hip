@@ -195,27 +195,45 @@ __device__ __forceinline__ unsigned long long range_mask(int j0, int j1) {
     return hi & ~((1ull << j0) - 1ull);
 }
 
+// Range of ray gr in the current pass.  Fixed mode (hint == nullptr): [j0, j1) for every ray.  Adaptive mode: pass 0 covers
+// [0, hint + margin) where hint is the depth index at which this ray terminated in the previous GN iteration (the pose moves
+// little between iterations), pass 1 the next `step` indices, the last pass whatever is left -- always contiguous and front
+// to back, so exactness does not depend on the hints, only the amount of skipped work does.
+__device__ __forceinline__ void pass_range(int gr, int j0, int j1, int n_depth, int pass, int last, const unsigned char* hint,
+                                           const unsigned char* plo, int& lo, int& hi) {
+    if (!hint) { lo = j0; hi = j1; return; }
+    lo = (pass == 0) ? 0 : (int)plo[gr];
+    hi = last ? n_depth : (pass == 0 ? min(n_depth, (int)hint[gr] + j0) : min(n_depth, lo + j1));
+    hi = max(hi, lo);
+}
+
 __global__ void k_pass_select(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff,
-                              const unsigned char* alive, int* pcnt, int j0, int j1) {
+                              const unsigned char* alive, int* pcnt, int j0, int j1, int n_depth, int pass, int last,
+                              const unsigned char* hint, const unsigned char* plo) {
     const int b = blockIdx.y;
     const ObjConst c = oc[b];
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= c.n_rays) return;
     const int gr = c.ray_off + r;
     const bool on = st[b].status == DSP_STATUS_GOOD && alive[gr];
-    pcnt[gr] = on ? __popcll(raymask[gr] & range_mask(j0, j1)) : 0;
+    int lo, hi;
+    pass_range(gr, j0, j1, n_depth, pass, last, hint, plo, lo, hi);
+    pcnt[gr] = on ? __popcll(raymask[gr] & range_mask(lo, hi)) : 0;
 }
 
 __global__ void k_pass_write(const ObjConst* oc, const ObjState* st, const unsigned long long* raymask, const int* rayoff,
-                             const unsigned char* alive, const int* poff, int* plist, int j0, int j1) {
+                             const unsigned char* alive, const int* poff, int* plist, int j0, int j1, int n_depth, int pass, int last,
+                             const unsigned char* hint, const unsigned char* plo) {
     const int b = blockIdx.y;
     const ObjConst c = oc[b];
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= c.n_rays) return;
     const int gr = c.ray_off + r;
     if (st[b].status != DSP_STATUS_GOOD || !alive[gr]) return;
+    int lo, hi;
+    pass_range(gr, j0, j1, n_depth, pass, last, hint, plo, lo, hi);
     const unsigned long long mask = raymask[gr];
-    unsigned long long sel = mask & range_mask(j0, j1);
+    unsigned long long sel = mask & range_mask(lo, hi);
     int* dst = plist + c.samp_off + poff[gr];
     const int base = c.samp_off + rayoff[gr];
     while (sel) {
@@ -226,23 +244,31 @@ __global__ void k_pass_write(const ObjConst* oc, const ObjState* st, const unsig
 }
 
 __global__ void k_pass_update(const ObjConst* oc, const ObjState* st, const unsigned long long* raymask, const int* rayoff,
-                              unsigned char* alive, const float* ssdf, float th, int j0, int j1) {
+                              unsigned char* alive, const float* ssdf, float th, int j0, int j1, int n_depth, int pass, int last,
+                              unsigned char* hint, unsigned char* plo) {
     const int b = blockIdx.y;
     const ObjConst c = oc[b];
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= c.n_rays) return;
     const int gr = c.ray_off + r;
     if (st[b].status != DSP_STATUS_GOOD || !alive[gr]) return;
+    int lo, hi;
+    pass_range(gr, j0, j1, n_depth, pass, last, hint, plo, lo, hi);
     const unsigned long long mask = raymask[gr];
-    unsigned long long sel = mask & range_mask(j0, j1);
+    unsigned long long sel = mask & range_mask(lo, hi);
     const int base = c.samp_off + rayoff[gr];
-    bool solid = false;
+    int first_solid = -1;
     while (sel) {
         const int j = __ffsll((long long)sel) - 1;
         sel &= sel - 1;
-        solid |= ssdf[base + __popcll(mask & ((1ull << j) - 1ull))] <= -th;
+        if (ssdf[base + __popcll(mask & ((1ull << j) - 1ull))] <= -th) { first_solid = j; break; }
     }
-    if (solid) alive[gr] = 0;
+    if (first_solid >= 0) alive[gr] = 0;
+    if (hint) {
+        plo[gr] = (unsigned char)hi;
+        if (first_solid >= 0) hint[gr] = (unsigned char)first_solid;
+        else if (last) hint[gr] = (unsigned char)n_depth;      // never terminated: decode the whole ray in pass 0 next time
+    }
 }
 
 // surface points -> object frame (loss.py:31-32); also the pose-only inlier bookkeeping (optimizer.py:76-78)
@@ -819,16 +845,19 @@ void launch_sample_write(const ObjConst* oc, const ObjState* st, const float* ra
     hipLaunchKernelGGL(k_sample_write, GRID2(maxR, B), dim3(256), 0, s, oc, st, rays, m, off, spts, ssdf, alive, D);
 }
 void launch_pass_select(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff, const unsigned char* alive,
-                        int* pcnt, int j0, int j1, int maxR, int B, hipStream_t s) {
-    hipLaunchKernelGGL(k_pass_select, GRID2(maxR, B), dim3(256), 0, s, oc, st, raymask, rayoff, alive, pcnt, j0, j1);
+                        int* pcnt, const PassSpec& ps, int maxR, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_pass_select, GRID2(maxR, B), dim3(256), 0, s, oc, st, raymask, rayoff, alive, pcnt, ps.j0, ps.j1, ps.n_depth, ps.pass,
+                       ps.last, ps.hint, ps.plo);
 }
 void launch_pass_write(const ObjConst* oc, const ObjState* st, const unsigned long long* raymask, const int* rayoff, const unsigned char* alive,
-                       const int* poff, int* plist, int j0, int j1, int maxR, int B, hipStream_t s) {
-    hipLaunchKernelGGL(k_pass_write, GRID2(maxR, B), dim3(256), 0, s, oc, st, raymask, rayoff, alive, poff, plist, j0, j1);
+                       const int* poff, int* plist, const PassSpec& ps, int maxR, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_pass_write, GRID2(maxR, B), dim3(256), 0, s, oc, st, raymask, rayoff, alive, poff, plist, ps.j0, ps.j1, ps.n_depth,
+                       ps.pass, ps.last, ps.hint, ps.plo);
 }
 void launch_pass_update(const ObjConst* oc, const ObjState* st, const unsigned long long* raymask, const int* rayoff, unsigned char* alive,
-                        const float* ssdf, float th, int j0, int j1, int maxR, int B, hipStream_t s) {
-    hipLaunchKernelGGL(k_pass_update, GRID2(maxR, B), dim3(256), 0, s, oc, st, raymask, rayoff, alive, ssdf, th, j0, j1);
+                        const float* ssdf, float th, const PassSpec& ps, int maxR, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_pass_update, GRID2(maxR, B), dim3(256), 0, s, oc, st, raymask, rayoff, alive, ssdf, th, ps.j0, ps.j1, ps.n_depth,
+                       ps.pass, ps.last, ps.hint, ps.plo);
 }
 void launch_surface(const ObjConst* oc, const ObjState* st, const float* pts, float4* jpts, float2* jaux, int maxM, int B, hipStream_t s) {
     hipLaunchKernelGGL(k_surface, GRID2(maxM, B), dim3(256), 0, s, oc, st, pts, jpts, jaux);

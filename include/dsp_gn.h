@@ -135,8 +135,8 @@ int dsp_batch_run(dsp_batch* b);        /* resets the state to the uploaded init
 int dsp_batch_results(dsp_batch* b, float* t_cam_obj_out, float* codes_out, float* loss_out, int32_t* status_out);
 int dsp_batch_stats(dsp_batch* b, dsp_stats* out);
 /* Number of front-to-back depth ranges the forward decoder is run in per iteration (exact early ray termination: a ray
- * stops being sampled behind its first solid sample, where the transmittance is exactly 0).  0 = automatic (2..10, about five
- * rounds of tiles per pass); 1 = decode every in-sphere sample like the reference does.  Results are identical
+ * stops being sampled behind its first solid sample, where the transmittance is exactly 0).  0 = automatic (ten uniform
+ * ranges for large batches; otherwise 2-3 per-ray ranges steered by where each ray stopped in the previous iteration); 1 = decode every in-sphere sample like the reference does.  Results are identical
  * for every setting. */
 int dsp_batch_set_ray_passes(dsp_batch* b, int n_passes);
 /* The same with explicit depth-index boundaries: bounds[0] = 0 <= ... <= bounds[n_passes] = num_depth_samples. */

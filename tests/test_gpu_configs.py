@@ -195,7 +195,7 @@ def test_early_ray_termination_is_exact(eng):
     args = ([o["t_cam_obj_init"] for o in objs], [o["pts"] for o in objs], [o["rays"] for o in objs], [o["depth"] for o in objs])
     ref = None
     evaluated = {}
-    for n_passes in (1, 2, 5, 10, 50):
+    for n_passes in (1, 0, 2, 5, 10, 50):      # 0 = automatic: per-ray ranges steered by the previous iteration's hits
         b = eng.batch(prm, *args, trace=True)
         b.set_ray_passes(n_passes)
         b.run()
@@ -216,4 +216,4 @@ def test_early_ray_termination_is_exact(eng):
             assert st["n_insphere_points"] == ref_v
         ref_v = st["n_insphere_points"]
     assert evaluated[50] < evaluated[5] < evaluated[2] < evaluated[1]
-    assert evaluated[5] < 0.85 * evaluated[1]
+    assert evaluated[5] < 0.85 * evaluated[1] and evaluated[0] < 0.85 * evaluated[1]
