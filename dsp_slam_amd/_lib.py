@@ -36,7 +36,7 @@ class GnParams(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("n_fwd_points", C.c_double), ("n_jac_points", C.c_double), ("ms_total", C.c_double),
                 ("ms_mlp_fwd", C.c_double), ("ms_mlp_jac", C.c_double),
-                ("n_mlp_fwd_launches", C.c_int32), ("n_mlp_jac_launches", C.c_int32), ("n_insphere_points", C.c_double)]
+                ("n_mlp_fwd_launches", C.c_int32), ("n_mlp_jac_launches", C.c_int32), ("n_insphere_points", C.c_double), ("n_render_rows", C.c_double)]
 
 
 class DspError(RuntimeError):
@@ -68,6 +68,7 @@ SYMBOLS = [
     ("dsp_batch_stats", C.c_int, [_VP, C.POINTER(Stats)]),
     ("dsp_batch_set_ray_passes", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_set_ray_pass_bounds", C.c_int, [_VP, c_i32p, C.c_int]),
+    ("dsp_batch_set_mask_reuse", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_enable_trace", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_trace", C.c_int, [_VP, C.c_int32, c_f32p, c_f32p, c_f32p, c_i64p, c_i64p, c_i64p, c_f32p, c_f32p, C.POINTER(C.c_uint32), c_f32p]),
     ("dsp_batch_destroy", None, [_VP]),

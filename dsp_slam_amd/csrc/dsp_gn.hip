@@ -241,19 +241,29 @@ void code_bias_host(const std::vector<float>& codew, const std::vector<float>& b
         }
 }
 
-MlpArgs make_mlp_args(const dsp_handle* h, bool bwd) {
+MlpArgs make_mlp_args(const dsp_handle* h, int mode) {   // mode: 0/1 forward, 2 forward+backward, 3 backward only (mlp_kernel)
     MlpArgs a;
     memset(&a, 0, sizeof a);
-    a.wstream = h->wstream.p;
     a.bias_tab = h->bias_tab.p;
     a.b_last = h->b_last;
     a.n_bias_rows = h->n_bias_rows;
     a.wlast_row = h->wlast_row;
     a.w0_row = h->w0_row;
-    a.n_fwd = h->n_fwd;
-    a.n_pass = bwd ? h->n_pass_all : h->n_fwd;
-    a.total_chunks = bwd ? h->chunks_all : h->chunks_fwd;
-    memcpy(a.pass, h->pass, sizeof a.pass);
+    a.seed_slot = h->n_fwd;        // mask slot of the last hidden layer (slot = layer index, layer 0 has slot 0)
+    if (mode == 3) {               // only the backward half of the stream and of the pass table
+        const int n_bwd = h->n_pass_all - h->n_fwd;
+        a.wstream = h->wstream.p + (size_t)h->chunks_fwd * (CHUNK_BYTES / 4);
+        a.n_fwd = 0;
+        a.n_pass = n_bwd;
+        a.total_chunks = h->chunks_all - h->chunks_fwd;
+        memcpy(a.pass, h->pass + h->n_fwd, n_bwd * sizeof(PassDesc));
+    } else {
+        a.wstream = h->wstream.p;
+        a.n_fwd = h->n_fwd;
+        a.n_pass = mode == 2 ? h->n_pass_all : h->n_fwd;
+        a.total_chunks = mode == 2 ? h->chunks_all : h->chunks_fwd;
+        memcpy(a.pass, h->pass, sizeof a.pass);
+    }
     return a;
 }
 
@@ -285,7 +295,7 @@ void run_decoder_points(dsp_handle* h, const float* codes, int64_t n_codes, cons
     HIP_TRY(hipMemcpyAsync(h->s_code.p, codes, (size_t)CODE_LEN * n_codes * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->s_tiles.p, tiles.data(), nt * sizeof(int4), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->s_ntiles.p, &nt, 4, hipMemcpyHostToDevice, h->stream));
-    MlpArgs a = make_mlp_args(h, bwd);
+    MlpArgs a = make_mlp_args(h, bwd ? 2 : 0);
     a.n_tiles = h->s_ntiles.p;
     a.tiles = h->s_tiles.p;
     a.pts = h->s_pts.p;
@@ -297,7 +307,7 @@ void run_decoder_points(dsp_handle* h, const float* codes, int64_t n_codes, cons
     a.out_grad = h->s_out.p;
     h->s_clk.ensure(4);
     a.clk = h->s_clk.p;
-    HIP_TRY(launch_mlp(bwd, a, std::min(nt, h->n_cu), h->stream));
+    HIP_TRY(launch_mlp(bwd ? 2 : 0, a, std::min(nt, h->n_cu), h->stream));
     if (!bwd) {
         HIP_TRY(hipMemcpyAsync(sdf_out, h->s_out.p, n_out * 4, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
@@ -331,6 +341,8 @@ struct dsp_batch {
     DevBuf<unsigned long long> raymask;
     DevBuf<int> raycnt, rayoff, kcnt, koff, mcnt, pcnt, poff, plist;
     DevBuf<unsigned char> ray_alive, ray_hint, ray_plo;
+    DevBuf<unsigned short> maskbuf;   // relu masks of band samples, 512 B per sample (written by the forward passes)
+    int mask_reuse = -1;      // render rows backward-only from exported relu masks: -1 auto, 0 off, 1 on (dsp_batch_set_mask_reuse)
     int n_ray_passes = 0;     // front-to-back forward passes per iteration (0 = pick from the batch size)
     std::vector<int> pass_bounds;   // optional explicit depth-index boundaries (n_passes + 1 entries, 0 .. D)
     int hint_margin = 2, hint_step = 8;   // adaptive passes: pass 0 = [0, hint + margin), middle pass = next `step` indices
@@ -418,6 +430,7 @@ dsp_batch* batch_build(dsp_handle* h, const dsp_gn_params* prm, int B, const int
         b->kcnt.alloc(b->sum_rays); b->koff.alloc(b->sum_rays); b->mcnt.alloc(b->sum_rays);
         b->pcnt.alloc(b->sum_rays); b->poff.alloc(b->sum_rays); b->plist.alloc(cap_s); b->ray_alive.alloc(b->sum_rays);
         b->ray_hint.alloc(b->sum_rays); b->ray_plo.alloc(b->sum_rays);
+        b->maskbuf.alloc((size_t)cap_s * 256);
         b->ray_res.alloc(b->sum_rays);
         b->spts.alloc(cap_s); b->ssdf.alloc(cap_s); b->sdeds.alloc(cap_s);
         b->tiles_f.alloc(cap_s / TILE_PTS + B);
@@ -427,8 +440,8 @@ dsp_batch* batch_build(dsp_handle* h, const dsp_gn_params* prm, int B, const int
     b->jpts.alloc(cap_j); b->jaux.alloc(cap_j);
     b->jgrad.alloc((size_t)cap_j * GRAD_STRIDE);
     b->tiles_j.alloc(cap_j / TILE_PTS + 2 * B);
-    b->n_tiles.alloc(2);
-    b->counters.alloc(3);
+    b->n_tiles.alloc(4);
+    b->counters.alloc(4);
     b->partials.alloc((size_t)B * 2 * b->n_slices * 72 * 72);
     b->gsum.alloc((size_t)B * 2 * 72 * 72);
     b->cbias.alloc((size_t)B * 2 * WIDTH);
@@ -454,23 +467,47 @@ hipEvent_t next_event(dsp_batch* b, size_t& cursor) {
     return b->ev[cursor++];
 }
 
-void launch_decoder(dsp_batch* b, bool bwd, size_t& cursor) {
+bool use_mask_reuse(const dsp_batch* b) {
+    if (b->pose_only) return false;
+    if (b->mask_reuse >= 0) return b->mask_reuse != 0;
+    // not for latency-sized batches: with one or two objects every jacobian tile fits a single round over the CUs, so a
+    // second launch adds a round instead of saving a forward sweep (tools/gpu_reuse_probe.py, cfg2 objects:
+    // 1 object 38.1 ms on vs 32.3 off; 4 objects 42.1 obj/s vs 40.1; 8: 49.6 vs 45.5; 32: 49.4 vs 44.9)
+    return b->sum_pts / TILE_PTS >= b->h->n_cu / 4;
+}
+
+// what: 0 = forward pass over the current sample list (with mask reuse: relu masks of band samples exported), 1 = jacobian
+// launch, forward + backward (with mask reuse the surface points only, else surface points and render rows), 2 = jacobian
+// of the kept render rows, backward only from the exported masks
+void launch_decoder(dsp_batch* b, int what, size_t& cursor) {
     dsp_handle* h = b->h;
-    MlpArgs a = make_mlp_args(h, bwd);
-    a.n_tiles = b->n_tiles.p + (bwd ? 1 : 0);
-    a.tiles = bwd ? b->tiles_j.p : b->tiles_f.p;
-    a.pts = bwd ? b->jpts.p : b->spts.p;
-    a.index = bwd ? nullptr : b->plist.p;
+    const bool reuse = use_mask_reuse(b);
+    const int mode = what == 0 ? (reuse ? 1 : 0) : (what == 1 ? 2 : 3);
+    MlpArgs a = make_mlp_args(h, mode);
+    if (what == 0) {
+        a.n_tiles = b->n_tiles.p;
+        a.tiles = b->tiles_f.p;
+        a.pts = b->spts.p;
+        a.index = b->plist.p;
+    } else {
+        a.tiles = b->tiles_j.p;
+        a.pts = b->jpts.p;
+        a.n_tiles = (what == 1 && reuse) ? b->n_tiles.p + 2 : b->n_tiles.p + 1;     // [2] = surface tiles, [1] = surface + render tiles
+        a.tile_begin = what == 1 ? nullptr : b->n_tiles.p + 2;
+    }
     a.codes = reinterpret_cast<const float*>(reinterpret_cast<const char*>(b->st.p) + offsetof(ObjState, code));
     a.code_stride = sizeof(ObjState) / 4;
     a.code_bias = b->cbias.p;
     a.code_bias_stride = 2 * WIDTH;
     a.out_sdf = b->ssdf.p;
+    a.sdf_in = b->ssdf.p;
+    a.mask_buf = b->maskbuf.p;
+    a.th = b->prm.cut_off;
     a.out_grad = b->jgrad.p;
     hipEvent_t e0 = next_event(b, cursor), e1 = next_event(b, cursor);
-    b->ev_kind.push_back(bwd ? 1 : 0);
+    b->ev_kind.push_back(what == 0 ? 0 : 1);
     HIP_TRY(hipEventRecord(e0, h->stream));
-    HIP_TRY(launch_mlp(bwd, a, h->n_cu, h->stream));
+    HIP_TRY(launch_mlp(mode, a, h->n_cu, h->stream));
     HIP_TRY(hipEventRecord(e1, h->stream));
 }
 
@@ -520,7 +557,7 @@ void iteration_front(dsp_batch* b, size_t& cursor, bool do_render) {
             launch_scan_rays(b->oc.p, b->st.p, b->pcnt.p, b->poff.p, 2, B, s);
             launch_pass_write(b->oc.p, b->st.p, b->raymask.p, b->rayoff.p, b->ray_alive.p, b->poff.p, b->plist.p, ps, b->maxR, B, s);
             launch_build_tiles(b->oc.p, b->st.p, B, 2, b->tiles_f.p, b->n_tiles.p, b->counters.p, ps.pass == 0 ? 1 : 0, s);
-            launch_decoder(b, false, cursor);
+            launch_decoder(b, 0, cursor);
             if (!ps.last || ps.hint)
                 launch_pass_update(b->oc.p, b->st.p, b->raymask.p, b->rayoff.p, b->ray_alive.p, b->ssdf.p, b->prm.cut_off, ps, b->maxR, B, s);
         }
@@ -533,7 +570,8 @@ void iteration_front(dsp_batch* b, size_t& cursor, bool do_render) {
     }
     launch_surface(b->oc.p, b->st.p, b->pts.p, b->jpts.p, b->jaux.p, b->maxM, B, s);
     launch_build_tiles(b->oc.p, b->st.p, B, 1, b->tiles_j.p, b->n_tiles.p + 1, b->counters.p, 0, s);
-    launch_decoder(b, true, cursor);
+    launch_decoder(b, 1, cursor);
+    if (do_render && use_mask_reuse(b)) launch_decoder(b, 2, cursor);
 }
 
 void batch_run(dsp_batch* b) {
@@ -547,7 +585,7 @@ void batch_run(dsp_batch* b) {
     b->ev_kind.clear();
     hipEvent_t e_start = next_event(b, cursor);
     HIP_TRY(hipEventRecord(e_start, s));
-    HIP_TRY(hipMemsetAsync(b->counters.p, 0, 3 * sizeof(double), s));
+    HIP_TRY(hipMemsetAsync(b->counters.p, 0, 4 * sizeof(double), s));
     HIP_TRY(hipMemsetAsync(b->st.p, 0, (size_t)B * sizeof(ObjState), s));
     launch_init_state(b->st.p, b->t_in.p, b->have_codes ? b->codes_in.p : nullptr, b->scale_in.p, B, b->D, b->pose_only ? 1 : 0, s);
     if (b->pose_only) HIP_TRY(hipMemsetAsync(b->alive.p, 1, b->cap_j, s));
@@ -569,11 +607,13 @@ void batch_run(dsp_batch* b) {
     // stats
     dsp_stats st;
     memset(&st, 0, sizeof st);
-    double cnt[3];
+    double cnt[4];
     HIP_TRY(hipMemcpy(cnt, b->counters.p, sizeof cnt, hipMemcpyDeviceToHost));
     st.n_fwd_points = cnt[0];
-    st.n_jac_points = cnt[1];
+    const bool reuse = use_mask_reuse(b);
+    st.n_jac_points = reuse ? cnt[1] : cnt[1] + cnt[3];
     st.n_insphere_points = cnt[2];
+    st.n_render_rows = reuse ? cnt[3] : 0.0;
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, e_start, e_end));
     st.ms_total = ms;
@@ -635,7 +675,7 @@ void run_terms(dsp_handle* h, const float* pts_cam, int64_t n_pts, const float* 
     st.n_alive = -1;
     HIP_TRY(hipMemcpyAsync(b->st.p, &st, sizeof st, hipMemcpyHostToDevice, h->stream));
     if (render) HIP_TRY(hipMemsetAsync(b->ray_hint.p, b->D, b->sum_rays, h->stream));   // no history: decode whole rays in pass 0
-    HIP_TRY(hipMemsetAsync(b->counters.p, 0, 3 * sizeof(double), h->stream));
+    HIP_TRY(hipMemsetAsync(b->counters.p, 0, 4 * sizeof(double), h->stream));
     size_t cursor = 0;
     b->ev_kind.clear();
     (void)next_event(b.get(), cursor);
@@ -697,7 +737,7 @@ int dsp_debug_slabs(dsp_handle* h, const float* code, const float* pts, int n, f
         HIP_TRY(hipMemcpy(h->s_code.p, code, CODE_LEN * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(h->s_tiles.p, &tile, sizeof tile, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(h->s_ntiles.p, &nt, 4, hipMemcpyHostToDevice));
-        MlpArgs a = make_mlp_args(h, true);
+        MlpArgs a = make_mlp_args(h, 2);
         std::vector<float> cb(2 * WIDTH);
         code_bias_host(h->h_codew, h->h_b0, h->h_blat, code, cb.data());
         h->s_cbias.ensure(2 * WIDTH);
@@ -705,7 +745,7 @@ int dsp_debug_slabs(dsp_handle* h, const float* code, const float* pts, int n, f
         a.n_tiles = h->s_ntiles.p; a.tiles = h->s_tiles.p; a.pts = h->s_pts.p; a.codes = h->s_code.p; a.code_stride = CODE_LEN;
         a.code_bias = h->s_cbias.p; a.code_bias_stride = 2 * WIDTH;
         a.out_sdf = out.p; a.out_grad = out.p; a.dbg = dbg.p;
-        HIP_TRY(launch_mlp(true, a, 1, h->stream));
+        HIP_TRY(launch_mlp(2, a, 1, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
         HIP_TRY(hipMemcpy(slabs_out, dbg.p, nd * 4, hipMemcpyDeviceToHost));
         if (grad_out) HIP_TRY(hipMemcpy(grad_out, out.p, (size_t)n * GRAD_STRIDE * 4, hipMemcpyDeviceToHost));
@@ -852,6 +892,12 @@ int dsp_batch_set_ray_pass_bounds(dsp_batch* b, const int32_t* bounds, int n_pas
     for (int p = 0; p < n_passes; ++p) if (bounds[p + 1] < bounds[p]) return DSP_E_ARG;
     b->n_ray_passes = n_passes;
     b->pass_bounds.assign(bounds, bounds + n_passes + 1);
+    return DSP_OK;
+}
+
+int dsp_batch_set_mask_reuse(dsp_batch* b, int mode) {
+    if (!b || mode < -1 || mode > 1) return DSP_E_ARG;
+    b->mask_reuse = mode;
     return DSP_OK;
 }
 

@@ -40,7 +40,8 @@ struct MlpArgs {
     int total_chunks;           // chunks consumed per tile
     PassDesc pass[MAX_PASSES];
     // work list (device memory, produced on device)
-    const int* n_tiles;         // [1]
+    const int* n_tiles;         // [1] one past the last tile
+    const int* tile_begin;      // optional [1]: first tile (0 when null)
     const int4* tiles;          // [n_tiles] {first point, n points, object (code index), output offset added to the point index}
     const float4* pts;          // object-frame points (xyz, w unused)
     const int* index;           // forward kernel, optional: point i of a tile is pts[index[first + i]] and its sdf goes to
@@ -49,6 +50,10 @@ struct MlpArgs {
     int code_stride;            // in floats (multiple of 4)
     const float* code_bias;     // per object: [0..511] = W0[:, :64] code + b0, [512..1023] = W_lat[:, code cols] code + b_lat
     int code_bias_stride;       // in floats (multiple of 4)
+    unsigned short* mask_buf;   // MODE 1 writes / MODE 3 reads: [sample][lane group 4][layer 8][output group 8] relu bits (16 per word)
+    const float* sdf_in;        // MODE 3: sdf of the samples, as written by the forward launches
+    float th;                   // MODE 1: export masks of samples with |sdf| < th
+    int seed_slot;              // MODE 3: mask slot of the last hidden layer
     float* out_sdf;             // FWD: [n_points]
     float* out_grad;            // BWD: [n_points][GRAD_STRIDE]
     unsigned long long* clk;    // optional: block 0 writes {clock64, wall_clock64} at entry and exit (effective shader clock)
@@ -90,10 +95,10 @@ struct GnParamsDev {
 };
 
 // kernels_mlp / kernels_gn launchers
-size_t mlp_lds_bytes(bool bwd);
+size_t mlp_lds_bytes(int mode);
 void launch_code_bias(const float* codew, const float* b0, const float* blat, const float* codes, int code_stride, float* out, int n_obj, hipStream_t s);
 hipError_t mlp_prepare_device();
-hipError_t launch_mlp(bool bwd, const MlpArgs& args, int n_blocks, hipStream_t stream);
+hipError_t launch_mlp(int mode, const MlpArgs& args, int n_blocks, hipStream_t stream);   // mode: see mlp_kernel
 void launch_init_state(ObjState* st, const float* t, const float* codes, const float* scale, int B, int D, int pose_only, hipStream_t s);
 void launch_sample_count(const ObjConst* oc, ObjState* st, const float* rays, unsigned long long* m, int* c, int D, int maxR, int B, hipStream_t s);
 void launch_scan_rays(const ObjConst* oc, ObjState* st, const int* cnt, int* off, int which, int B, hipStream_t s);

@@ -295,32 +295,42 @@ __global__ __launch_bounds__(256) void k_build_tiles(const ObjConst* oc, const O
     __shared__ int base;
     if (threadIdx.x == 0) base = 0;
     __syncthreads();
-    double cnt = 0.0, vtot = 0.0;
-    for (int b = 0; b < n_obj; ++b) {
-        const ObjConst c = oc[b];
-        const ObjState& s = st[b];
-        const bool good = s.status == DSP_STATUS_GOOD;
-        const int b0 = base;
-        __syncthreads();
-        if (mode == 0 || mode == 2) {
-            const int n = good ? (mode == 0 ? s.V : s.P) : 0;
-            const int nt = (n + TILE_PTS - 1) / TILE_PTS;
-            for (int i = threadIdx.x; i < nt; i += 256)
-                tiles[b0 + i] = make_int4(c.samp_off + i * TILE_PTS, min(TILE_PTS, n - i * TILE_PTS), b, 0);
-            if (threadIdx.x == 0) { base = b0 + nt; cnt += n; if (good) vtot += s.V; }
-        } else {
-            const int n1 = good ? c.n_pts : 0;
-            const int n2 = good ? s.K : 0;
-            const int nt1 = (n1 + TILE_PTS - 1) / TILE_PTS, nt2 = (n2 + TILE_PTS - 1) / TILE_PTS;
-            for (int i = threadIdx.x; i < nt1; i += 256)
-                tiles[b0 + i] = make_int4(c.jsdf_off + i * TILE_PTS, min(TILE_PTS, n1 - i * TILE_PTS), b, 0);
-            for (int i = threadIdx.x; i < nt2; i += 256)
-                tiles[b0 + nt1 + i] = make_int4(c.jren_off + i * TILE_PTS, min(TILE_PTS, n2 - i * TILE_PTS), b, 0);
-            if (threadIdx.x == 0) { base = b0 + nt1 + nt2; cnt += n1 + n2; }
+    double cnt = 0.0, vtot = 0.0, rows = 0.0;
+    int n_surface_tiles = 0;
+    // mode 1 lists every object's surface tiles first and the render tiles after them, so that the two jacobian launches
+    // (forward+backward / backward-only) each take one contiguous range
+    for (int phase = 0; phase < (mode == 1 ? 2 : 1); ++phase) {
+        for (int b = 0; b < n_obj; ++b) {
+            const ObjConst c = oc[b];
+            const ObjState& s = st[b];
+            const bool good = s.status == DSP_STATUS_GOOD;
+            const int b0 = base;
+            __syncthreads();
+            if (mode != 1) {
+                const int n = good ? (mode == 0 ? s.V : s.P) : 0;
+                const int nt = (n + TILE_PTS - 1) / TILE_PTS;
+                for (int i = threadIdx.x; i < nt; i += 256)
+                    tiles[b0 + i] = make_int4(c.samp_off + i * TILE_PTS, min(TILE_PTS, n - i * TILE_PTS), b, 0);
+                if (threadIdx.x == 0) { base = b0 + nt; cnt += n; if (good) vtot += s.V; }
+            } else {
+                const int n = good ? (phase == 0 ? c.n_pts : s.K) : 0;
+                const int off = phase == 0 ? c.jsdf_off : c.jren_off;
+                const int nt = (n + TILE_PTS - 1) / TILE_PTS;
+                for (int i = threadIdx.x; i < nt; i += 256)
+                    tiles[b0 + i] = make_int4(off + i * TILE_PTS, min(TILE_PTS, n - i * TILE_PTS), b, 0);
+                if (threadIdx.x == 0) { base = b0 + nt; if (phase == 0) cnt += n; else rows += n; }
+            }
+            __syncthreads();
         }
-        __syncthreads();
+        if (phase == 0) n_surface_tiles = base;
     }
-    if (threadIdx.x == 0) { *n_tiles = base; counters[mode == 2 ? 0 : mode] += cnt; if (add_v) counters[2] += vtot; }
+    if (threadIdx.x == 0) {
+        n_tiles[0] = base;
+        if (mode == 1) n_tiles[1] = n_surface_tiles;
+        counters[mode == 2 ? 0 : mode] += cnt;
+        if (add_v) counters[2] += vtot;
+        if (mode == 1) counters[3] += rows;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -422,7 +432,9 @@ __global__ void k_render_write(const ObjConst* oc, const ObjState* st, const int
     for (int k = 0; k < n; ++k) {
         const float deds = sdeds[base + k];
         if (deds != 0.f) {
-            jpts[dst] = spts[base + k];
+            float4 p = spts[base + k];
+            p.w = __int_as_float(base + k);   // compact sample index: where the forward launch left this sample's sdf and relu masks
+            jpts[dst] = p;
             jaux[dst] = make_float2(deds, res);
             ++dst;
         }

@@ -78,8 +78,15 @@ __device__ __forceinline__ float relu1(float x) {
 
 #define FOR16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
 
-template <bool BWD, bool DBG>
+// MODE 0: forward only.  MODE 1: forward, relu masks kept and exported (with nothing else to do) for every sample whose
+// |sdf| < th -- the candidates of the render term.  MODE 2: forward + backward (input gradient).  MODE 3: backward only,
+// from the masks and sdf a MODE 1 launch exported for the same point and code (the render rows of the jacobian: their
+// forward pass is not repeated).
+template <int MODE, bool DBG>
 __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
+    constexpr bool BWD = MODE >= 2;        // runs the backward sweep
+    constexpr bool MASKS = MODE != 0;      // relu masks live in LDS
+    constexpr bool DOFWD = MODE != 3;      // runs the forward sweep
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -90,11 +97,12 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
     float* bias_l = reinterpret_cast<float*>(smem);
     float* cb_l = reinterpret_cast<float*>(smem + BIAS_BYTES);   // [0..511] layer-0 code bias, [512..1023] latent_in code bias
     unsigned short* mask_l = reinterpret_cast<unsigned short*>(smem + BIAS_BYTES + CODEBIAS_BYTES);
-    char* ring_ptr = smem + BIAS_BYTES + CODEBIAS_BYTES + (BWD ? MASK_BYTES : 0);
+    char* ring_ptr = smem + BIAS_BYTES + CODEBIAS_BYTES + (MASKS ? MASK_BYTES : 0);
     const unsigned ring0 = lds_addr(ring_ptr);
 
     const int n_tiles = *a.n_tiles;
-    if ((int)blockIdx.x >= n_tiles) return;
+    const int tile0 = a.tile_begin ? *a.tile_begin : 0;
+    if (tile0 + (int)blockIdx.x >= n_tiles) return;
     if (a.clk && blockIdx.x == 0 && tid == 0) { a.clk[0] = clock64(); a.clk[1] = wall_clock64(); }
     for (int i = tid; i < a.n_bias_rows * WIDTH; i += 256) bias_l[i] = a.bias_tab[i];
     __syncthreads();
@@ -140,17 +148,18 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
 #pragma unroll
     for (int i = 0; i < 32; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (int tile = tile0 + blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int4 td = a.tiles[tile];
         const int local = wave * WAVE_PTS + pl;
         const bool valid = local < td.y;
         const int pidx = td.x + (valid ? local : 0);
-        const int src = (!BWD && a.index) ? a.index[pidx] : pidx;
+        const int src = (MODE <= 1 && a.index) ? a.index[pidx] : pidx;
         float4 pt = a.pts[src];
         if (!valid) pt = make_float4(0.f, 0.f, 0.f, 0.f);
         // The shape code is the same for every point of the tile, so its contribution to layer 0 and to the latent_in
         // layer is a per-object bias vector (k_code_bias): stage both into LDS.  What is left of layer 0 is three
         // multiply-adds per row (W0[:, xyz] . p) -- done on the VALU below instead of 16 mostly-empty MFMA chunks.
+        if (DOFWD) {
         reinterpret_cast<float4*>(cb_l)[tid] = reinterpret_cast<const float4*>(a.code_bias + (size_t)td.z * a.code_bias_stride)[tid];
         __syncthreads();
         {
@@ -172,8 +181,9 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
                         sin_[16 * o + 4 * j + r] = relu1(pre);
                     }
                 }
-                if (BWD) mask_l[(0 * 8 + o) * 256 + tid] = (unsigned short)bits;
+                if (MASKS) mask_l[(0 * 8 + o) * 256 + tid] = (unsigned short)bits;
             }
+        }
         }
         float skipc[16];
         float skipx[3];
@@ -182,6 +192,42 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) skipc[i] = 0.f;
         skipx[0] = skipx[1] = skipx[2] = 0.f;
+
+        // seed of the backward sweep: d tanh * W_last, masked by the last hidden layer's relu
+        auto seed_backward = [&](int slot) {
+            const float* wl = bias_l + a.wlast_row * WIDTH + 4 * g;
+            const float d = 1.f - y * y;
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                const unsigned bits = mask_l[(slot * 8 + o) * 256 + tid];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(wl + 16 * (4 * o + j));
+                    sin_[16 * o + 4 * j + 0] = ((bits >> (4 * j + 0)) & 1u) ? d * w4.x : 0.f;
+                    sin_[16 * o + 4 * j + 1] = ((bits >> (4 * j + 1)) & 1u) ? d * w4.y : 0.f;
+                    sin_[16 * o + 4 * j + 2] = ((bits >> (4 * j + 2)) & 1u) ? d * w4.z : 0.f;
+                    sin_[16 * o + 4 * j + 3] = ((bits >> (4 * j + 3)) & 1u) ? d * w4.w : 0.f;
+                }
+            }
+        };
+        if (MODE == 3) {
+            // masks and sdf of this point as the forward (MODE 1) launch of the same iteration exported them; each lane
+            // only ever touches its own 64 mask words, so no barrier is needed
+            const int sidx = __float_as_int(pt.w);
+            const uint4* mp = reinterpret_cast<const uint4*>(a.mask_buf + ((size_t)sidx * 4 + g) * 64);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const uint4 w = valid ? mp[q] : make_uint4(0, 0, 0, 0);
+                const unsigned ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    mask_l[(8 * q + 2 * e + 0) * 256 + tid] = (unsigned short)(ww[e] & 0xffffu);
+                    mask_l[(8 * q + 2 * e + 1) * 256 + tid] = (unsigned short)(ww[e] >> 16);
+                }
+            }
+            y = valid ? a.sdf_in[sidx] : 0.f;
+            seed_backward(a.seed_slot);
+        }
 
         for (int ps = 0; ps < a.n_pass; ++ps) {
             const PassDesc pd = a.pass[ps];
@@ -293,7 +339,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
                             bits |= (v[k] > 0.f ? 1u : 0u) << k;
                             v[k] = relu1(v[k]);
                         }
-                        if (BWD) mask_l[(pd.mask_slot * 8 + og) * 256 + tid] = (unsigned short)bits;
+                        if (MASKS) mask_l[(pd.mask_slot * 8 + og) * 256 + tid] = (unsigned short)bits;
                     } else if (BWD && pd.mask_slot >= 0) {
                         if (pd.kind == 4) {
                             // latent_in layer: rows 445..447 / 448..511 of its input are the re-injected xyz / code, not
@@ -320,7 +366,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
 
-            if (ps == a.n_fwd - 1) {
+            if (DOFWD && ps == a.n_fwd - 1) {
                 // final layer (512 -> 1) on the VALU + tanh  (deep_sdf_decoder.py:93,107-108)
                 const float* wl = bias_l + a.wlast_row * WIDTH + 4 * g;
                 float part = 0.f;
@@ -337,22 +383,21 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
                 y = tanhf(part + a.b_last);
                 if (!BWD) {
                     if (valid && g == 0) a.out_sdf[a.index ? src : pidx + td.w] = y;
-                } else {
-                    // seed of the backward sweep: d tanh * W_last, masked by the last hidden relu
-                    const float d = 1.f - y * y;
-                    const int slot = pd.mask_slot;
+                    if (MODE == 1 && valid && y > -a.th && y < a.th) {
+                        // a candidate row of the render term (loss.py:88): export this lane's 64 mask words (8 layers x 8
+                        // output groups) so that the jacobian launch can run the backward sweep without a second forward
+                        uint4* mp = reinterpret_cast<uint4*>(a.mask_buf + ((size_t)src * 4 + g) * 64);
 #pragma unroll
-                    for (int o = 0; o < 8; ++o) {
-                        const unsigned bits = mask_l[(slot * 8 + o) * 256 + tid];
+                        for (int q = 0; q < 8; ++q) {
+                            unsigned ww[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const f32x4 w4 = *reinterpret_cast<const f32x4*>(wl + 16 * (4 * o + j));
-                            sin_[16 * o + 4 * j + 0] = ((bits >> (4 * j + 0)) & 1u) ? d * w4.x : 0.f;
-                            sin_[16 * o + 4 * j + 1] = ((bits >> (4 * j + 1)) & 1u) ? d * w4.y : 0.f;
-                            sin_[16 * o + 4 * j + 2] = ((bits >> (4 * j + 2)) & 1u) ? d * w4.z : 0.f;
-                            sin_[16 * o + 4 * j + 3] = ((bits >> (4 * j + 3)) & 1u) ? d * w4.w : 0.f;
+                            for (int e = 0; e < 4; ++e)
+                                ww[e] = (unsigned)mask_l[(8 * q + 2 * e + 0) * 256 + tid] | ((unsigned)mask_l[(8 * q + 2 * e + 1) * 256 + tid] << 16);
+                            mp[q] = make_uint4(ww[0], ww[1], ww[2], ww[3]);
                         }
                     }
+                } else {
+                    seed_backward(pd.mask_slot);
                 }
             }
         }
@@ -384,31 +429,38 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
     if (a.clk && blockIdx.x == 0 && tid == 0) { a.clk[2] = clock64(); a.clk[3] = wall_clock64(); }
 }
 
-template __global__ void mlp_kernel<false, false>(const MlpArgs);
-template __global__ void mlp_kernel<true, false>(const MlpArgs);
-template __global__ void mlp_kernel<true, true>(const MlpArgs);
+template __global__ void mlp_kernel<0, false>(const MlpArgs);
+template __global__ void mlp_kernel<1, false>(const MlpArgs);
+template __global__ void mlp_kernel<2, false>(const MlpArgs);
+template __global__ void mlp_kernel<2, true>(const MlpArgs);
+template __global__ void mlp_kernel<3, false>(const MlpArgs);
 
-size_t mlp_lds_bytes(bool bwd) { return BIAS_BYTES + CODEBIAS_BYTES + (bwd ? MASK_BYTES : 0) + NBUF * CHUNK_BYTES; }
+size_t mlp_lds_bytes(int mode) { return BIAS_BYTES + CODEBIAS_BYTES + (mode != 0 ? MASK_BYTES : 0) + NBUF * CHUNK_BYTES; }
 
 // Opt every kernel variant into > 64 KiB of dynamic LDS on the current device (called by dsp_create).
 hipError_t mlp_prepare_device() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_kernel<false, false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlp_lds_bytes(false));
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)mlp_lds_bytes(true));
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)mlp_lds_bytes(true));
+    const void* fns[5] = {reinterpret_cast<const void*>(&mlp_kernel<0, false>), reinterpret_cast<const void*>(&mlp_kernel<1, false>),
+                          reinterpret_cast<const void*>(&mlp_kernel<2, false>), reinterpret_cast<const void*>(&mlp_kernel<2, true>),
+                          reinterpret_cast<const void*>(&mlp_kernel<3, false>)};
+    const int modes[5] = {0, 1, 2, 2, 3};
+    for (int i = 0; i < 5; ++i) {
+        const hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlp_lds_bytes(modes[i]));
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
-hipError_t launch_mlp(bool bwd, const MlpArgs& args, int n_blocks, hipStream_t stream) {
+hipError_t launch_mlp(int mode, const MlpArgs& args, int n_blocks, hipStream_t stream) {
     if (args.dbg)
-        hipLaunchKernelGGL((mlp_kernel<true, true>), dim3(n_blocks), dim3(256), mlp_lds_bytes(true), stream, args);
-    else if (bwd)
-        hipLaunchKernelGGL((mlp_kernel<true, false>), dim3(n_blocks), dim3(256), mlp_lds_bytes(true), stream, args);
+        hipLaunchKernelGGL((mlp_kernel<2, true>), dim3(n_blocks), dim3(256), mlp_lds_bytes(2), stream, args);
+    else if (mode == 0)
+        hipLaunchKernelGGL((mlp_kernel<0, false>), dim3(n_blocks), dim3(256), mlp_lds_bytes(0), stream, args);
+    else if (mode == 1)
+        hipLaunchKernelGGL((mlp_kernel<1, false>), dim3(n_blocks), dim3(256), mlp_lds_bytes(1), stream, args);
+    else if (mode == 2)
+        hipLaunchKernelGGL((mlp_kernel<2, false>), dim3(n_blocks), dim3(256), mlp_lds_bytes(2), stream, args);
     else
-        hipLaunchKernelGGL((mlp_kernel<false, false>), dim3(n_blocks), dim3(256), mlp_lds_bytes(false), stream, args);
+        hipLaunchKernelGGL((mlp_kernel<3, false>), dim3(n_blocks), dim3(256), mlp_lds_bytes(3), stream, args);
     return hipGetLastError();
 }
 

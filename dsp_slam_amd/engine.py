@@ -70,6 +70,10 @@ class Batch(object):
         L.check(L.load().dsp_batch_set_ray_pass_bounds(self._h, L.ptr(bounds, L.c_i32p), bounds.shape[0] - 1), self.engine._h,
                 "dsp_batch_set_ray_pass_bounds")
 
+    def set_mask_reuse(self, mode):
+        """-1 = automatic, 0 = render rows share the surface points' forward+backward launch, 1 = backward-only from exported masks."""
+        L.check(L.load().dsp_batch_set_mask_reuse(self._h, int(mode)), self.engine._h, "dsp_batch_set_mask_reuse")
+
     def run(self):
         L.check(L.load().dsp_batch_run(self._h), self.engine._h, "dsp_batch_run")
 

@@ -69,13 +69,14 @@ typedef struct dsp_gn_params {
 /* Counters and device timings of the last run of a batch. */
 typedef struct dsp_stats {
     double n_fwd_points;         /* forward-only decoder points actually evaluated (<= sum of V: samples behind a solid sample are skipped) */
-    double n_jac_points;         /* sum of M + K (forward + input-gradient points) */
+    double n_jac_points;         /* points decoded forward + backward: sum of M (surface), plus K (render rows) without mask reuse */
     double ms_total;             /* HIP-event time of the whole run on the handle's stream */
     double ms_mlp_fwd;           /* summed time of the forward-only decoder kernel launches */
     double ms_mlp_jac;           /* summed time of the forward+gradient decoder kernel launches */
     int32_t n_mlp_fwd_launches;
     int32_t n_mlp_jac_launches;
     double n_insphere_points;    /* sum over iterations and objects of V, the in-sphere sample count the reference decodes */
+    double n_render_rows;        /* render rows that ran the backward sweep only (mask reuse on): sum of K, else 0 */
 } dsp_stats;
 
 /* ---- lifetime --------------------------------------------------------------------------------- */
@@ -141,6 +142,13 @@ int dsp_batch_stats(dsp_batch* b, dsp_stats* out);
 int dsp_batch_set_ray_passes(dsp_batch* b, int n_passes);
 /* The same with explicit depth-index boundaries: bounds[0] = 0 <= ... <= bounds[n_passes] = num_depth_samples. */
 int dsp_batch_set_ray_pass_bounds(dsp_batch* b, const int32_t* bounds, int n_passes);
+/* Render rows (kept ray samples) need the decoder's input gradient at points the forward launches of the same iteration
+ * already decoded.  With mask reuse on, those launches export the relu masks of band samples (|sdf| < cut_off, 512 B each)
+ * and the render rows run the backward sweep only, in a launch of their own after the surface points' forward + backward
+ * launch.  Off: surface points and render rows share one forward + backward launch.  -1 = automatic (on unless the
+ * batch is latency-sized -- fewer surface tiles than a quarter of the CUs -- where the extra launch costs more than the
+ * skipped forward), 0 = off, 1 = on.  Results are identical for every setting. */
+int dsp_batch_set_mask_reuse(dsp_batch* b, int mode);
 /* Record per-iteration traces during the following runs (testing; costs ~21 KB per object-iteration). */
 int dsp_batch_enable_trace(dsp_batch* b, int on);
 /* Per-iteration trace of the last run (testing): for iteration e < num_iterations and object i,

@@ -217,3 +217,31 @@ def test_early_ray_termination_is_exact(eng):
         ref_v = st["n_insphere_points"]
     assert evaluated[50] < evaluated[5] < evaluated[2] < evaluated[1]
     assert evaluated[5] < 0.85 * evaluated[1] and evaluated[0] < 0.85 * evaluated[1]
+
+
+def test_mask_reuse_is_exact(eng):
+    """Render rows either share the surface points' forward+backward launch or run backward-only from the relu masks the
+    forward launches exported: every bit of every iteration (H, b, dx, sets, results) must agree, and the backward-only
+    launch must actually have run when asked for."""
+    prm = E.gn_params(num_iterations=4)
+    objs = synth.make_batch(3, first_seed=960, n_surface=500, n_background=150)
+    args = ([o["t_cam_obj_init"] for o in objs], [o["pts"] for o in objs], [o["rays"] for o in objs], [o["depth"] for o in objs])
+    out = {}
+    for mode in (0, 1):
+        for n_passes in (0, 10):
+            b = eng.batch(prm, *args, trace=True)
+            b.set_mask_reuse(mode)
+            b.set_ray_passes(n_passes)
+            b.run()
+            out[mode, n_passes] = (b.results(), [b.trace(e) for e in range(4)], b.stats())
+            b.close()
+    ref = out[0, 0]
+    assert ref[2]["n_render_rows"] == 0 and out[1, 0][2]["n_render_rows"] > 0
+    assert out[1, 0][2]["n_mlp_jac_launches"] == 2 * ref[2]["n_mlp_jac_launches"]
+    assert out[1, 0][2]["n_jac_points"] + out[1, 0][2]["n_render_rows"] == ref[2]["n_jac_points"]
+    for key, (res, tr, st) in out.items():
+        for a, c in zip(res, ref[0]):
+            assert np.array_equal(a, c), key
+        for ta, tc in zip(tr, ref[1]):
+            for k in ("H", "b", "dx", "V", "K", "set_sums"):
+                assert np.array_equal(ta[k], tc[k]), (key, k)

@@ -34,12 +34,13 @@ b = eng.batch(prm, [o["t_cam_obj_init"] for o in objs], [o["pts"] for o in objs]
 for rep in range(3):
     t0 = time.time(); b.run(); dt = time.time() - t0
     st = b.stats()
-    flops = st["n_fwd_points"] * 3.67104e6 + st["n_jac_points"] * 7.34208e6
+    jflops = st["n_jac_points"] * 7.34208e6 + st["n_render_rows"] * 3.67104e6
+    flops = st["n_fwd_points"] * 3.67104e6 + jflops
     print("cfg2 x%d: %.1f ms wall, %.2f obj/s; events total %.1f ms, mlp fwd %.1f ms (%d launches) jac %.1f ms (%d); "
           "V+K pts %.3g/%.3g; alg %.2f TFLOP -> %.1f TFLOP/s overall, fwd kernel %.1f TFLOP/s, jac kernel %.1f TFLOP/s" % (
               nobj, dt * 1e3, nobj / dt, st["ms_total"], st["ms_mlp_fwd"], st["n_mlp_fwd_launches"], st["ms_mlp_jac"], st["n_mlp_jac_launches"],
               st["n_fwd_points"], st["n_jac_points"], flops / 1e12, flops / dt / 1e12,
-              st["n_fwd_points"] * 3.67104e6 / (st["ms_mlp_fwd"] * 1e-3) / 1e12, st["n_jac_points"] * 7.34208e6 / (st["ms_mlp_jac"] * 1e-3) / 1e12), flush=True)
+              st["n_fwd_points"] * 3.67104e6 / (st["ms_mlp_fwd"] * 1e-3) / 1e12, jflops / (st["ms_mlp_jac"] * 1e-3) / 1e12), flush=True)
 t, c, l, s = b.results()
 print("status", s, "loss", l)
 for i, o in enumerate(objs[:4]):
