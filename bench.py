@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--objects-per-gpu", type=int, default=32)
+    ap.add_argument("--objects-per-gpu", type=int, default=64)   # BASELINE configs[2]: batches of 64 cfg2 objects saturate the matrix pipe
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency-runs", type=int, default=9)
     args = ap.parse_args()
@@ -121,6 +121,9 @@ def main():
         return
 
     value = world * B * args.steps / elapsed
+    # fabric bytes per decoded point from the last committed rocprofv3 --pmc pass (tools/rocpd_pmc.py, FETCH_SIZE x 2 on gfx950)
+    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    pmc = json.load(open(pmc_path)) if os.path.exists(pmc_path) else {}
     fwd_tflops = fwd_pts * F_FWD / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else 0.0
     # surface points run forward + backward; render rows only the backward sweep (masks come from the forward launches)
     jac_flop = jac_pts * F_JAC + ren_rows * (F_JAC - F_FWD)
@@ -147,13 +150,13 @@ def main():
         },
         "roofline": {
             "bound": "mfma",
-            "kernel": "mlp_kernel<false> (decoder forward, fp32 v_mfma_f32_16x16x4_f32)",
+            "kernel": "mlp_kernel<1,false> (decoder forward with relu-mask export, fp32 v_mfma_f32_16x16x4_f32)",
             "achieved": round(fwd_tflops, 2),
             "peak": PEAK_FP32_MFMA_TFLOPS,
             "unit": "TFLOP/s",
             "frac": round(fwd_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
-            "traffic": None,
-            "traffic_note": "PMC pass (profiles/r01_final_pmc.md): 1.46 GB/launch L2-fabric reads = Infinity-Cache-served weight re-reads, 133 GB/s; algorithmic 20 B/point",
+            "traffic": pmc.get("fwd_fetch_bytes_per_point", 0.0) * fwd_pts / max(n_fwd, 1) or None,
+            "traffic_note": pmc.get("note", "no PMC pass recorded (profiles/pmc_traffic.json missing)"),
             "avg_launch_ms": round(fwd_ms / max(n_fwd, 1), 4),
             "alg_flop_per_launch": round(fwd_pts * F_FWD / max(n_fwd, 1)),
             "fwd_points_evaluated_over_insphere": round(fwd_pts / max(insphere_pts, 1.0), 4),

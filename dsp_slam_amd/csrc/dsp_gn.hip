@@ -66,6 +66,13 @@ struct dsp_handle {
     DevBuf<int4> s_tiles;
     DevBuf<int> s_ntiles;
     DevBuf<unsigned long long> s_clk;
+    // mesh extraction: case table, scan scratch and the last extracted mesh (device resident until fetched)
+    DevBuf<McTables> mc_tab;
+    DevBuf<int2> mc_blocks;
+    DevBuf<long long> mc_totals;
+    DevBuf<float> mc_vol, mc_verts;
+    DevBuf<int> mc_vidmap, mc_faces;
+    int64_t mesh_nv = -1, mesh_nf = -1;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -267,22 +274,17 @@ MlpArgs make_mlp_args(const dsp_handle* h, int mode) {   // mode: 0/1 forward, 2
     return a;
 }
 
-// n_codes objects x the same n points (object frame): forward or forward+gradient.  Output row = code * n + point.
-void run_decoder_points(dsp_handle* h, const float* codes, int64_t n_codes, const float* pts, int64_t n, bool bwd, float* sdf_out,
-                        float* grad_out) {
-    if (n <= 0 || n_codes <= 0) return;
-    HIP_TRY(hipSetDevice(h->device));
+// n_codes objects x the same n points, already in h->s_pts (device): decoder forward or forward+gradient into h->s_out,
+// output row = code * n + point.  Asynchronous on h->stream.
+void decode_resident_points(dsp_handle* h, const float* codes, int64_t n_codes, int64_t n, bool bwd) {
     const int64_t ntile = (n + TILE_PTS - 1) / TILE_PTS;
     if (ntile * n_codes > (int64_t)1 << 30 || n * n_codes > (int64_t)1 << 31) throw std::invalid_argument("decode request too large");
     const int nt = (int)(ntile * n_codes);
-    std::vector<float4> p4((size_t)n);
-    for (int64_t i = 0; i < n; ++i) p4[i] = make_float4(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], 0.f);
     std::vector<int4> tiles(nt);
     for (int64_t c = 0; c < n_codes; ++c)
         for (int64_t i = 0; i < ntile; ++i)
             tiles[c * ntile + i] = make_int4((int)(i * TILE_PTS), (int)std::min<int64_t>(TILE_PTS, n - i * TILE_PTS), (int)c, (int)(c * n));
     const size_t n_out = (size_t)n * n_codes;
-    h->s_pts.ensure(n);
     h->s_code.ensure((size_t)CODE_LEN * n_codes);
     h->s_cbias.ensure((size_t)2 * WIDTH * n_codes);
     std::vector<float> cb((size_t)2 * WIDTH * n_codes);
@@ -291,10 +293,10 @@ void run_decoder_points(dsp_handle* h, const float* codes, int64_t n_codes, cons
     h->s_tiles.ensure(nt);
     h->s_ntiles.ensure(1);
     h->s_out.ensure(bwd ? n_out * GRAD_STRIDE : n_out);
-    HIP_TRY(hipMemcpyAsync(h->s_pts.p, p4.data(), n * sizeof(float4), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->s_code.p, codes, (size_t)CODE_LEN * n_codes * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->s_tiles.p, tiles.data(), nt * sizeof(int4), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->s_ntiles.p, &nt, 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));     // the staging vectors above go out of scope
     MlpArgs a = make_mlp_args(h, bwd ? 2 : 0);
     a.n_tiles = h->s_ntiles.p;
     a.tiles = h->s_tiles.p;
@@ -308,6 +310,19 @@ void run_decoder_points(dsp_handle* h, const float* codes, int64_t n_codes, cons
     h->s_clk.ensure(4);
     a.clk = h->s_clk.p;
     HIP_TRY(launch_mlp(bwd ? 2 : 0, a, std::min(nt, h->n_cu), h->stream));
+}
+
+// n_codes objects x the same n host points (object frame): forward or forward+gradient.  Output row = code * n + point.
+void run_decoder_points(dsp_handle* h, const float* codes, int64_t n_codes, const float* pts, int64_t n, bool bwd, float* sdf_out,
+                        float* grad_out) {
+    if (n <= 0 || n_codes <= 0) return;
+    HIP_TRY(hipSetDevice(h->device));
+    std::vector<float4> p4((size_t)n);
+    for (int64_t i = 0; i < n; ++i) p4[i] = make_float4(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], 0.f);
+    h->s_pts.ensure(n);
+    HIP_TRY(hipMemcpyAsync(h->s_pts.p, p4.data(), n * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+    decode_resident_points(h, codes, n_codes, n, bwd);
+    const size_t n_out = (size_t)n * n_codes;
     if (!bwd) {
         HIP_TRY(hipMemcpyAsync(sdf_out, h->s_out.p, n_out * 4, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
@@ -320,6 +335,35 @@ void run_decoder_points(dsp_handle* h, const float* codes, int64_t n_codes, cons
             if (sdf_out) sdf_out[i] = tmp[i * GRAD_STRIDE + 67];
         }
     }
+}
+
+// marching cubes over a device-resident volume; the mesh stays in h->mc_verts / mc_faces until dsp_mesh_fetch
+void extract_mesh_device(dsp_handle* h, const float* vol, int n0, int n1, int n2, float level, float spacing, float origin) {
+    if ((int64_t)n0 * n1 * n2 > ((int64_t)1 << 30)) throw std::invalid_argument("volume too large");
+    const int n_pts = n0 * n1 * n2;
+    if (!h->mc_tab.p) {
+        McTables t;
+        mc_build_tables(t);
+        h->mc_tab.alloc(1);
+        HIP_TRY(hipMemcpy(h->mc_tab.p, &t, sizeof t, hipMemcpyHostToDevice));
+    }
+    h->mc_blocks.ensure(mc_num_blocks(n_pts));
+    h->mc_totals.ensure(2);
+    h->mesh_nv = h->mesh_nf = -1;
+    HIP_TRY(launch_mc_count(vol, n0, n1, n2, level, h->mc_tab.p, h->mc_blocks.p, h->mc_totals.p, h->stream));
+    long long tot[2];
+    HIP_TRY(hipMemcpyAsync(tot, h->mc_totals.p, sizeof tot, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (tot[0] > ((long long)1 << 30) || tot[1] > ((long long)1 << 30)) throw std::invalid_argument("mesh too large");
+    h->mc_verts.ensure((size_t)std::max<long long>(tot[0], 1) * 3);
+    h->mc_faces.ensure((size_t)std::max<long long>(tot[1], 1) * 3);
+    h->mc_vidmap.ensure((size_t)n_pts * 3);
+    if (tot[0] > 0)
+        HIP_TRY(launch_mc_emit(vol, n0, n1, n2, level, h->mc_tab.p, h->mc_blocks.p, spacing, origin, h->mc_verts.p, h->mc_vidmap.p,
+                               h->mc_faces.p, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->mesh_nv = tot[0];
+    h->mesh_nf = tot[1];
 }
 
 }  // namespace
@@ -830,6 +874,57 @@ int dsp_decode_sdf(dsp_handle* h, const float* code, const float* pts, int64_t n
 int dsp_decode_sdf_multi(dsp_handle* h, const float* codes, int64_t n_codes, const float* pts, int64_t n, float* sdf_out) {
     if (!h || !codes || n_codes < 0 || n < 0 || (n > 0 && n_codes > 0 && (!pts || !sdf_out))) return DSP_E_ARG;
     return guarded(h, [&] { run_decoder_points(h, codes, n_codes, pts, n, false, sdf_out, nullptr); });
+}
+
+int dsp_extract_mesh(dsp_handle* h, const float* code, int32_t vol_dim, int64_t* n_vertices, int64_t* n_faces) {
+    if (!h || !code || vol_dim < 2 || vol_dim > 512 || !n_vertices || !n_faces) return DSP_E_ARG;
+    return guarded(h, [&] {
+        HIP_TRY(hipSetDevice(h->device));
+        const int64_t n = (int64_t)vol_dim * vol_dim * vol_dim;
+        const float voxel_size = (float)(2.0 / (vol_dim - 1));
+        h->s_pts.ensure(n);
+        HIP_TRY(launch_grid_points(h->s_pts.p, vol_dim, voxel_size, h->stream));
+        decode_resident_points(h, code, 1, n, false);
+        extract_mesh_device(h, h->s_out.p, vol_dim, vol_dim, vol_dim, 0.f, voxel_size, -1.f);
+        *n_vertices = h->mesh_nv;
+        *n_faces = h->mesh_nf;
+    });
+}
+
+int dsp_marching_cubes(dsp_handle* h, const float* volume, int32_t n0, int32_t n1, int32_t n2, float level, float spacing, float origin,
+                       int64_t* n_vertices, int64_t* n_faces) {
+    if (!h || !volume || n0 < 2 || n1 < 2 || n2 < 2 || !n_vertices || !n_faces) return DSP_E_ARG;
+    return guarded(h, [&] {
+        HIP_TRY(hipSetDevice(h->device));
+        const size_t n = (size_t)n0 * n1 * n2;
+        h->mc_vol.ensure(n);
+        HIP_TRY(hipMemcpyAsync(h->mc_vol.p, volume, n * 4, hipMemcpyHostToDevice, h->stream));
+        extract_mesh_device(h, h->mc_vol.p, n0, n1, n2, level, spacing, origin);
+        *n_vertices = h->mesh_nv;
+        *n_faces = h->mesh_nf;
+    });
+}
+
+int dsp_mesh_fetch(dsp_handle* h, float* vertices, int32_t* faces) {
+    if (!h) return DSP_E_ARG;
+    if (h->mesh_nv < 0) return DSP_E_STATE;
+    if ((h->mesh_nv > 0 && !vertices) || (h->mesh_nf > 0 && !faces)) return DSP_E_ARG;
+    return guarded(h, [&] {
+        HIP_TRY(hipSetDevice(h->device));
+        if (h->mesh_nv > 0) HIP_TRY(hipMemcpyAsync(vertices, h->mc_verts.p, (size_t)h->mesh_nv * 12, hipMemcpyDeviceToHost, h->stream));
+        if (h->mesh_nf > 0) HIP_TRY(hipMemcpyAsync(faces, h->mc_faces.p, (size_t)h->mesh_nf * 12, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    });
+}
+
+int dsp_debug_mc_table(uint8_t* n_tri, uint8_t* tri) {
+    if (!n_tri || !tri) return DSP_E_ARG;
+    return guarded(nullptr, [&] {
+        McTables t;
+        mc_build_tables(t);
+        memcpy(n_tri, t.n_tri, 256);
+        for (int c = 0; c < 256; ++c) memcpy(tri + c * 3 * MC_MAX_TRI, t.tri[c], 3 * MC_MAX_TRI);
+    });
 }
 
 int dsp_sdf_jacobian(dsp_handle* h, const float* code, const float* pts, int64_t n, float* sdf_out, float* grad_out) {

@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
+#include <stdexcept>
 
 namespace dsp {
 
@@ -131,5 +133,20 @@ void launch_solve(const ObjConst* oc, ObjState* st, const float* partials, doubl
                   float* trace, int B, hipStream_t s);
 void launch_inlier_filter(const ObjConst* oc, ObjState* st, const float* jgrad, unsigned char* alive, int maxM, int B, hipStream_t s);
 void launch_finalize(ObjState* st, const float* scale, int B, int pose_only, float* t, float* code, float* loss, int* status, hipStream_t s);
+
+// ---- mesh extraction (mesh_kernels.hip) ---------------------------------------------------------
+constexpr int MC_MAX_TRI = 5;
+struct McTables {                        // marching-cubes case table, generated on the host (mc_build_tables)
+    unsigned char n_tri[256];            // triangles of a cell whose corner-inside bits are the index
+    unsigned char tri[256][16];          // 3 cube-edge ids per triangle, 0xff padded
+    unsigned char edge_off[12][4];       // cube edge -> (offset of the owning grid point along axes 0, 1, 2; axis)
+};
+void mc_build_tables(McTables& t);
+int mc_num_blocks(int n_pts);
+hipError_t launch_grid_points(float4* pts, int n, float voxel_size, hipStream_t s);
+hipError_t launch_mc_count(const float* vol, int n0, int n1, int n2, float level, const McTables* tab, int2* block_sums, long long* totals,
+                           hipStream_t s);
+hipError_t launch_mc_emit(const float* vol, int n0, int n1, int n2, float level, const McTables* tab, const int2* block_off, float spacing,
+                          float origin, float* verts, int* vidmap, int* faces, hipStream_t s);
 
 }  // namespace dsp

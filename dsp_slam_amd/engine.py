@@ -3,6 +3,7 @@
 Everything numeric happens in the HIP library; there is no CPU or PyTorch fallback.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -116,6 +117,18 @@ class Batch(object):
             pass
 
 
+_last_engine = None
+
+
+def last_engine():
+    """The engine created last that is still alive (for module-level helpers of the reference API that take no decoder
+    argument, such as reconstruct.utils.convert_sdf_voxels_to_mesh)."""
+    e = _last_engine() if _last_engine is not None else None
+    if e is None or not e._h:
+        raise RuntimeError("no decoder is loaded on a GPU (get_decoder / config_decoder first)")
+    return e
+
+
 class Engine(object):
     """Owns a dsp_handle: packed decoder weights on one MI355X + a HIP stream."""
 
@@ -130,6 +143,8 @@ class Engine(object):
             raise L.DspError("dsp_create failed (%d): %s" % (rc, msg.decode() if msg else "?"))
         self.device = int(device)
         self.code_len = int(code_len)
+        global _last_engine
+        _last_engine = weakref.ref(self)
 
     # -- decoder ------------------------------------------------------------------------------------
     def decode_sdf(self, code, pts):
@@ -147,6 +162,31 @@ class Engine(object):
         L.check(L.load().dsp_decode_sdf_multi(self._h, L.ptr(codes), codes.shape[0], L.ptr(pts), pts.shape[0], L.ptr(out)),
                 self._h, "dsp_decode_sdf_multi")
         return out
+
+    # -- mesh extraction ---------------------------------------------------------------------------
+    def _fetch_mesh(self, nv, nf):
+        verts = np.zeros((nv.value, 3), np.float32)
+        faces = np.zeros((nf.value, 3), np.int32)
+        L.check(L.load().dsp_mesh_fetch(self._h, L.ptr(verts), L.ptr(faces, L.c_i32p)), self._h, "dsp_mesh_fetch")
+        return verts, faces
+
+    def extract_mesh(self, code, vol_dim):
+        """Grid decode + marching cubes on the device (the SDF volume never leaves HBM): vertices (V,3) float32 in the
+        decoder's [-1,1]^3 frame, faces (F,3) int32.  Empty when the surface does not cross the grid."""
+        code = L.f32(code).reshape(-1)[:L.CODE_LEN]
+        nv, nf = C.c_int64(0), C.c_int64(0)
+        L.check(L.load().dsp_extract_mesh(self._h, L.ptr(code), int(vol_dim), C.byref(nv), C.byref(nf)), self._h, "dsp_extract_mesh")
+        return self._fetch_mesh(nv, nf)
+
+    def marching_cubes(self, volume, level=0.0, spacing=1.0, origin=0.0):
+        """Marching cubes of a host volume on the device: vertices = index * spacing + origin."""
+        vol = L.f32(volume)
+        if vol.ndim != 3:
+            raise ValueError("volume must be 3-D")
+        nv, nf = C.c_int64(0), C.c_int64(0)
+        L.check(L.load().dsp_marching_cubes(self._h, L.ptr(vol), vol.shape[0], vol.shape[1], vol.shape[2], float(level), float(spacing),
+                                            float(origin), C.byref(nv), C.byref(nf)), self._h, "dsp_marching_cubes")
+        return self._fetch_mesh(nv, nf)
 
     def sdf_jacobian(self, code, pts):
         pts = L.f32(pts).reshape(-1, 3)

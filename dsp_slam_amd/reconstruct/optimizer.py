@@ -128,9 +128,11 @@ class MeshExtractor(object):
         return sdf.reshape(codes.shape[0], self.voxels_dim, self.voxels_dim, self.voxels_dim)
 
     def extract_mesh_from_code(self, code):
+        """Grid decode + marching cubes, both on the GPU without the volume leaving HBM (reference optimizer.py:214-223;
+        there: GPU decode, then scikit-image marching cubes on the CPU)."""
         start = get_time()
-        vertices, faces = convert_sdf_voxels_to_mesh(self.decode_grid(code))
-        vertices = vertices.astype("float32")
-        faces = faces.astype("int32")
+        vertices, faces = self.decoder.engine.extract_mesh(_f32(code)[:self.code_len], self.voxels_dim)
+        if vertices.shape[0] == 0:
+            raise ValueError("Surface level must be within volume data range.")   # what scikit-image raises in the reference
         print("Extract mesh takes %f seconds" % (get_time() - start))
         return ForceKeyErrorDict(vertices=vertices, faces=faces)

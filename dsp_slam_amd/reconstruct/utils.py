@@ -56,16 +56,19 @@ def create_voxel_grid(vol_dim=128):
     return (v * np.float32(voxel_size) + np.float32(-1.0)).astype(np.float32)
 
 
-def convert_sdf_voxels_to_mesh(sdf_volume):
-    """Marching cubes on the decoded grid (reference utils.py:119-140).  CPU / scikit-image, as in the reference."""
-    try:
-        import skimage.measure as measure
-    except ImportError as e:  # not in this image; the SDF grid itself comes from the GPU (MeshExtractor.decode_grid)
-        raise ImportError("extract_mesh_from_code needs scikit-image for marching cubes: %s" % e)
-    vol = np.asarray(sdf_volume, np.float32)
+def convert_sdf_voxels_to_mesh(sdf_volume, engine=None):
+    """Marching cubes (level 0) on a decoded (n,n,n) grid, vertices in the [-1,1]^3 frame (reference utils.py:119-140).
+
+    The reference calls scikit-image's marching_cubes_lewiner on the CPU; here it runs on the GPU (dsp_marching_cubes) with a
+    generated classic case table: same vertices (one per sign-changing grid edge, linearly interpolated), triangulation may
+    differ from Lewiner's inside ambiguous cells, vertex/face order differs.  `engine`: the dsp_slam_amd Engine to run on
+    (default: the engine created last, i.e. of the decoder loaded last)."""
+    vol = np.ascontiguousarray(np.asarray(sdf_volume, np.float32))
+    if not (vol.min() <= 0.0 <= vol.max()):
+        raise ValueError("Surface level must be within volume data range.")      # scikit-image's error for an empty surface
+    if engine is None:
+        from dsp_slam_amd.engine import last_engine
+        engine = last_engine()
     n = vol.shape[0]
-    voxel_size = 2.0 / (n - 1)
-    mc = getattr(measure, "marching_cubes_lewiner", None) or measure.marching_cubes
-    verts, faces, _, _ = mc(vol, level=0.0, spacing=[voxel_size] * 3)
-    verts = verts + np.array([-1.0, -1.0, -1.0])
+    verts, faces = engine.marching_cubes(vol, level=0.0, spacing=np.float32(2.0 / (n - 1)), origin=-1.0)
     return verts, faces

@@ -1,0 +1,104 @@
+"""CPU-only: the marching-cubes oracle (oracle/mc_oracle.py) and the case table the library generates on the host.
+
+Parity is UNPINNED for this step: the reference delegates to scikit-image's marching_cubes_lewiner (reconstruct/utils.py:130),
+which is neither in /root/reference nor installed, and it holds no golden meshes.  What is pinned instead: the library's host-
+generated table equals the oracle's independent (numpy) construction, and the construction yields closed, consistently oriented
+2-manifolds whose vertices sit on the interpolated zero crossings."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import mc_oracle as M
+from dsp_slam_amd import _lib as L, synth
+
+
+def lib_table():
+    lib = L.load()
+    n_tri = np.zeros(256, np.uint8)
+    tri = np.zeros((256, 15), np.uint8)
+    u8p = C.POINTER(C.c_uint8)
+    L.check(lib.dsp_debug_mc_table(n_tri.ctypes.data_as(u8p), tri.ctypes.data_as(u8p)), None, "dsp_debug_mc_table")
+    return n_tri, tri
+
+
+def test_library_case_table_equals_oracle_construction():
+    n_tri, tri = lib_table()
+    o_n, o_tri = M.tables()
+    assert o_tri.shape == (256, 15)
+    assert np.array_equal(n_tri, o_n)
+    assert np.array_equal(tri, o_tri)
+
+
+def test_case_table_invariants():
+    n_tri, tab = M.tables()
+    assert n_tri[0] == 0 and n_tri[255] == 0 and n_tri.max() == 5
+    for cfg in range(256):
+        crossing = set()
+        for e in range(12):
+            off, axis = M.edge_owner(e)
+            c0 = M.corner_index(off)
+            o1 = list(off); o1[axis] = 1
+            c1 = M.corner_index(o1)
+            if ((cfg >> c0) & 1) != ((cfg >> c1) & 1):
+                crossing.add(e)
+        used = set(int(x) for x in tab[cfg, :3 * n_tri[cfg]])
+        assert used == crossing, cfg            # every sign-changing edge carries a vertex of the patch, and no other edge does
+        assert (tab[cfg, 3 * n_tri[cfg]:] == 255).all()
+        # a closed polygon set with v vertices in l loops has v - 2 l triangles
+        assert n_tri[cfg] == len(crossing) - 2 * len(M._loops(cfg, False))
+
+
+def grid(n):
+    g = np.linspace(-1, 1, n, dtype=np.float32)
+    return np.meshgrid(g, g, g, indexing="ij")
+
+
+def test_sphere_mesh_is_a_closed_outward_sphere():
+    n = 40
+    X, Y, Z = grid(n)
+    vol = (np.sqrt(X * X + Y * Y + Z * Z) - 0.7).astype(np.float32)
+    v, f = M.convert_sdf_voxels_to_mesh(vol)
+    boundary, nonmanifold, euler, volume = M.mesh_report(v, f)
+    assert boundary == 0 and nonmanifold == 0 and euler == 2
+    assert abs(volume - 4 / 3 * np.pi * 0.7 ** 3) < 0.02 * volume and volume > 0        # outward winding
+    assert np.abs(np.linalg.norm(v, axis=1) - 0.7).max() < 0.25 * (2.0 / (n - 1))
+    assert f.min() == 0 and f.max() == len(v) - 1 and len(np.unique(f)) == len(v)       # every vertex is used, shared between faces
+
+
+def test_rounded_box_mesh_closed_and_on_the_surface():
+    n = 48
+    X, Y, Z = grid(n)
+    pts = np.stack([X, Y, Z], -1).reshape(-1, 3)
+    code = np.zeros(64, np.float32)
+    vol = synth.rounded_box_sdf(pts, code[:3]).reshape(n, n, n).astype(np.float32)
+    v, f = M.convert_sdf_voxels_to_mesh(vol)
+    boundary, nonmanifold, euler, volume = M.mesh_report(v, f)
+    assert boundary == 0 and nonmanifold == 0 and euler == 2 and volume > 0
+    assert np.abs(synth.rounded_box_sdf(v, code[:3])).max() < 0.5 * (2.0 / (n - 1))
+
+
+def test_noise_volume_is_still_a_closed_manifold():
+    """Ambiguous faces and cells everywhere: the face rule must keep neighbouring cells consistent."""
+    rng = np.random.default_rng(5)
+    vol = rng.normal(size=(14, 11, 13)).astype(np.float32)
+    vol[0] = vol[-1] = 1; vol[:, 0] = vol[:, -1] = 1; vol[:, :, 0] = vol[:, :, -1] = 1      # surface stays inside the grid
+    v, f = M.marching_cubes(vol)
+    boundary, nonmanifold, _, _ = M.mesh_report(v, f)
+    assert len(f) > 1000 and boundary == 0 and nonmanifold == 0
+    # vertices lie on grid edges: exactly one non-integer coordinate (or none when a sample equals the level)
+    frac = (v != np.floor(v)).sum(1)
+    assert frac.max() <= 1
+
+
+def test_values_equal_to_the_level_and_empty_volumes():
+    vol = np.ones((5, 5, 5), np.float32)
+    v, f = M.marching_cubes(vol)
+    assert v.shape == (0, 3) and f.shape == (0, 3)
+    with pytest.raises(ValueError):
+        M.convert_sdf_voxels_to_mesh(vol)
+    vol[2, 2, 2] = -1.0
+    vol[2, 2, 3] = 0.0            # exactly the level: outside; the crossing from (2,2,2) sits AT the sample
+    v, f = M.marching_cubes(vol)
+    assert len(v) == 6 and len(f) == 8 and M.mesh_report(v, f)[:3] == (0, 0, 2)
+    assert np.array_equal(v[(v[:, 2] > 2)][0], np.array([2, 2, 3], np.float32))
