@@ -72,3 +72,37 @@ def convert_sdf_voxels_to_mesh(sdf_volume, engine=None):
     n = vol.shape[0]
     verts, faces = engine.marching_cubes(vol, level=0.0, spacing=np.float32(2.0 / (n - 1)), origin=-1.0)
     return verts, faces
+
+
+def write_mesh_to_ply(v, f, ply_filename_out):
+    """Binary little-endian PLY with `vertex` (x, y, z float) and `face` (list uchar int vertex_indices) elements -- the file
+    the reference writes through plyfile (utils.py:143-163, plyfile's default byte order on x86/AMD64 hosts); plyfile is
+    not needed here."""
+    v = np.ascontiguousarray(np.asarray(v, "<f4").reshape(-1, 3))
+    f = np.asarray(f, "<i4").reshape(-1, 3)
+    header = ("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n"
+              "element face %d\nproperty list uchar int vertex_indices\nend_header\n" % (v.shape[0], f.shape[0]))
+    faces = np.zeros(f.shape[0], dtype=[("n", "u1"), ("vertex_indices", "<i4", (3,))])
+    faces["n"] = 3
+    faces["vertex_indices"] = f
+    with open(ply_filename_out, "wb") as out:
+        out.write(header.encode("ascii"))
+        out.write(v.tobytes())
+        out.write(faces.tobytes())
+
+
+def read_mesh_from_ply(ply_filename):
+    """Inverse of write_mesh_to_ply (triangle meshes in the layout above only)."""
+    with open(ply_filename, "rb") as f:
+        data = f.read()
+    end = data.index(b"end_header\n") + len(b"end_header\n")
+    head = data[:end].decode("ascii").split("\n")
+    if head[0] != "ply" or head[1] != "format binary_little_endian 1.0":
+        raise ValueError("unsupported PLY flavour")
+    nv = int([h for h in head if h.startswith("element vertex")][0].split()[-1])
+    nf = int([h for h in head if h.startswith("element face")][0].split()[-1])
+    v = np.frombuffer(data, "<f4", nv * 3, end).reshape(nv, 3).copy()
+    faces = np.frombuffer(data, np.dtype([("n", "u1"), ("vertex_indices", "<i4", (3,))]), nf, end + nv * 12)
+    if nf and not (faces["n"] == 3).all():
+        raise ValueError("not a triangle mesh")
+    return v, faces["vertex_indices"].astype(np.int32)

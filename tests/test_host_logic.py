@@ -132,3 +132,24 @@ def test_map_objects_roundtrip(tmp_path):
     # the reference's own reader logic (extract_map_objects.py:46-63) accepts the file
     N = int(len(lines) / 3)
     assert N == 3 and np.asarray([float(x) for x in lines[1].strip().split(" ")]).reshape(3, 4).shape == (3, 4)
+
+
+def test_ply_writer_layout_and_roundtrip(mirror, tmp_path):
+    """write_mesh_to_ply emits the binary PLY the reference writes through plyfile (utils.py:143-163): fixed header,
+    12 B per vertex, 13 B per face."""
+    from reconstruct.utils import write_mesh_to_ply, read_mesh_from_ply
+    rng = np.random.default_rng(0)
+    v = rng.normal(size=(7, 3)).astype(np.float32)
+    f = rng.integers(0, 7, size=(5, 3)).astype(np.int32)
+    p = str(tmp_path / "m.ply")
+    write_mesh_to_ply(np.asfortranarray(v), f, p)
+    raw = open(p, "rb").read()
+    head = (b"ply\nformat binary_little_endian 1.0\nelement vertex 7\nproperty float x\nproperty float y\nproperty float z\n"
+            b"element face 5\nproperty list uchar int vertex_indices\nend_header\n")
+    assert raw.startswith(head) and len(raw) == len(head) + 7 * 12 + 5 * 13
+    assert raw[len(head) + 7 * 12] == 3
+    v2, f2 = read_mesh_from_ply(p)
+    assert np.array_equal(v2, v) and np.array_equal(f2, f)
+    write_mesh_to_ply(np.zeros((0, 3)), np.zeros((0, 3)), p)
+    v2, f2 = read_mesh_from_ply(p)
+    assert v2.shape == (0, 3) and f2.shape == (0, 3)
