@@ -69,6 +69,7 @@ SYMBOLS = [
     ("dsp_batch_set_ray_passes", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_set_ray_pass_bounds", C.c_int, [_VP, c_i32p, C.c_int]),
     ("dsp_batch_set_mask_reuse", C.c_int, [_VP, C.c_int]),
+    ("dsp_batch_set_split_rows", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_enable_trace", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_trace", C.c_int, [_VP, C.c_int32, c_f32p, c_f32p, c_f32p, c_i64p, c_i64p, c_i64p, c_f32p, c_f32p, C.POINTER(C.c_uint32), c_f32p]),
     ("dsp_batch_destroy", None, [_VP]),

@@ -54,7 +54,8 @@ struct dsp_handle {
     std::string err;
     int n_cu = 256;
     // packed decoder
-    DevBuf<float> wstream, bias_tab, codew, b0, blat;
+    DevBuf<float> wstream, wsplit, bias_tab, codew, b0, blat;
+    int split_off[4] = {0, 0, 0, 0}, split_len[4] = {0, 0, 0, 0}, split_len_fwd[4] = {0, 0, 0, 0};   // per-wave layout of wsplit (latency-form kernels)
     std::vector<float> h_codew, h_b0, h_blat;   // host copies for the single-shot decoder calls
     float b_last = 0.f;
     int wlast_row = 0, w0_row = 0;
@@ -232,6 +233,30 @@ void pack_decoder(dsp_handle* h, const dsp_decoder_desc* d) {
     memcpy(h->pass, pn.pass, sizeof h->pass);
     h->wstream.alloc(pn.stream.size());
     HIP_TRY(hipMemcpy(h->wstream.p, pn.stream.data(), pn.stream.size() * 4, hipMemcpyHostToDevice));
+    {   // latency form: wave w of a workgroup produces output groups 2w, 2w+1 of every pass and streams only their chunks;
+        // lay those out contiguously per wave, in consumption order (pass, group, chunk), over the forward + backward passes
+        const size_t cf = CHUNK_BYTES / 4;
+        std::vector<float> split;
+        split.reserve(pn.stream.size());
+        for (int w = 0; w < 4; ++w) {
+            h->split_off[w] = (int)(split.size() / cf);
+            for (int ps = 0; ps < pn.n_pass_all; ++ps) {
+                if (ps == pn.n_fwd) h->split_len_fwd[w] = (int)(split.size() / cf) - h->split_off[w];
+                for (int ol = 0; ol < 2; ++ol) {
+                    const int og = 2 * w + ol;
+                    if (og >= pn.pass[ps].nog) continue;
+                    for (int c = 0; c < pn.pass[ps].nchunks; ++c) {
+                        const size_t src = (size_t)(pn.pass[ps].chunk_base + og * pn.pass[ps].nchunks + c) * cf;
+                        split.insert(split.end(), pn.stream.begin() + src, pn.stream.begin() + src + cf);
+                    }
+                }
+            }
+            h->split_len[w] = (int)(split.size() / cf) - h->split_off[w];
+        }
+        if (split.size() != pn.stream.size()) throw std::logic_error("split weight stream does not cover the stream");
+        h->wsplit.alloc(split.size());
+        HIP_TRY(hipMemcpy(h->wsplit.p, split.data(), split.size() * 4, hipMemcpyHostToDevice));
+    }
     h->bias_tab.alloc(pn.bias.size());
     HIP_TRY(hipMemcpy(h->bias_tab.p, pn.bias.data(), pn.bias.size() * 4, hipMemcpyHostToDevice));
 }
@@ -257,6 +282,10 @@ MlpArgs make_mlp_args(const dsp_handle* h, int mode) {   // mode: 0/1 forward, 2
     a.wlast_row = h->wlast_row;
     a.w0_row = h->w0_row;
     a.seed_slot = h->n_fwd;        // mask slot of the last hidden layer (slot = layer index, layer 0 has slot 0)
+    a.wsplit = h->wsplit.p;
+    memcpy(a.split_off, h->split_off, sizeof a.split_off);
+    memcpy(a.split_len, h->split_len, sizeof a.split_len);
+    memcpy(a.split_len_fwd, h->split_len_fwd, sizeof a.split_len_fwd);
     if (mode == 3) {               // only the backward half of the stream and of the pass table
         const int n_bwd = h->n_pass_all - h->n_fwd;
         a.wstream = h->wstream.p + (size_t)h->chunks_fwd * (CHUNK_BYTES / 4);
@@ -386,6 +415,7 @@ struct dsp_batch {
     DevBuf<int> raycnt, rayoff, kcnt, koff, mcnt, pcnt, poff, plist;
     DevBuf<unsigned char> ray_alive, ray_hint, ray_plo;
     DevBuf<unsigned short> maskbuf;   // relu masks of band samples, 512 B per sample (written by the forward passes)
+    int split_rows = -1;      // jacobian launch in the latency form (16-point tiles, rows split over waves): -1 auto, 0 off, 1 on
     int mask_reuse = -1;      // render rows backward-only from exported relu masks: -1 auto, 0 off, 1 on (dsp_batch_set_mask_reuse)
     int n_ray_passes = 0;     // front-to-back forward passes per iteration (0 = pick from the batch size)
     std::vector<int> pass_bounds;   // optional explicit depth-index boundaries (n_passes + 1 entries, 0 .. D)
@@ -477,13 +507,13 @@ dsp_batch* batch_build(dsp_handle* h, const dsp_gn_params* prm, int B, const int
         b->maskbuf.alloc((size_t)cap_s * 256);
         b->ray_res.alloc(b->sum_rays);
         b->spts.alloc(cap_s); b->ssdf.alloc(cap_s); b->sdeds.alloc(cap_s);
-        b->tiles_f.alloc(cap_s / TILE_PTS + B);
+        b->tiles_f.alloc(cap_s / SPLIT_TILE_PTS + B);     // sized for the latency form's 16-point tiles
     } else {
         b->alive.alloc(cap_j);
     }
     b->jpts.alloc(cap_j); b->jaux.alloc(cap_j);
     b->jgrad.alloc((size_t)cap_j * GRAD_STRIDE);
-    b->tiles_j.alloc(cap_j / TILE_PTS + 2 * B);
+    b->tiles_j.alloc(cap_j / SPLIT_TILE_PTS + 2 * B);     // sized for the latency form's 16-point tiles
     b->n_tiles.alloc(4);
     b->counters.alloc(4);
     b->partials.alloc((size_t)B * 2 * b->n_slices * 72 * 72);
@@ -520,6 +550,26 @@ bool use_mask_reuse(const dsp_batch* b) {
     return b->sum_pts / TILE_PTS >= b->h->n_cu / 4;
 }
 
+// Jacobian launch in the latency form (mlp_split_kernel: 16-point tiles, each layer's rows split over the four waves, a tile
+// takes ~1/3 of a 64-point tile's time)?  Worth it only while the 16-point tiles still fit a round or two over the CUs.
+bool use_split_rows(const dsp_batch* b) {
+    if (use_mask_reuse(b)) return false;               // the backward-only launch has no latency form
+    if (b->split_rows >= 0) return b->split_rows != 0;
+    const double rows = (double)b->sum_pts + (b->pose_only ? 0.0 : 0.045 * (double)b->sum_rays * b->D);   // M + typical K
+    const double n_cu = b->h->n_cu;
+    const double rounds16 = std::ceil(rows / SPLIT_TILE_PTS / n_cu), rounds64 = std::ceil(rows / TILE_PTS / n_cu);
+    return 0.34 * rounds16 <= 0.8 * rounds64;
+}
+
+// The same question for the forward launches over ray samples (per pass roughly a third of the in-sphere samples).
+bool use_split_fwd(const dsp_batch* b) {
+    if (b->pose_only || use_mask_reuse(b)) return false;   // the mask-exporting forward has no latency form
+    if (b->split_rows >= 0) return b->split_rows != 0;
+    const double pts = 0.3 * (double)b->cap_s, n_cu = b->h->n_cu;
+    const double rounds16 = std::ceil(pts / SPLIT_TILE_PTS / n_cu), rounds64 = std::ceil(pts / TILE_PTS / n_cu);
+    return 0.30 * rounds16 <= 0.8 * rounds64;
+}
+
 // what: 0 = forward pass over the current sample list (with mask reuse: relu masks of band samples exported), 1 = jacobian
 // launch, forward + backward (with mask reuse the surface points only, else surface points and render rows), 2 = jacobian
 // of the kept render rows, backward only from the exported masks
@@ -551,7 +601,12 @@ void launch_decoder(dsp_batch* b, int what, size_t& cursor) {
     hipEvent_t e0 = next_event(b, cursor), e1 = next_event(b, cursor);
     b->ev_kind.push_back(what == 0 ? 0 : 1);
     HIP_TRY(hipEventRecord(e0, h->stream));
-    HIP_TRY(launch_mlp(mode, a, h->n_cu, h->stream));
+    if (what == 1 && use_split_rows(b))
+        HIP_TRY(launch_mlp_split(true, a, h->n_cu, h->stream));
+    else if (what == 0 && use_split_fwd(b))
+        HIP_TRY(launch_mlp_split(false, a, h->n_cu, h->stream));
+    else
+        HIP_TRY(launch_mlp(mode, a, h->n_cu, h->stream));
     HIP_TRY(hipEventRecord(e1, h->stream));
 }
 
@@ -600,7 +655,7 @@ void iteration_front(dsp_batch* b, size_t& cursor, bool do_render) {
             launch_pass_select(b->oc.p, b->st.p, b->raymask.p, b->rayoff.p, b->ray_alive.p, b->pcnt.p, ps, b->maxR, B, s);
             launch_scan_rays(b->oc.p, b->st.p, b->pcnt.p, b->poff.p, 2, B, s);
             launch_pass_write(b->oc.p, b->st.p, b->raymask.p, b->rayoff.p, b->ray_alive.p, b->poff.p, b->plist.p, ps, b->maxR, B, s);
-            launch_build_tiles(b->oc.p, b->st.p, B, 2, b->tiles_f.p, b->n_tiles.p, b->counters.p, ps.pass == 0 ? 1 : 0, s);
+            launch_build_tiles(b->oc.p, b->st.p, B, 2, b->tiles_f.p, b->n_tiles.p, b->counters.p, ps.pass == 0 ? 1 : 0, use_split_fwd(b) ? SPLIT_TILE_PTS : TILE_PTS, s);
             launch_decoder(b, 0, cursor);
             if (!ps.last || ps.hint)
                 launch_pass_update(b->oc.p, b->st.p, b->raymask.p, b->rayoff.p, b->ray_alive.p, b->ssdf.p, b->prm.cut_off, ps, b->maxR, B, s);
@@ -613,7 +668,7 @@ void iteration_front(dsp_batch* b, size_t& cursor, bool do_render) {
                             b->jpts.p, b->jaux.p, b->maxR, B, s);
     }
     launch_surface(b->oc.p, b->st.p, b->pts.p, b->jpts.p, b->jaux.p, b->maxM, B, s);
-    launch_build_tiles(b->oc.p, b->st.p, B, 1, b->tiles_j.p, b->n_tiles.p + 1, b->counters.p, 0, s);
+    launch_build_tiles(b->oc.p, b->st.p, B, 1, b->tiles_j.p, b->n_tiles.p + 1, b->counters.p, 0, use_split_rows(b) ? SPLIT_TILE_PTS : TILE_PTS, s);
     launch_decoder(b, 1, cursor);
     if (do_render && use_mask_reuse(b)) launch_decoder(b, 2, cursor);
 }
@@ -850,6 +905,7 @@ int dsp_create(const dsp_decoder_desc* decoder, int device, dsp_handle** out) {
         h->n_cu = prop.multiProcessorCount;
         HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         HIP_TRY(mlp_prepare_device());
+        HIP_TRY(mlp_split_prepare_device());
         pack_decoder(h, decoder);
     });
     if (rc != DSP_OK) { delete h; return rc; }
@@ -915,6 +971,11 @@ int dsp_mesh_fetch(dsp_handle* h, float* vertices, int32_t* faces) {
         if (h->mesh_nf > 0) HIP_TRY(hipMemcpyAsync(faces, h->mc_faces.p, (size_t)h->mesh_nf * 12, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
     });
+}
+
+int dsp_debug_solve_clocks(dsp_handle* h, uint64_t* out8) {
+    if (!h || !out8) return DSP_E_ARG;
+    return guarded(h, [&] { HIP_TRY(hipSetDevice(h->device)); HIP_TRY(debug_solve_clocks(reinterpret_cast<unsigned long long*>(out8))); });
 }
 
 int dsp_debug_mc_table(uint8_t* n_tri, uint8_t* tri) {
@@ -993,6 +1054,12 @@ int dsp_batch_set_ray_pass_bounds(dsp_batch* b, const int32_t* bounds, int n_pas
 int dsp_batch_set_mask_reuse(dsp_batch* b, int mode) {
     if (!b || mode < -1 || mode > 1) return DSP_E_ARG;
     b->mask_reuse = mode;
+    return DSP_OK;
+}
+
+int dsp_batch_set_split_rows(dsp_batch* b, int mode) {
+    if (!b || mode < -1 || mode > 1) return DSP_E_ARG;
+    b->split_rows = mode;
     return DSP_OK;
 }
 

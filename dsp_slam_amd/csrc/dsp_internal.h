@@ -14,6 +14,7 @@ constexpr int WIDTH = 512;          // hidden width == slab rows
 constexpr int CODE_LEN = 64;
 constexpr int IN_DIM = CODE_LEN + 3;
 constexpr int TILE_PTS = 64;        // points per workgroup tile (4 waves x 16)
+constexpr int SPLIT_TILE_PTS = 16;  // points per workgroup tile of the latency form (4 waves share them, mlp_split_kernel.hip)
 constexpr int WAVE_PTS = 16;
 constexpr int KSTEPS_PER_CHUNK = 16;            // 16 MFMA k-steps (64 slab rows) per weight chunk
 constexpr int CHUNK_BYTES = KSTEPS_PER_CHUNK * 64 * 16;   // 16 KiB: [kstep][lane] float4
@@ -58,6 +59,10 @@ struct MlpArgs {
     int seed_slot;              // MODE 3: mask slot of the last hidden layer
     float* out_sdf;             // FWD: [n_points]
     float* out_grad;            // BWD: [n_points][GRAD_STRIDE]
+    const float* wsplit;        // latency form (mlp_split_kernel): the same chunks laid out per wave (see pack_decoder)
+    int split_off[4];           //   first chunk of wave w's stream inside wsplit
+    int split_len[4];           //   chunks wave w consumes per tile (forward + backward)
+    int split_len_fwd[4];       //   ... of which the forward passes (a prefix of the wave's stream)
     unsigned long long* clk;    // optional: block 0 writes {clock64, wall_clock64} at entry and exit (effective shader clock)
     float* dbg;                 // development aid: [pass][wave][128][64] slab dump of tile 0 (nullptr = off)
 };
@@ -101,13 +106,16 @@ size_t mlp_lds_bytes(int mode);
 void launch_code_bias(const float* codew, const float* b0, const float* blat, const float* codes, int code_stride, float* out, int n_obj, hipStream_t s);
 hipError_t mlp_prepare_device();
 hipError_t launch_mlp(int mode, const MlpArgs& args, int n_blocks, hipStream_t stream);   // mode: see mlp_kernel
+hipError_t mlp_split_prepare_device();
+hipError_t launch_mlp_split(bool bwd, const MlpArgs& args, int n_blocks, hipStream_t stream);   // 16-point tiles; forward (+ backward)
 void launch_init_state(ObjState* st, const float* t, const float* codes, const float* scale, int B, int D, int pose_only, hipStream_t s);
 void launch_sample_count(const ObjConst* oc, ObjState* st, const float* rays, unsigned long long* m, int* c, int D, int maxR, int B, hipStream_t s);
 void launch_scan_rays(const ObjConst* oc, ObjState* st, const int* cnt, int* off, int which, int B, hipStream_t s);
 void launch_sample_write(const ObjConst* oc, const ObjState* st, const float* rays, const unsigned long long* m, const int* off, float4* spts,
                          float* ssdf, unsigned char* alive, int D, int maxR, int B, hipStream_t s);
 void launch_surface(const ObjConst* oc, const ObjState* st, const float* pts, float4* jpts, float2* jaux, int maxM, int B, hipStream_t s);
-void launch_build_tiles(const ObjConst* oc, const ObjState* st, int B, int mode, int4* tiles, int* n_tiles, double* counters, int add_v, hipStream_t s);
+void launch_build_tiles(const ObjConst* oc, const ObjState* st, int B, int mode, int4* tiles, int* n_tiles, double* counters, int add_v, int tile_pts,
+                        hipStream_t s);
 void launch_render_scan(const ObjConst* oc, ObjState* st, const unsigned long long* m, const int* off, const float* ssdf, const float* depth,
                         float* sdeds, float* ray_res, int* kcnt, int* mcnt, int D, float th, int maxR, int B, hipStream_t s);
 void launch_render_write(const ObjConst* oc, const ObjState* st, const int* raycnt, const int* rayoff, const int* koff, const float4* spts,
@@ -133,6 +141,8 @@ void launch_solve(const ObjConst* oc, ObjState* st, const float* partials, doubl
                   float* trace, int B, hipStream_t s);
 void launch_inlier_filter(const ObjConst* oc, ObjState* st, const float* jgrad, unsigned char* alive, int maxM, int B, hipStream_t s);
 void launch_finalize(ObjState* st, const float* scale, int B, int pose_only, float* t, float* code, float* loss, int* status, hipStream_t s);
+
+hipError_t debug_solve_clocks(unsigned long long* out8);
 
 // ---- mesh extraction (mesh_kernels.hip) ---------------------------------------------------------
 constexpr int MC_MAX_TRI = 5;

@@ -28,23 +28,52 @@ __device__ __forceinline__ float3 xform(const float* T, float x, float y, float 
 }
 
 __device__ bool inv4(const double* a, double* out) {   // Gauss-Jordan with partial pivoting
+    // Fully unrolled with compile-time indices only (row swaps are conditional register swaps): a run-time row index would
+    // put the 4x8 tableau into scratch memory, i.e. ~150 dependent HBM-latency accesses in a single-thread section
+    // (measured: 100 us of k_solve's 137 us).
     double m[4][8];
+#pragma unroll
     for (int i = 0; i < 4; ++i)
+#pragma unroll
         for (int j = 0; j < 4; ++j) { m[i][j] = a[4 * i + j]; m[i][4 + j] = (i == j) ? 1.0 : 0.0; }
+    bool ok = true;
+#pragma unroll
     for (int c = 0; c < 4; ++c) {
         int p = c;
-        for (int r = c + 1; r < 4; ++r) if (fabs(m[r][c]) > fabs(m[p][c])) p = r;
-        if (m[p][c] == 0.0) return false;
-        if (p != c) for (int j = 0; j < 8; ++j) { double t = m[c][j]; m[c][j] = m[p][j]; m[p][j] = t; }
+        double best = fabs(m[c][c]);
+#pragma unroll
+        for (int r = c + 1; r < 4; ++r) {
+            const double v = fabs(m[r][c]);
+            if (v > best) { best = v; p = r; }
+        }
+        if (best == 0.0) ok = false;
+#pragma unroll
+        for (int r = c + 1; r < 4; ++r) {
+            const bool sw = (p == r);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const double x = m[c][j], y = m[r][j];
+                m[c][j] = sw ? y : x;
+                m[r][j] = sw ? x : y;
+            }
+        }
         const double inv = 1.0 / m[c][c];
+#pragma unroll
         for (int j = 0; j < 8; ++j) m[c][j] *= inv;
-        for (int r = 0; r < 4; ++r) if (r != c) {
-            const double f = m[r][c];
-            for (int j = 0; j < 8; ++j) m[r][j] -= f * m[c][j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (r != c) {
+                const double f = m[r][c];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) m[r][j] -= f * m[c][j];
+            }
         }
     }
-    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) out[4 * i + j] = m[i][4 + j];
-    return true;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[4 * i + j] = m[i][4 + j];
+    return ok;
 }
 
 __device__ double det3(const double* r, int ld) {
@@ -289,7 +318,7 @@ __global__ void k_surface(const ObjConst* oc, const ObjState* st, const float* p
 // tile lists for the decoder kernels (single workgroup; counts live on the device)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_build_tiles(const ObjConst* oc, const ObjState* st, int n_obj, int mode, int4* tiles,
-                                                     int* n_tiles, double* counters, int add_v) {
+                                                     int* n_tiles, double* counters, int add_v, int tile_pts) {
     // mode 0: forward tiles over the V in-sphere samples; mode 1: jacobian tiles over M surface + K render points;
     // mode 2: forward tiles over the P samples selected for the current front-to-back pass (indexed through plist)
     __shared__ int base;
@@ -308,16 +337,16 @@ __global__ __launch_bounds__(256) void k_build_tiles(const ObjConst* oc, const O
             __syncthreads();
             if (mode != 1) {
                 const int n = good ? (mode == 0 ? s.V : s.P) : 0;
-                const int nt = (n + TILE_PTS - 1) / TILE_PTS;
+                const int nt = (n + tile_pts - 1) / tile_pts;
                 for (int i = threadIdx.x; i < nt; i += 256)
-                    tiles[b0 + i] = make_int4(c.samp_off + i * TILE_PTS, min(TILE_PTS, n - i * TILE_PTS), b, 0);
+                    tiles[b0 + i] = make_int4(c.samp_off + i * tile_pts, min(tile_pts, n - i * tile_pts), b, 0);
                 if (threadIdx.x == 0) { base = b0 + nt; cnt += n; if (good) vtot += s.V; }
             } else {
                 const int n = good ? (phase == 0 ? c.n_pts : s.K) : 0;
                 const int off = phase == 0 ? c.jsdf_off : c.jren_off;
-                const int nt = (n + TILE_PTS - 1) / TILE_PTS;
+                const int nt = (n + tile_pts - 1) / tile_pts;
                 for (int i = threadIdx.x; i < nt; i += 256)
-                    tiles[b0 + i] = make_int4(off + i * TILE_PTS, min(TILE_PTS, n - i * TILE_PTS), b, 0);
+                    tiles[b0 + i] = make_int4(off + i * tile_pts, min(tile_pts, n - i * tile_pts), b, 0);
                 if (threadIdx.x == 0) { base = b0 + nt; if (phase == 0) cnt += n; else rows += n; }
             }
             __syncthreads();
@@ -339,7 +368,7 @@ __global__ __launch_bounds__(256) void k_build_tiles(const ObjConst* oc, const O
 // One thread per ray, the 50-sample row kept in registers.  Pass 1 (count): occupancy o_j, T_l =
 // prod_{i<=l}(1-o_i), rendered depth d_u, suffix sums for de_do, keeps samples with |sdf| < th and
 // de_do > 1e-2; stores de_ds per compact sample (0 = dropped), d_u per ray and the kept count.
-__global__ void k_render_scan(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff,
+__global__ __launch_bounds__(256) void k_render_scan(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff,
                               const float* ssdf, const float* depth_fg, float* sdeds, float* ray_res, int* kcnt, int* mcnt,
                               int n_depth, float th) {
     const int b = blockIdx.y;
@@ -381,7 +410,7 @@ __global__ void k_render_scan(const ObjConst* oc, ObjState* st, const unsigned l
             du = __fadd_rn(du, __fmul_rn(s.depths[j], tp));
         }
     }
-    du = __fadd_rn(du, __fmul_rn(d_bg, T[n_depth - 1]));
+    du = __fadd_rn(du, __fmul_rn(d_bg, T[63]));   // T[63] == T[n_depth-1] exactly: o_j = 0 behind the last sample (static index keeps T in registers)
     const float obs = (r < c.n_fg) ? depth_fg[c.depth_off + r] : d_bg;   // optimizer.py:126
     float res = __fsub_rn(obs, du);
     res = fminf(fmaxf(res, -0.30f), 0.30f);                               // loss.py:139-140
@@ -389,13 +418,12 @@ __global__ void k_render_scan(const ObjConst* oc, ObjState* st, const unsigned l
     // de_do_k = sum_{l>=k} T_l / (1 - o_k); keep > 1e-2; de_ds = de_do * delta_d * (-1/(2 th))  (loss.py:118-130)
     const float delta_d = __fdiv_rn(__fsub_rn(s.depths[n_depth - 1], s.depths[0]), (float)(n_depth - 1));
     const float do_ds = __fdiv_rn(-1.f, __fmul_rn(2.f, th));
-    float suf[64];
-    {
+    {   // suffix sums of T, in place (T itself is not needed any more)
         float sacc = 0.f;
 #pragma unroll
         for (int j = 63; j >= 0; --j) {
             if (j < n_depth) sacc = __fadd_rn(sacc, T[j]);
-            suf[j] = sacc;
+            T[j] = sacc;
         }
     }
     int kept = 0, k = 0;
@@ -405,7 +433,7 @@ __global__ void k_render_scan(const ObjConst* oc, ObjState* st, const unsigned l
         if (j < n_depth && ((mask >> j) & 1ull)) {
             float deds = 0.f;
             if ((wg >> j) & 1ull) {
-                const float dedo = __fdiv_rn(suf[j], __fsub_rn(1.f, o[j]));
+                const float dedo = __fdiv_rn(T[j], __fsub_rn(1.f, o[j]));
                 if (dedo > 1e-2f) { deds = __fmul_rn(__fmul_rn(dedo, delta_d), do_ds); ++kept; khash += id_hash(((unsigned)r << 6) | (unsigned)j); }
             }
             sdeds[base + k] = deds;   // never exactly 0 for a kept sample (dedo > 0.01, delta_d > 0)
@@ -651,6 +679,8 @@ __device__ void rotation_prior(const ObjState& s, float* jrot, float& res) {
 
 constexpr int NSOLVE = 71;
 
+__device__ unsigned long long g_solve_clk[8];   // development aid: wall_clock64 (100 MHz) stamps of object 0's last k_solve
+
 // per-slice Gram partials -> one fp64 Gram matrix per (object, term); fixed summation order
 __global__ __launch_bounds__(256) void k_gram_reduce(const ObjState* st, const float* partials, int n_slices, double* gsum) {
     const int b = blockIdx.y, term = blockIdx.z;
@@ -663,10 +693,14 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const ObjState* st, const f
     gsum[((size_t)b * 2 + term) * (72 * 72) + e] = a;
 }
 
-__global__ __launch_bounds__(256) void k_solve(const ObjConst* oc, ObjState* st, const double* gsum, GnParamsDev prm, int iter,
+constexpr int SOLVE_THREADS = 1024;   // 16 waves: the elimination is instruction-issue bound, so it is spread over 12 row groups x 72 columns
+
+__global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, ObjState* st, const double* gsum, GnParamsDev prm, int iter,
                                                float* trace /*nullable*/, int n_obj) {
     __shared__ double A[NSOLVE][NSOLVE + 1];
     const int b = blockIdx.x, tid = threadIdx.x;
+    const bool stamp = (b == 0 && tid == 0);
+    if (stamp) g_solve_clk[0] = wall_clock64();
     const ObjConst c = oc[b];
     ObjState& s = st[b];
     if (s.status != DSP_STATUS_GOOD) return;
@@ -684,20 +718,37 @@ __global__ __launch_bounds__(256) void k_solve(const ObjConst* oc, ObjState* st,
         if (tid == 0) s.loss = prm.k1 * ren_loss + prm.k2 * sdf_loss;
         float jrot[7], res_rot;
         rotation_prior(s, jrot, res_rot);
+        // only entries 3 and 5 of the prior's jacobian are non-zero; selects instead of a run-time index keep it out of scratch
+        const float jrot3 = jrot[3], jrot5 = jrot[5];
+        auto jr = [=](int i) { return i == 3 ? jrot3 : (i == 5 ? jrot5 : 0.f); };
         const double w_s = (double)prm.k2 / (double)M, w_r = (double)prm.k1 / (double)K;
-        for (int e = tid; e < n * (n + 1); e += 256) {
-            const int i = e / (n + 1), j = e % (n + 1);
+        // thread (tr, tc) fills column tc of rows tr, tr+12, ...: all its Gram loads are issued before the first use
+        const int tr0 = tid / (NSOLVE + 1), j = tid % (NSOLVE + 1);
+        constexpr int RG = 12, RPT = (NSOLVE + RG - 1) / RG;
+        double g0[RPT], g1[RPT];
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const int i = tr0 + RG * q;
+            const bool live = tr0 < RG && i < n;
+            const int col = (j < n) ? j : 71;            // the augmented column is b = -J^T r~ (Gram column 71)
+            g0[q] = live ? G0[i * 72 + col] : 0.0;
+            g1[q] = live ? G1[i * 72 + col] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const int i = tr0 + RG * q;
+            if (!(tr0 < RG && i < n)) continue;
             double v;
             if (j < n) {
-                v = w_s * G0[i * 72 + j] + w_r * G1[i * 72 + j];                              // :161-168
+                v = w_s * g0[q] + w_r * g1[q];                                                 // :161-168
                 if (i >= pd && i == j) v += (double)prm.k3;                                    // :170
-                if (i < pd && j < pd) v += (double)prm.k4 * (double)jrot[i] * (double)jrot[j]; // :176,178
+                if (i < pd && j < pd) v += (double)prm.k4 * (double)jr(i) * (double)jr(j);       // :176,178
                 if (i < pd && i == j) v += 1.0;                                                // :183
                 if (i == pd - 1 && j == pd - 1) v += (double)prm.s_damp;                       // :184
             } else {
-                v = -(w_s * G0[i * 72 + 71] + w_r * G1[i * 72 + 71]);                          // b = -J^T r~
+                v = -(w_s * g0[q] + w_r * g1[q]);                                              // b = -J^T r~
                 if (i >= pd) v -= (double)prm.k3 * (double)s.code[i - pd];                     // :172
-                if (i < pd) v += (double)prm.k4 * (double)jrot[i] * (double)res_rot;           // :177,179 (sign as written)
+                if (i < pd) v += (double)prm.k4 * (double)jr(i) * (double)res_rot;             // :177,179 (sign as written)
             }
             A[i][j] = v;
         }
@@ -705,7 +756,7 @@ __global__ __launch_bounds__(256) void k_solve(const ObjConst* oc, ObjState* st,
         // pose-only (optimizer.py:68-72): H = J6^T J6 / M + 1e-2 I, b = -J6^T r / M with the raw residual
         const int Ma = (s.n_alive >= 0) ? s.n_alive : M;
         if (Ma == 0) { if (tid == 0) s.status = DSP_STATUS_NAN; return; }
-        for (int e = tid; e < n * (n + 1); e += 256) {
+        for (int e = tid; e < n * (n + 1); e += SOLVE_THREADS) {
             const int i = e / (n + 1), j = e % (n + 1);
             double v;
             if (j < n) { v = G0[i * 72 + j] / (double)Ma; if (i == j) v += 1e-2; }
@@ -714,10 +765,11 @@ __global__ __launch_bounds__(256) void k_solve(const ObjConst* oc, ObjState* st,
         }
     }
     __syncthreads();
+    if (stamp) { g_solve_clk[1] = wall_clock64(); g_solve_clk[5] = clock64(); }
     if (trace) {   // [iter][obj][71*71 H | 71 b | 71 dx | 16 t_oc | 64 code | V m K]
         float* tr = trace + ((size_t)iter * n_obj + b) * TRACE_STRIDE;
-        for (int e = tid; e < n * n; e += 256) tr[(e / n) * NSOLVE + (e % n)] = (float)A[e / n][e % n];
-        for (int e = tid; e < n; e += 256) tr[NSOLVE * NSOLVE + e] = (float)A[e][n];
+        for (int e = tid; e < n * n; e += SOLVE_THREADS) tr[(e / n) * NSOLVE + (e % n)] = (float)A[e / n][e % n];
+        for (int e = tid; e < n; e += SOLVE_THREADS) tr[NSOLVE * NSOLVE + e] = (float)A[e][n];
         if (tid < 16) tr[NSOLVE * NSOLVE + 2 * NSOLVE + tid] = s.t_oc[tid];
         if (tid < 64) tr[NSOLVE * NSOLVE + 2 * NSOLVE + 16 + tid] = s.code[tid];
         if (tid < 64) tr[5280 + tid] = s.depths[tid];
@@ -736,23 +788,84 @@ __global__ __launch_bounds__(256) void k_solve(const ObjConst* oc, ObjState* st,
     //    definite, so no pivoting is needed (the reference inverts H with fp32 LU, optimizer.py:186); eliminating above
     //    and below the diagonal leaves x_i = A[i][n] / A[i][i] with no serial back-substitution.  Column k itself is
     //    never rewritten (it is not read again), so one barrier per step suffices.
-    for (int k = 0; k < n; ++k) {
-        const double pv = A[k][k];
-        if (!(fabs(pv) > 0.0) || isnan(pv)) { if (tid == 0) s.status = DSP_STATUS_NAN; return; }
-        const int cols = n - k;   // columns k+1 .. n
-        for (int e = tid; e < (n - 1) * cols; e += 256) {
-            int r = e / cols;
-            if (r >= k) ++r;
-            const int j = k + 1 + e % cols;
-            A[r][j] -= (A[r][k] / pv) * A[k][j];
-        }
-        __syncthreads();
+    //    The matrix lives in REGISTERS during the elimination: thread (tr, tc) holds column tc of rows tr, tr+12, ... (6
+    //    doubles).  Per step only the pivot row and the pivot column travel through LDS (published by their owners, one
+    //    barrier per step).  Register indices must be compile-time, yet a 71-step unrolled body is 150 KB of code executed once
+    //    (instruction-fetch bound, 100 us), so the loop runs over groups of twelve pivots and ROTATES the register file by one
+    //    position per group: the pivot rows of the current group are always a[0], and a[i] is row 12*((kk+i) mod 6) + tr.
+    //    (History for one 71x71 solve: [H | b] in LDS with per-element division and one LDS round trip per element, 137 us;
+    //    registers + batched reads on 4 waves, 94 us, instruction-issue bound; 16 waves, this form.)
+    const int tr = tid / (NSOLVE + 1), tc = tid % (NSOLVE + 1);     // 12 row groups x 72 columns = 864 working threads
+    constexpr int ROW_GROUPS = 12, ROWS_PER_THREAD = (NSOLVE + ROW_GROUPS - 1) / ROW_GROUPS;
+    __shared__ double prow[ROW_GROUPS][NSOLVE + 1];
+    __shared__ __attribute__((aligned(16))) double pcol[ROW_GROUPS][ROW_GROUPS][ROWS_PER_THREAD];
+    __shared__ double diag[NSOLVE + 1];
+    const bool worker = tr < ROW_GROUPS && tc <= n;
+    double a[ROWS_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < ROWS_PER_THREAD; ++i) {
+        const int r = tr + ROW_GROUPS * i;
+        a[i] = (worker && r < n) ? A[r][tc] : 0.0;
     }
-    if (tid < n) A[tid][n] = A[tid][n] / A[tid][tid];
+    bool singular = false;
+#pragma unroll 1
+    for (int kk = 0; kk < ROWS_PER_THREAD; ++kk) {
+#pragma unroll
+        for (int t = 0; t < ROW_GROUPS; ++t) {
+            const int k = ROW_GROUPS * kk + t;
+            if (k < n) {                                                  // uniform
+                if (worker && tr == t) prow[t][tc] = a[0];                // row k = 3 kk + t is a[0] of row group t
+                if (worker && tc == k) {
+#pragma unroll
+                    for (int i = 0; i < ROWS_PER_THREAD; ++i) pcol[t][tr][i] = a[i];      // column k, in rotated order
+                }
+                __syncthreads();
+                const double pv = prow[t][k];
+                if (!(fabs(pv) > 0.0) || isnan(pv)) singular = true;      // uniform: every thread reads the same pivot
+                const double ipv = 1.0 / pv;
+                const bool col_live = worker && tc > k;
+                const double akj = col_live ? prow[t][tc] : 0.0;
+                // all column entries are read up front and unconditionally, and the row tests
+                // become selects: as `if (live) a[i] -= pc[i] * ...` hipcc emitted one branch + LDS round trip per element
+                // (24 serialised ~150-cycle waits per step -- that, not LDS bandwidth, was the 115 us)
+                const double2* pc2 = reinterpret_cast<const double2*>(pcol[t][tr < ROW_GROUPS ? tr : 0]);
+                double pc[ROWS_PER_THREAD];
+#pragma unroll
+                for (int i = 0; i < ROWS_PER_THREAD / 2; ++i) { const double2 v = pc2[i]; pc[2 * i] = v.x; pc[2 * i + 1] = v.y; }
+#pragma unroll
+                for (int i = 0; i < ROWS_PER_THREAD; ++i) {
+                    int pos = kk + i;
+                    if (pos >= ROWS_PER_THREAD) pos -= ROWS_PER_THREAD;
+                    const int r = ROW_GROUPS * pos + tr;
+                    const double f = (col_live && r < n && r != k) ? (pc[i] * ipv) * akj : 0.0;
+                    a[i] = a[i] - f;
+                }
+            }
+        }
+        const double first = a[0];
+#pragma unroll
+        for (int i = 0; i + 1 < ROWS_PER_THREAD; ++i) a[i] = a[i + 1];
+        a[ROWS_PER_THREAD - 1] = first;
+    }
+    // ROWS_PER_THREAD rotations later a[i] is row tr + 12 i again
+    if (singular) { if (tid == 0) s.status = DSP_STATUS_NAN; return; }
+    // x_i = b_i / H_ii after the elimination: the diagonal sits in thread (r % 3, r), the right-hand side in column n
+#pragma unroll
+    for (int i = 0; i < ROWS_PER_THREAD; ++i) {
+        const int r = tr + ROW_GROUPS * i;
+        if (worker && r < n && r == tc) diag[r] = a[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ROWS_PER_THREAD; ++i) {
+        const int r = tr + ROW_GROUPS * i;
+        if (worker && r < n && tc == n) A[r][n] = a[i] / diag[r];
+    }
+    if (stamp) { g_solve_clk[2] = wall_clock64(); g_solve_clk[6] = clock64(); }
     __syncthreads();
     if (trace) {
         float* tr = trace + ((size_t)iter * n_obj + b) * TRACE_STRIDE;
-        for (int e = tid; e < n; e += 256) tr[NSOLVE * NSOLVE + NSOLVE + e] = (float)A[e][n];
+        for (int e = tid; e < n; e += SOLVE_THREADS) tr[NSOLVE * NSOLVE + NSOLVE + e] = (float)A[e][n];
     }
     // 3. update (optimizer.py:187-192 / 73-74)
     if (!prm.pose_only) {
@@ -765,15 +878,21 @@ __global__ __launch_bounds__(256) void k_solve(const ObjConst* oc, ObjState* st,
         float dx[7], dT[16], nt[16];
         for (int i = 0; i < pd; ++i) dx[i] = (prm.pose_only ? 1.f : prm.lr) * (float)A[i][n];
         if (prm.pose_only) exp_se3_dev(dx, dT); else exp_sim3_dev(dx, dT);
+#pragma unroll
         for (int r = 0; r < 4; ++r)
+#pragma unroll
             for (int cc = 0; cc < 4; ++cc) {
-                float a = 0.f;
-                for (int k = 0; k < 4; ++k) a += dT[4 * r + k] * s.t_oc[4 * k + cc];
-                nt[4 * r + cc] = a;
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc += dT[4 * r + k] * s.t_oc[4 * k + cc];
+                nt[4 * r + cc] = acc;
             }
+#pragma unroll
         for (int i = 0; i < 16; ++i) s.t_oc[i] = nt[i];
         s.vsum = 0; s.ksum = 0;
+        if (stamp) g_solve_clk[3] = wall_clock64();
         if (!prm.pose_only) derive_iter_state(s, prm.n_depth);
+        if (stamp) g_solve_clk[4] = wall_clock64();
     }
 }
 
@@ -874,8 +993,9 @@ void launch_pass_update(const ObjConst* oc, const ObjState* st, const unsigned l
 void launch_surface(const ObjConst* oc, const ObjState* st, const float* pts, float4* jpts, float2* jaux, int maxM, int B, hipStream_t s) {
     hipLaunchKernelGGL(k_surface, GRID2(maxM, B), dim3(256), 0, s, oc, st, pts, jpts, jaux);
 }
-void launch_build_tiles(const ObjConst* oc, const ObjState* st, int B, int mode, int4* tiles, int* n_tiles, double* counters, int add_v, hipStream_t s) {
-    hipLaunchKernelGGL(k_build_tiles, dim3(1), dim3(256), 0, s, oc, st, B, mode, tiles, n_tiles, counters, add_v);
+void launch_build_tiles(const ObjConst* oc, const ObjState* st, int B, int mode, int4* tiles, int* n_tiles, double* counters, int add_v, int tile_pts,
+                        hipStream_t s) {
+    hipLaunchKernelGGL(k_build_tiles, dim3(1), dim3(256), 0, s, oc, st, B, mode, tiles, n_tiles, counters, add_v, tile_pts);
 }
 void launch_render_scan(const ObjConst* oc, ObjState* st, const unsigned long long* m, const int* off, const float* ssdf, const float* depth,
                         float* sdeds, float* ray_res, int* kcnt, int* mcnt, int D, float th, int maxR, int B, hipStream_t s) {
@@ -898,7 +1018,7 @@ void launch_jrows(const ObjConst* oc, const ObjState* st, const float4* jpts, co
 void launch_solve(const ObjConst* oc, ObjState* st, const float* partials, double* gsum, int n_slices, const GnParamsDev& prm, int iter,
                   float* trace, int B, hipStream_t s) {
     hipLaunchKernelGGL(k_gram_reduce, dim3((72 * 72 + 255) / 256, B, prm.pose_only ? 1 : 2), dim3(256), 0, s, st, partials, n_slices, gsum);
-    hipLaunchKernelGGL(k_solve, dim3(B), dim3(256), 0, s, oc, st, gsum, prm, iter, trace, B);
+    hipLaunchKernelGGL(k_solve, dim3(B), dim3(SOLVE_THREADS), 0, s, oc, st, gsum, prm, iter, trace, B);
 }
 void launch_inlier_filter(const ObjConst* oc, ObjState* st, const float* jgrad, unsigned char* alive, int maxM, int B, hipStream_t s) {
     hipLaunchKernelGGL(k_inlier_filter, GRID2(maxM, B), dim3(256), 0, s, oc, st, jgrad, alive);
@@ -907,5 +1027,7 @@ void launch_inlier_filter(const ObjConst* oc, ObjState* st, const float* jgrad, 
 void launch_finalize(ObjState* st, const float* scale, int B, int pose_only, float* t, float* code, float* loss, int* status, hipStream_t s) {
     hipLaunchKernelGGL(k_finalize, dim3((B + 63) / 64), dim3(64), 0, s, st, scale, B, pose_only, t, code, loss, status);
 }
+
+hipError_t debug_solve_clocks(unsigned long long* out8) { return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_solve_clk), 64); }
 
 }  // namespace dsp

@@ -14,67 +14,9 @@
 // ring filled by LDS-DMA (global_load_lds_dwordx4) with counted vmcnt waits and one s_barrier per
 // 16 KiB chunk (64 MFMAs per wave).  ReLU masks for the backward sweep live in LDS (32 KiB).
 #include "dsp_internal.h"
+#include "mlp_common.h"
 
 namespace dsp {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int NBUF = 6;                       // LDS ring depth (chunks)
-constexpr int BIAS_ROWS_MAX = 11;             // 7 hidden biases, final-layer weights, 3 first-layer xyz columns
-constexpr int BIAS_BYTES = BIAS_ROWS_MAX * WIDTH * 4;      // 22 KiB
-constexpr int CODEBIAS_BYTES = 2 * WIDTH * 4;              // per-object code contribution of layer 0 and of the latent_in layer
-constexpr int MASK_SLOTS = 8;
-constexpr int MASK_BYTES = MASK_SLOTS * 8 * 256 * 2;       // [slot][og][tid] u16 = 32 KiB
-constexpr int PREFETCH = 2;                   // A operands are read this many k-steps ahead of their MFMAs (<= 3 with 4 buffers)
-constexpr int GLDS_PER_CHUNK = 4;             // per wave: 4 x 1 KiB pieces of a 16 KiB chunk
-
-#define MFMA16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x4f32((A), (B), (C), 0, 0, 0)
-
-// LDS-DMA of one wave's quarter (4 KiB) of a weight chunk: four global_load_lds_dwordx4, each 64 lanes x 16 B from a
-// per-lane global address to LDS at M0 + lane*16.  The instruction's immediate offset moves BOTH the global source and
-// the LDS destination (measured: tools/probes/hw_probe.hip), so one address VGPR pair and one M0 value serve all four.
-// Invisible to hipcc's s_waitcnt bookkeeping by design: completion is counted by hand (vmcnt) below.
-__device__ __forceinline__ void glds_quarter(const void* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
-        "global_load_lds_dwordx4 %1, off offset:1024\n\t"
-        "global_load_lds_dwordx4 %1, off offset:2048\n\t"
-        "global_load_lds_dwordx4 %1, off offset:3072\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(gsrc), "s"(lds_dst)
-        : "memory");
-}
-
-// One 1 KiB piece of the quarter: PIECE selects the immediate offset (moves source and destination alike).
-template <int PIECE>
-__device__ __forceinline__ void glds_piece(const void* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off offset:%3\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(gsrc), "s"(lds_dst), "n"(PIECE * 1024)
-        : "memory");
-}
-
-__device__ __forceinline__ unsigned lds_addr(const void* p) {
-    return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
-}
-
-// relu as ONE instruction: fmaxf() on an MFMA result makes hipcc emit a canonicalising v_max before the real one
-__device__ __forceinline__ float relu1(float x) {
-    float r;
-    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
-    return r;
-}
 
 #define FOR16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
 

@@ -75,6 +75,10 @@ class Batch(object):
         """-1 = automatic, 0 = render rows share the surface points' forward+backward launch, 1 = backward-only from exported masks."""
         L.check(L.load().dsp_batch_set_mask_reuse(self._h, int(mode)), self.engine._h, "dsp_batch_set_mask_reuse")
 
+    def set_split_rows(self, mode):
+        """-1 = automatic, 0 = 64-point throughput tiles, 1 = 16-point latency tiles for the jacobian launch (when mask reuse is off)."""
+        L.check(L.load().dsp_batch_set_split_rows(self._h, int(mode)), self.engine._h, "dsp_batch_set_split_rows")
+
     def run(self):
         L.check(L.load().dsp_batch_run(self._h), self.engine._h, "dsp_batch_run")
 

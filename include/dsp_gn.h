@@ -165,6 +165,11 @@ int dsp_batch_set_ray_pass_bounds(dsp_batch* b, const int32_t* bounds, int n_pas
  * batch is latency-sized -- fewer surface tiles than a quarter of the CUs -- where the extra launch costs more than the
  * skipped forward), 0 = off, 1 = on.  Results are identical for every setting. */
 int dsp_batch_set_mask_reuse(dsp_batch* b, int mode);
+/* The jacobian launch has a latency form for one or two objects in flight (SLAM's per-detection calls): 16-point tiles whose
+ * layer rows are split over the four waves of a workgroup, ~3x shorter per tile than the 64-point throughput form, bit-identical
+ * results.  -1 = automatic (on while the 16-point tiles fit a round or two over the CUs and mask reuse is off), 0 = off, 1 = on
+ * (ignored while mask reuse is on). */
+int dsp_batch_set_split_rows(dsp_batch* b, int mode);
 /* Record per-iteration traces during the following runs (testing; costs ~21 KB per object-iteration). */
 int dsp_batch_enable_trace(dsp_batch* b, int on);
 /* Per-iteration trace of the last run (testing): for iteration e < num_iterations and object i,

@@ -245,3 +245,31 @@ def test_mask_reuse_is_exact(eng):
         for ta, tc in zip(tr, ref[1]):
             for k in ("H", "b", "dx", "V", "K", "set_sums"):
                 assert np.array_equal(ta[k], tc[k]), (key, k)
+
+
+def test_split_kernel_is_exact(eng, oracle_decoder):
+    """The latency form of the jacobian launch (16-point tiles, every layer's rows split over the four waves, per-wave weight
+    streams) must reproduce the throughput form bit for bit -- joint optimisation traces, results, and the pose-only path --
+    for ragged tile counts (tiles with 1..16 valid points)."""
+    prm = E.gn_params(num_iterations=3)
+    objs = [synth.make_object(970, n_surface=333, n_background=90), synth.make_object(971, n_surface=17, n_background=40),
+            synth.make_object(972, n_surface=512, n_background=0)]
+    args = ([o["t_cam_obj_init"] for o in objs], [o["pts"] for o in objs], [o["rays"] for o in objs], [o["depth"] for o in objs])
+    out = {}
+    for split in (0, 1):
+        b = eng.batch(prm, *args, trace=True)
+        b.set_mask_reuse(0)
+        b.set_split_rows(split)
+        b.run()
+        out[split] = (b.results(), [b.trace(e) for e in range(3)])
+        b.close()
+    for a, c in zip(out[1][0], out[0][0]):
+        assert np.array_equal(a, c)
+    for ta, tc in zip(out[1][1], out[0][1]):
+        for k in ("H", "b", "dx", "V", "K", "set_sums"):
+            assert np.array_equal(ta[k], tc[k]), k
+    assert (out[0][0][3] == 0).all()
+    # pose-only batches take the latency form automatically; compare with the golden pose-only result and with a decode
+    gp = golden("golden_pose_only.npz")
+    t = eng.estimate_pose_batch(E.gn_params(), [gp["t_co_se3"]], [float(gp["scale"])], [gp["pts"]], [gp["code"]])
+    assert np.abs(t[0] - gp["out"]).max() / np.abs(gp["out"]).max() < 1e-4
