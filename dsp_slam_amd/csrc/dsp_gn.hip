@@ -565,7 +565,7 @@ bool use_split_rows(const dsp_batch* b) {
 bool use_split_fwd(const dsp_batch* b) {
     if (b->pose_only || use_mask_reuse(b)) return false;   // the mask-exporting forward has no latency form
     if (b->split_rows >= 0) return b->split_rows != 0;
-    const double pts = 0.3 * (double)b->cap_s, n_cu = b->h->n_cu;
+    const double pts = 0.2 * (double)b->cap_s, n_cu = b->h->n_cu;   // tools/gpu_split_probe.py: 4 real-size objects 14.8 vs 17.3 ms forward; 1-2 cfg2 objects: 64-point tiles win
     const double rounds16 = std::ceil(pts / SPLIT_TILE_PTS / n_cu), rounds64 = std::ceil(pts / TILE_PTS / n_cu);
     return 0.30 * rounds16 <= 0.8 * rounds64;
 }
