@@ -76,6 +76,7 @@ SYMBOLS = [
     ("dsp_extract_mesh", C.c_int, [_VP, c_f32p, C.c_int32, c_i64p, c_i64p]),
     ("dsp_marching_cubes", C.c_int, [_VP, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, c_i64p, c_i64p]),
     ("dsp_mesh_fetch", C.c_int, [_VP, c_f32p, c_i32p]),
+    ("dsp_debug_split_layout", C.c_int, [C.POINTER(DecoderDesc), c_i32p, c_i32p, c_i64p]),
     ("dsp_debug_mc_table", C.c_int, [C.POINTER(C.c_uint8), C.POINTER(C.c_uint8)]),
     ("dsp_debug_code_bias", C.c_int, [C.POINTER(DecoderDesc), c_f32p, c_f32p]),
     ("dsp_debug_pack", C.c_int, [C.POINTER(DecoderDesc), c_f32p, c_i64p, c_f32p, c_i64p, c_i32p, c_i32p, c_f32p]),

@@ -218,6 +218,28 @@ void pack_decoder_host(PackedNet* h, const dsp_decoder_desc* d) {
     h->chunks_all = chunk;
 }
 
+// Latency form (mlp_split_kernel): wave w of a workgroup produces output groups 2w and 2w+1 of every pass and streams only
+// their chunks.  Returns the chunk ids of the throughput stream in the order the four waves consume them (wave 0's whole
+// stream, then wave 1's, ...; inside a wave: pass, own group, chunk -- forward passes first, then backward), and each wave's
+// offset / length / forward-prefix length in chunks.
+std::vector<int> split_chunk_order(const PackedNet& pn, int off[4], int len[4], int len_fwd[4]) {
+    std::vector<int> order;
+    for (int w = 0; w < 4; ++w) {
+        off[w] = (int)order.size();
+        len_fwd[w] = 0;
+        for (int ps = 0; ps < pn.n_pass_all; ++ps) {
+            if (ps == pn.n_fwd) len_fwd[w] = (int)order.size() - off[w];
+            for (int ol = 0; ol < 2; ++ol) {
+                const int og = 2 * w + ol;
+                if (og >= pn.pass[ps].nog) continue;
+                for (int c = 0; c < pn.pass[ps].nchunks; ++c) order.push_back(pn.pass[ps].chunk_base + og * pn.pass[ps].nchunks + c);
+            }
+        }
+        len[w] = (int)order.size() - off[w];
+    }
+    return order;
+}
+
 void pack_decoder(dsp_handle* h, const dsp_decoder_desc* d) {
     PackedNet pn;
     pack_decoder_host(&pn, d);
@@ -233,26 +255,12 @@ void pack_decoder(dsp_handle* h, const dsp_decoder_desc* d) {
     memcpy(h->pass, pn.pass, sizeof h->pass);
     h->wstream.alloc(pn.stream.size());
     HIP_TRY(hipMemcpy(h->wstream.p, pn.stream.data(), pn.stream.size() * 4, hipMemcpyHostToDevice));
-    {   // latency form: wave w of a workgroup produces output groups 2w, 2w+1 of every pass and streams only their chunks;
-        // lay those out contiguously per wave, in consumption order (pass, group, chunk), over the forward + backward passes
+    {   // latency form: per-wave copy of the stream (split_chunk_order)
         const size_t cf = CHUNK_BYTES / 4;
+        const std::vector<int> order = split_chunk_order(pn, h->split_off, h->split_len, h->split_len_fwd);
         std::vector<float> split;
         split.reserve(pn.stream.size());
-        for (int w = 0; w < 4; ++w) {
-            h->split_off[w] = (int)(split.size() / cf);
-            for (int ps = 0; ps < pn.n_pass_all; ++ps) {
-                if (ps == pn.n_fwd) h->split_len_fwd[w] = (int)(split.size() / cf) - h->split_off[w];
-                for (int ol = 0; ol < 2; ++ol) {
-                    const int og = 2 * w + ol;
-                    if (og >= pn.pass[ps].nog) continue;
-                    for (int c = 0; c < pn.pass[ps].nchunks; ++c) {
-                        const size_t src = (size_t)(pn.pass[ps].chunk_base + og * pn.pass[ps].nchunks + c) * cf;
-                        split.insert(split.end(), pn.stream.begin() + src, pn.stream.begin() + src + cf);
-                    }
-                }
-            }
-            h->split_len[w] = (int)(split.size() / cf) - h->split_off[w];
-        }
+        for (int chunk : order) split.insert(split.end(), pn.stream.begin() + (size_t)chunk * cf, pn.stream.begin() + (size_t)(chunk + 1) * cf);
         if (split.size() != pn.stream.size()) throw std::logic_error("split weight stream does not cover the stream");
         h->wsplit.alloc(split.size());
         HIP_TRY(hipMemcpy(h->wsplit.p, split.data(), split.size() * 4, hipMemcpyHostToDevice));
@@ -970,6 +978,24 @@ int dsp_mesh_fetch(dsp_handle* h, float* vertices, int32_t* faces) {
         if (h->mesh_nv > 0) HIP_TRY(hipMemcpyAsync(vertices, h->mc_verts.p, (size_t)h->mesh_nv * 12, hipMemcpyDeviceToHost, h->stream));
         if (h->mesh_nf > 0) HIP_TRY(hipMemcpyAsync(faces, h->mc_faces.p, (size_t)h->mesh_nf * 12, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
+    });
+}
+
+// host-only: the per-wave chunk order of the latency-form weight stream.  layout12 = off[4] | len[4] | len_fwd[4]; chunk_ids may be
+// null (size query: *n_chunks is set), else it receives *n_chunks ids.
+int dsp_debug_split_layout(const dsp_decoder_desc* decoder, int32_t* layout12, int32_t* chunk_ids, int64_t* n_chunks) {
+    if (!decoder || !layout12 || !n_chunks) return DSP_E_ARG;
+    return guarded(nullptr, [&] {
+        PackedNet pn;
+        pack_decoder_host(&pn, decoder);
+        int off[4], len[4], lf[4];
+        const std::vector<int> order = split_chunk_order(pn, off, len, lf);
+        for (int w = 0; w < 4; ++w) { layout12[w] = off[w]; layout12[4 + w] = len[w]; layout12[8 + w] = lf[w]; }
+        if (chunk_ids) {
+            if (*n_chunks < (int64_t)order.size()) throw std::invalid_argument("chunk_ids too small");
+            for (size_t i = 0; i < order.size(); ++i) chunk_ids[i] = order[i];
+        }
+        *n_chunks = (int64_t)order.size();
     });
 }
 

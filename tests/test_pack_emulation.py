@@ -54,3 +54,35 @@ def test_emulated_jacobian_matches_oracle(packed):
     assert np.abs(sdf - y).max() < 2e-6
     assert np.abs(grad - g).max() < 1e-5 * max(1.0, np.abs(g).max())
     assert np.abs(g[:, :64]).max() > 1e-4 and np.abs(g[:, 64:]).max() > 1e-4   # the check is not vacuous
+
+
+def test_split_stream_layout(packed):
+    """Latency-form kernel: every wave streams exactly the chunks of its two output groups, in consumption order (pass, group,
+    chunk), the four per-wave streams partition the throughput stream, and the forward part is a prefix of each."""
+    import ctypes as C
+    from dsp_slam_amd import _lib as L
+    dec, pk = packed
+    lib = L.load()
+    layout = np.zeros(12, np.int32)
+    n = C.c_int64(0)
+    L.check(lib.dsp_debug_split_layout(C.byref(pk["_holder"].desc), L.ptr(layout, L.c_i32p), None, C.byref(n)), None, "split(size)")
+    assert n.value == pk["chunks_all"]
+    ids = np.zeros(n.value, np.int32)
+    L.check(lib.dsp_debug_split_layout(C.byref(pk["_holder"].desc), L.ptr(layout, L.c_i32p), L.ptr(ids, L.c_i32p), C.byref(n)), None, "split")
+    off, ln, lf = layout[:4], layout[4:8], layout[8:]
+    assert sorted(ids.tolist()) == list(range(pk["chunks_all"]))            # a permutation: every chunk once
+    assert off[0] == 0 and all(off[w + 1] == off[w] + ln[w] for w in range(3)) and off[3] + ln[3] == pk["chunks_all"]
+    p = pk["passes"]
+    for w in range(4):
+        want, want_fwd = [], 0
+        for ps in range(pk["n_pass"]):
+            if ps == pk["n_fwd"]:
+                want_fwd = len(want)
+            nog, nchunks, chunk_base = int(p[ps, 0]), int(p[ps, 1]), int(p[ps, 6])
+            for og in (2 * w, 2 * w + 1):
+                if og < nog:
+                    want += [chunk_base + og * nchunks + c for c in range(nchunks)]
+        assert ids[off[w]:off[w] + ln[w]].tolist() == want
+        assert lf[w] == want_fwd and all(i < pk["chunks_fwd"] for i in want[:want_fwd])
+    # waves 0..2 carry two groups of every pass; wave 3 one group fewer in the two 445/448-row passes; wave 0 the first-layer backward
+    assert ln[0] > ln[1] == ln[2] > ln[3]
