@@ -18,6 +18,12 @@
 
 namespace dsp {
 
+// relu-mask bit of one pre-activation, shifted into `bits` (bits = 2 * bits + (x > 0)): v_cmp + v_addc instead of the
+// v_cmp / v_cndmask / v_lshl_or chain hipcc emits for `bits |= (x > 0) << k`.  Feed elements 15 down to 0 and element k ends at bit k.
+__device__ __forceinline__ void push_mask_bit(unsigned& bits, float x) {
+    asm volatile("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(x) : "vcc");
+}
+
 #define FOR16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
 
 // MODE 0: forward only.  MODE 1: forward, relu masks kept and exported (with nothing else to do) for every sample whose
@@ -108,7 +114,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
             const float* w0 = bias_l + a.w0_row * WIDTH + 4 * g;
 #pragma unroll
             for (int o = 0; o < 8; ++o) {
-                unsigned bits = 0;
+                float pre[16];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int row = 16 * (4 * o + j);
@@ -117,13 +123,16 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
                     const f32x4 wy = *reinterpret_cast<const f32x4*>(w0 + WIDTH + row);
                     const f32x4 wz = *reinterpret_cast<const f32x4*>(w0 + 2 * WIDTH + row);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float pre = fmaf(wz[r], pt.z, fmaf(wy[r], pt.y, fmaf(wx[r], pt.x, c0[r])));
-                        bits |= (pre > 0.f ? 1u : 0u) << (4 * j + r);
-                        sin_[16 * o + 4 * j + r] = relu1(pre);
-                    }
+                    for (int r = 0; r < 4; ++r) pre[4 * j + r] = fmaf(wz[r], pt.z, fmaf(wy[r], pt.y, fmaf(wx[r], pt.x, c0[r])));
                 }
-                if (MASKS) mask_l[(0 * 8 + o) * 256 + tid] = (unsigned short)bits;
+                if (MASKS) {
+                    unsigned bits = 0;
+#pragma unroll
+                    for (int k = 15; k >= 0; --k) push_mask_bit(bits, pre[k]);
+                    mask_l[(0 * 8 + o) * 256 + tid] = (unsigned short)bits;
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) sin_[16 * o + k] = relu1(pre[k]);
             }
         }
         }
@@ -275,13 +284,14 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
                         v[4 * j + 2] = acc[4 * og + j].z; v[4 * j + 3] = acc[4 * og + j].w;
                     }
                     if (pd.relu) {
-                        unsigned bits = 0;
+                        if (MASKS) {
+                            unsigned bits = 0;
 #pragma unroll
-                        for (int k = 0; k < 16; ++k) {
-                            bits |= (v[k] > 0.f ? 1u : 0u) << k;
-                            v[k] = relu1(v[k]);
+                            for (int k = 15; k >= 0; --k) push_mask_bit(bits, v[k]);
+                            mask_l[(pd.mask_slot * 8 + og) * 256 + tid] = (unsigned short)bits;
                         }
-                        if (MASKS) mask_l[(pd.mask_slot * 8 + og) * 256 + tid] = (unsigned short)bits;
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) v[k] = relu1(v[k]);
                     } else if (BWD && pd.mask_slot >= 0) {
                         if (pd.kind == 4) {
                             // latent_in layer: rows 445..447 / 448..511 of its input are the re-injected xyz / code, not
