@@ -17,8 +17,9 @@ transcribed:
     (outside -> inside corner) is joined to the next "leaving" edge counter-clockwise.  On an ambiguous face (two
     diagonal inside corners) this always cuts the two inside corners apart; the rule only looks at the face's own
     four signs, so the two cells sharing the face agree and the mesh is watertight;
-  * the face segments chain into closed loops; each loop is fan-triangulated; winding gives normals along +grad
-    (outward for a signed distance).
+  * the face segments chain into closed loops; each loop gets the triangulation with the fewest diagonals lying inside
+    a cube face (such a diagonal could coincide with the neighbouring cell's and give an edge shared by four triangles;
+    ties: lexicographically smallest triangle list); winding gives normals along +grad (outward for a signed distance).
 
 The mesh agrees with Lewiner's in vertex positions (same edge interpolation) and in every non-ambiguous cell; it can
 differ in how an ambiguous cell is triangulated.  Ordering is fixed so that an implementation can be compared
