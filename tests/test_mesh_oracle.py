@@ -102,3 +102,34 @@ def test_values_equal_to_the_level_and_empty_volumes():
     v, f = M.marching_cubes(vol)
     assert len(v) == 6 and len(f) == 8 and M.mesh_report(v, f)[:3] == (0, 0, 2)
     assert np.array_equal(v[(v[:, 2] > 2)][0], np.array([2, 2, 3], np.float32))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_smooth_fields_give_closed_consistent_surfaces(seed):
+    """Blobby implicit surfaces (sums of Gaussians, several components, saddles -> ambiguous cells): whenever the surface
+    stays inside the grid the mesh must be closed, 2-manifold and consistently oriented, and every vertex must sit on a
+    grid edge between samples of opposite sign."""
+    rng = np.random.default_rng(100 + seed)
+    n = 28
+    X, Y, Z = grid(n)
+    f = np.full(X.shape, 0.35, np.float64)
+    for _ in range(int(rng.integers(3, 9))):
+        c = rng.uniform(-0.55, 0.55, 3)
+        s = rng.uniform(0.12, 0.3)
+        f -= rng.uniform(0.5, 1.2) * np.exp(-((X - c[0]) ** 2 + (Y - c[1]) ** 2 + (Z - c[2]) ** 2) / (2 * s * s))
+    vol = f.astype(np.float32)
+    assert vol[0].min() > 0 and vol[-1].min() > 0 and vol[:, 0].min() > 0 and vol[:, -1].min() > 0 and vol[:, :, 0].min() > 0 and vol[:, :, -1].min() > 0
+    v, faces = M.marching_cubes(vol)
+    assert len(faces) > 50
+    boundary, nonmanifold, euler, volume = M.mesh_report(v, faces)
+    assert boundary == 0 and nonmanifold == 0 and euler % 2 == 0 and volume > 0
+    # each vertex: exactly one fractional coordinate, between an inside and an outside sample
+    lo = np.floor(v).astype(int)
+    frac_axis = np.argmax(v - lo, axis=1)
+    hi = lo.copy()
+    hi[np.arange(len(v)), frac_axis] += (v[np.arange(len(v)), frac_axis] != lo[np.arange(len(v)), frac_axis])
+    s0, s1 = vol[lo[:, 0], lo[:, 1], lo[:, 2]], vol[hi[:, 0], hi[:, 1], hi[:, 2]]
+    moved = (hi != lo).any(1)
+    assert ((s0[moved] < 0) != (s1[moved] < 0)).all()
+    # signed volume == number of inside samples x cell volume, up to the surface layer
+    assert abs(volume - (vol < 0).sum()) < 0.75 * len(v)
