@@ -10,6 +10,7 @@
 #include <cstring>
 #include <memory>
 #include <stdexcept>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -49,6 +50,7 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 }  // namespace
 
 struct dsp_handle {
+    std::mutex mu;             // every entry point that touches the handle's stream / scratch holds it (see guarded())
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
@@ -743,6 +745,10 @@ void batch_results(dsp_batch* b, float* t_out, float* codes_out, float* loss_out
 
 template <class F>
 int guarded(dsp_handle* h, F f) {
+    // one call at a time per handle: its HIP stream, scratch buffers and last mesh are shared state, and ctypes / pybind11
+    // callers release the GIL around these calls, so two Python threads can arrive here together
+    std::unique_lock<std::mutex> lock;
+    if (h) lock = std::unique_lock<std::mutex>(h->mu);
     try {
         f();
         return DSP_OK;

@@ -80,6 +80,8 @@ typedef struct dsp_stats {
 } dsp_stats;
 
 /* ---- lifetime --------------------------------------------------------------------------------- */
+/* Thread safety: calls on ONE handle (and on batches created from it) are serialised inside the library (one call at a time per handle);
+ * different handles are independent.  Callers that release the GIL around these calls (ctypes, pybind11) may therefore call from any thread. */
 int dsp_create(const dsp_decoder_desc* decoder, int device, dsp_handle** out);
 void dsp_destroy(dsp_handle* h);
 const char* dsp_last_error(const dsp_handle* h);   /* h may be NULL: error of the last failed dsp_create */
