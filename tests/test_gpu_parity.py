@@ -234,7 +234,8 @@ def test_reconstruct_redwood_each_iteration(eng, oracle_decoder):
     _check_iterations(oracle_decoder, obj, traces, oprm, cfg["optimizer"]["joint_optim"]["k4"])
 
 
-@pytest.mark.parametrize("name", ["golden_recon_small.npz", "golden_recon_cfg1.npz", "golden_recon_redwood.npz", "golden_recon_cfg2.npz"])
+@pytest.mark.parametrize("name", ["golden_recon_small.npz", "golden_recon_cfg1.npz", "golden_recon_redwood.npz", "golden_recon_freiburg.npz",
+                                  "golden_recon_cfg2.npz"])
 def test_reconstruct_end_to_end(eng, name):
     """All iterations chained, against the reference's final pose / code.  Tolerance: 1e-4 relative, or 10x the
     REFERENCE'S OWN movement when its input points move by one float32 ulp (golden ulp_*), whichever is larger:

@@ -133,6 +133,12 @@ def test_reconstruct_redwood_warm_start(oracle_decoder):
     _check_trace(oracle_decoder, "golden_recon_redwood.npz", 1e-4)
 
 
+def test_reconstruct_freiburg_hyper_parameters(oracle_decoder):
+    """Third hyper-parameter set of the reference (configs/config_freiburg_001.json:15-30: k3 = 0.5, k4 = 0, 5 iterations,
+    scale damping 100)."""
+    _check_trace(oracle_decoder, "golden_recon_freiburg.npz", 1e-4)
+
+
 def test_reconstruct_cfg1(oracle_decoder):
     _check_trace(oracle_decoder, "golden_recon_cfg1.npz", 1e-4)
 

@@ -30,6 +30,8 @@ KITTI = dict(k1=1.0, k2=100.0, k3=0.25, k4=1e7, b1=0.20, b2=0.025, num_iteration
              learning_rate=1.0, scale_damping=1.0)
 REDWOOD = dict(k1=10.0, k2=100.0, k3=2.5, k4=0.0, b1=0.20, b2=0.02, num_iterations=5,
                learning_rate=1.0, scale_damping=100.0)
+FREIBURG = dict(k1=1.0, k2=100.0, k3=0.5, k4=0.0, b1=0.20, b2=0.025, num_iterations=5,      # configs/config_freiburg_001.json:15-30
+                learning_rate=1.0, scale_damping=100.0)
 
 
 def make_cfg(deepsdf_dir, joint, data_type="KITTI"):
@@ -250,6 +252,8 @@ def main():
         code0 = np.zeros(64, np.float32)
         code0[:3] = obj["code_gt"][:3] * 0.5
         recon("golden_recon_redwood.npz", obj, make_cfg(cars_dir, REDWOOD, "Redwood"), code=code0)
+    if want("freiburg"):
+        recon("golden_recon_freiburg.npz", synth.make_object(15, n_surface=180, n_background=60), make_cfg(cars_dir, FREIBURG, "Freiburg"))
     if want("cfg1"):
         c1 = make_cfg(cars_dir, dict(KITTI, num_iterations=5))
         recon("golden_recon_cfg1.npz", synth.make_object(0, n_surface=500, n_background=0), c1)
