@@ -18,6 +18,7 @@ CODE_LEN = 64
 GRAD_DIM = 67
 
 OBJ_GOOD, OBJ_FEW_SAMPLES, OBJ_NAN = 0, 1, 2
+PREPASS_OFF, PREPASS_F16, PREPASS_BF16 = 0, 1, 2
 
 
 class DecoderDesc(C.Structure):
@@ -54,6 +55,8 @@ SYMBOLS = [
     ("dsp_last_error", C.c_char_p, [_VP]),
     ("dsp_decode_sdf", C.c_int, [_VP, c_f32p, c_f32p, C.c_int64, c_f32p]),
     ("dsp_decode_sdf_multi", C.c_int, [_VP, c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p]),
+    ("dsp_decode_sdf_prepass", C.c_int, [_VP, C.c_int, c_f32p, c_f32p, C.c_int64, c_f32p]),
+    ("dsp_debug_pack_prepass", C.c_int, [C.POINTER(DecoderDesc), C.c_int, C.POINTER(C.c_uint16), c_i64p, c_i32p, c_i32p]),
     ("dsp_sdf_jacobian", C.c_int, [_VP, c_f32p, c_f32p, C.c_int64, c_f32p, c_f32p]),
     ("dsp_compute_sdf_loss", C.c_int, [_VP, c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p]),
     ("dsp_compute_render_loss", C.c_int, [_VP, c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_int32, c_f32p, C.c_float,

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libdspgn.so")
-SOURCES = ["mlp_kernel.hip", "mlp_split_kernel.hip", "gn_kernels.hip", "mesh_kernels.hip", "dsp_gn.hip"]
+SOURCES = ["mlp_kernel.hip", "mlp_split_kernel.hip", "mlp_lp_kernel.hip", "gn_kernels.hip", "mesh_kernels.hip", "dsp_gn.hip"]
 HEADERS = [os.path.join(CSRC, "dsp_internal.h"), os.path.join(CSRC, "mlp_common.h"), os.path.join(ROOT, "include", "dsp_gn.h")]
 
 

@@ -63,6 +63,11 @@ struct dsp_handle {
     int wlast_row = 0, w0_row = 0;
     int n_bias_rows = 0, n_fwd = 0, n_pass_all = 0, chunks_fwd = 0, chunks_all = 0;
     PassDesc pass[MAX_PASSES];
+    // low-precision prepass (mlp_lp_kernel.hip): packed 16-bit weight streams [0] = f16, [1] = bf16 and their pass table
+    DevBuf<uint16_t> wlp[2];
+    LpPass lp_pass[LP_MAX_PASSES];
+    int lp_n_pass = 0, lp_chunks = 0;
+    bool lp_ok = false;        // decoder geometry supported by the prepass kernel (hidden width 512)
     // scratch of the single-shot decoder calls
     DevBuf<float4> s_pts;
     DevBuf<float> s_code, s_out, s_cbias;
@@ -220,6 +225,107 @@ void pack_decoder_host(PackedNet* h, const dsp_decoder_desc* d) {
     h->chunks_all = chunk;
 }
 
+// ---- low-precision prepass stream (mlp_lp_kernel.hip) --------------------------------------------------------------------
+uint16_t lp_bits(float v, bool bf) {      // fp32 -> f16 / bf16 bits, round to nearest even (= v_cvt_pk_{f16,bf16}_f32)
+    uint16_t r;
+    if (bf) {
+        uint32_t u;
+        memcpy(&u, &v, 4);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        r = (uint16_t)(u >> 16);
+    } else {
+        const _Float16 h = (_Float16)v;
+        memcpy(&r, &h, 2);
+    }
+    return r;
+}
+float lp_value(uint16_t b, bool bf) {
+    if (bf) { const uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }
+    _Float16 h;
+    memcpy(&h, &b, 2);
+    return (float)h;
+}
+// part p (1..3) of the split w = w1 + w2 + w3 (each a 16-bit value)
+float lp_part(float w, int p, bool bf) {
+    const float w1 = lp_value(lp_bits(w, bf), bf);
+    if (p == 1) return w1;
+    const float w2 = lp_value(lp_bits(w - w1, bf), bf);
+    if (p == 2) return w2;
+    return lp_value(lp_bits(w - w1 - w2, bf), bf);
+}
+
+struct PackedLp {
+    std::vector<uint16_t> stream;
+    LpPass pass[LP_MAX_PASSES];
+    int n_pass = 0, chunks = 0;
+};
+
+// Returns false when the decoder's geometry is outside what mlp_lp_kernel<*, 4> is built for (the prepass is then off and
+// every sample goes through the fp32 kernel, as in round 1).
+bool pack_decoder_lp_host(PackedLp* out, const dsp_decoder_desc* d, bool bf) {
+    const int hidden = d->n_layers - 1, lat = d->latent_in;
+    constexpr int NCH = 4, NOG = 2 * NCH;
+    if (hidden < 2 || hidden > LP_MAX_PASSES || lat < 2 || lat >= hidden) return false;
+    const int in_dim = d->code_len + 3;
+    for (int k = 0; k < d->n_layers; ++k) {
+        const int want_in = k == 0 ? in_dim : WIDTH;
+        const int want_out = k == hidden ? 1 : (k + 1 == lat ? WIDTH - in_dim : WIDTH);
+        if (d->in_dims[k] != want_in || d->out_dims[k] != want_out) return false;
+    }
+    const int lat_rows = WIDTH - in_dim;                                  // slab rows of the latent_in layer (445)
+    const int lat_ksteps = (lat_rows + 15) / 16;
+    const int xyz0 = LP_KSTEPS_PER_CHUNK * NCH - LP_XYZ_KSTEPS;           // first xyz k-step of the latent_in layer
+    if (lat_ksteps > xyz0 || xyz0 - lat_ksteps > 3) return false;
+    const int tsel = bf ? 1 : 0;
+    out->stream.clear();
+    memset(out->pass, 0, sizeof out->pass);
+    int chunk = 0;
+    for (int k = 0; k < hidden; ++k) {
+        LpPass& p = out->pass[k];
+        const int od = d->out_dims[k], id = d->in_dims[k];
+        const float* W = d->weights[k];
+        p.kind = (int16_t)(k == 0 ? 0 : (k == lat ? 2 : 1));
+        p.nog = (int16_t)((od + 63) / 64);
+        if (p.nog != NOG && p.nog != NOG - 1) return false;
+        p.nchunks = (int16_t)(k == 0 ? 1 : NCH);
+        p.bias_row = (int16_t)(k == 0 ? -3 : (k == lat ? -2 : k - 1));
+        p.npad = (int16_t)(k == lat ? xyz0 - lat_ksteps : 0);
+        p.last = (int16_t)(k == hidden - 1);
+        p.chunk_base = chunk;
+        const int slab_rows = k == 0 ? 0 : (k == lat ? lat_rows : id);
+        const int xyz_col = k == 0 ? d->code_len : lat_rows + d->code_len;   // first of the three xyz columns of W
+        const int xyz_first = k == 0 ? 0 : (k == lat ? xyz0 : 1 << 20);       // k-step of the first xyz operand
+        const size_t base = out->stream.size();
+        out->stream.resize(base + (size_t)p.nog * p.nchunks * (CHUNK_BYTES / 2), 0);
+        uint16_t* dst = out->stream.data() + base;
+        for (int g = 0; g < p.nog; ++g)
+            for (int c = 0; c < p.nchunks; ++c)
+                for (int sl = 0; sl < LP_KSTEPS_PER_CHUNK; ++sl)
+                    for (int j = 0; j < 2; ++j)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int e = 0; e < 8; ++e) {
+                                const int s = LP_KSTEPS_PER_CHUNK * c + sl, hh = lane >> 5;
+                                const int orow = 64 * g + 32 * j + (lane & 31);
+                                float v = 0.f;
+                                if (orow < od) {
+                                    if (s >= xyz_first && s < xyz_first + LP_XYZ_KSTEPS) {
+                                        const int kk = 8 * hh + e, t = kk / 3;
+                                        const int ent = t < 5 ? LP_XYZ_TERMS[tsel][s - xyz_first][t] : 0;
+                                        if (ent) v = lp_part(W[(size_t)orow * id + xyz_col + kk % 3], ent & 3, bf);
+                                    } else if (s < xyz_first) {
+                                        const int krow = 16 * s + 8 * (e >> 2) + 4 * hh + (e & 3);
+                                        if (krow < slab_rows) v = W[(size_t)orow * id + krow];
+                                    }
+                                }
+                                dst[((((size_t)(g * p.nchunks + c) * LP_KSTEPS_PER_CHUNK + sl) * 2 + j) * 64 + lane) * 8 + e] = lp_bits(v, bf);
+                            }
+        chunk += p.nog * p.nchunks;
+    }
+    out->n_pass = hidden;
+    out->chunks = chunk;
+    return true;
+}
+
 // Latency form (mlp_split_kernel): wave w of a workgroup produces output groups 2w and 2w+1 of every pass and streams only
 // their chunks.  Returns the chunk ids of the throughput stream in the order the four waves consume them (wave 0's whole
 // stream, then wave 1's, ...; inside a wave: pass, own group, chunk -- forward passes first, then backward), and each wave's
@@ -269,6 +375,30 @@ void pack_decoder(dsp_handle* h, const dsp_decoder_desc* d) {
     }
     h->bias_tab.alloc(pn.bias.size());
     HIP_TRY(hipMemcpy(h->bias_tab.p, pn.bias.data(), pn.bias.size() * 4, hipMemcpyHostToDevice));
+    h->lp_ok = true;
+    for (int bf = 0; bf < 2 && h->lp_ok; ++bf) {
+        PackedLp pl;
+        if (!pack_decoder_lp_host(&pl, d, bf != 0)) { h->lp_ok = false; break; }
+        h->wlp[bf].alloc(pl.stream.size());
+        HIP_TRY(hipMemcpy(h->wlp[bf].p, pl.stream.data(), pl.stream.size() * 2, hipMemcpyHostToDevice));
+        memcpy(h->lp_pass, pl.pass, sizeof h->lp_pass);
+        h->lp_n_pass = pl.n_pass;
+        h->lp_chunks = pl.chunks;
+    }
+}
+
+LpArgs make_lp_args(const dsp_handle* h, bool bf) {
+    LpArgs a;
+    memset(&a, 0, sizeof a);
+    a.wstream = h->wlp[bf ? 1 : 0].p;
+    a.bias_tab = h->bias_tab.p;
+    a.b_last = h->b_last;
+    a.n_bias_rows = h->n_bias_rows;
+    a.wlast_row = h->wlast_row;
+    a.n_pass = h->lp_n_pass;
+    a.total_chunks = h->lp_chunks;
+    memcpy(a.pass, h->lp_pass, sizeof a.pass);
+    return a;
 }
 
 // per-object code bias on the host (single-shot calls); same arithmetic as k_code_bias
@@ -315,14 +445,17 @@ MlpArgs make_mlp_args(const dsp_handle* h, int mode) {   // mode: 0/1 forward, 2
 
 // n_codes objects x the same n points, already in h->s_pts (device): decoder forward or forward+gradient into h->s_out,
 // output row = code * n + point.  Asynchronous on h->stream.
-void decode_resident_points(dsp_handle* h, const float* codes, int64_t n_codes, int64_t n, bool bwd) {
-    const int64_t ntile = (n + TILE_PTS - 1) / TILE_PTS;
+// lp: 0 = fp32 kernels, 1 = f16 prepass kernel, 2 = bf16 prepass kernel (forward only)
+void decode_resident_points(dsp_handle* h, const float* codes, int64_t n_codes, int64_t n, bool bwd, int lp = 0) {
+    if (lp && (bwd || !h->lp_ok)) throw std::invalid_argument("low-precision decode: forward only, hidden width 512");
+    const int tile_pts = lp ? LP_TILE_PTS : TILE_PTS;
+    const int64_t ntile = (n + tile_pts - 1) / tile_pts;
     if (ntile * n_codes > (int64_t)1 << 30 || n * n_codes > (int64_t)1 << 31) throw std::invalid_argument("decode request too large");
     const int nt = (int)(ntile * n_codes);
     std::vector<int4> tiles(nt);
     for (int64_t c = 0; c < n_codes; ++c)
         for (int64_t i = 0; i < ntile; ++i)
-            tiles[c * ntile + i] = make_int4((int)(i * TILE_PTS), (int)std::min<int64_t>(TILE_PTS, n - i * TILE_PTS), (int)c, (int)(c * n));
+            tiles[c * ntile + i] = make_int4((int)(i * tile_pts), (int)std::min<int64_t>(tile_pts, n - i * tile_pts), (int)c, (int)(c * n));
     const size_t n_out = (size_t)n * n_codes;
     h->s_code.ensure((size_t)CODE_LEN * n_codes);
     h->s_cbias.ensure((size_t)2 * WIDTH * n_codes);
@@ -336,6 +469,19 @@ void decode_resident_points(dsp_handle* h, const float* codes, int64_t n_codes, 
     HIP_TRY(hipMemcpyAsync(h->s_tiles.p, tiles.data(), nt * sizeof(int4), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->s_ntiles.p, &nt, 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));     // the staging vectors above go out of scope
+    h->s_clk.ensure(4);
+    if (lp) {
+        LpArgs la = make_lp_args(h, lp == 2);
+        la.n_tiles = h->s_ntiles.p;
+        la.tiles = h->s_tiles.p;
+        la.pts = h->s_pts.p;
+        la.code_bias = h->s_cbias.p;
+        la.code_bias_stride = 2 * WIDTH;
+        la.out_sdf = h->s_out.p;
+        la.clk = h->s_clk.p;
+        HIP_TRY(launch_mlp_lp(lp == 2, la, std::min(nt, h->n_cu), h->stream));
+        return;
+    }
     MlpArgs a = make_mlp_args(h, bwd ? 2 : 0);
     a.n_tiles = h->s_ntiles.p;
     a.tiles = h->s_tiles.p;
@@ -353,14 +499,14 @@ void decode_resident_points(dsp_handle* h, const float* codes, int64_t n_codes, 
 
 // n_codes objects x the same n host points (object frame): forward or forward+gradient.  Output row = code * n + point.
 void run_decoder_points(dsp_handle* h, const float* codes, int64_t n_codes, const float* pts, int64_t n, bool bwd, float* sdf_out,
-                        float* grad_out) {
+                        float* grad_out, int lp = 0) {
     if (n <= 0 || n_codes <= 0) return;
     HIP_TRY(hipSetDevice(h->device));
     std::vector<float4> p4((size_t)n);
     for (int64_t i = 0; i < n; ++i) p4[i] = make_float4(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], 0.f);
     h->s_pts.ensure(n);
     HIP_TRY(hipMemcpyAsync(h->s_pts.p, p4.data(), n * sizeof(float4), hipMemcpyHostToDevice, h->stream));
-    decode_resident_points(h, codes, n_codes, n, bwd);
+    decode_resident_points(h, codes, n_codes, n, bwd, lp);
     const size_t n_out = (size_t)n * n_codes;
     if (!bwd) {
         HIP_TRY(hipMemcpyAsync(sdf_out, h->s_out.p, n_out * 4, hipMemcpyDeviceToHost, h->stream));
@@ -920,6 +1066,7 @@ int dsp_create(const dsp_decoder_desc* decoder, int device, dsp_handle** out) {
         HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         HIP_TRY(mlp_prepare_device());
         HIP_TRY(mlp_split_prepare_device());
+        HIP_TRY(mlp_lp_prepare_device());
         pack_decoder(h, decoder);
     });
     if (rc != DSP_OK) { delete h; return rc; }
@@ -939,6 +1086,32 @@ const char* dsp_last_error(const dsp_handle* h) { return h ? h->err.c_str() : g_
 int dsp_decode_sdf(dsp_handle* h, const float* code, const float* pts, int64_t n, float* sdf_out) {
     if (!h || !code || (n > 0 && (!pts || !sdf_out)) || n < 0) return DSP_E_ARG;
     return guarded(h, [&] { run_decoder_points(h, code, 1, pts, n, false, sdf_out, nullptr); });
+}
+
+int dsp_decode_sdf_prepass(dsp_handle* h, int dtype, const float* code, const float* pts, int64_t n, float* sdf_out) {
+    if (!h || !code || (n > 0 && (!pts || !sdf_out)) || n < 0 || (dtype != DSP_PREPASS_F16 && dtype != DSP_PREPASS_BF16)) return DSP_E_ARG;
+    return guarded(h, [&] { run_decoder_points(h, code, 1, pts, n, false, sdf_out, nullptr, dtype); });
+}
+
+/* Host-only: pack the prepass weight stream exactly as dsp_create does (tests emulate the kernel's data flow on it without a GPU).
+ * pass_out receives n_pass x 8 int32 {nog, nchunks, bias_row, kind, npad, last, chunk_base, 0}; meta_out = {n_pass, chunks}.
+ * Call with NULL stream_out to query *stream_len (in 16-bit elements). */
+int dsp_debug_pack_prepass(const dsp_decoder_desc* decoder, int dtype, uint16_t* stream_out, int64_t* stream_len, int32_t* pass_out,
+                           int32_t* meta_out) {
+    if (!decoder || !stream_len || !meta_out || (dtype != DSP_PREPASS_F16 && dtype != DSP_PREPASS_BF16)) return DSP_E_ARG;
+    return guarded(nullptr, [&] {
+        PackedLp pl;
+        if (!pack_decoder_lp_host(&pl, decoder, dtype == DSP_PREPASS_BF16)) throw std::invalid_argument("decoder geometry not supported by the prepass kernel");
+        *stream_len = (int64_t)pl.stream.size();
+        meta_out[0] = pl.n_pass; meta_out[1] = pl.chunks;
+        if (stream_out) memcpy(stream_out, pl.stream.data(), pl.stream.size() * 2);
+        if (pass_out)
+            for (int i = 0; i < pl.n_pass; ++i) {
+                const LpPass& q = pl.pass[i];
+                int32_t* o = pass_out + 8 * i;
+                o[0] = q.nog; o[1] = q.nchunks; o[2] = q.bias_row; o[3] = q.kind; o[4] = q.npad; o[5] = q.last; o[6] = q.chunk_base; o[7] = 0;
+            }
+    });
 }
 
 int dsp_decode_sdf_multi(dsp_handle* h, const float* codes, int64_t n_codes, const float* pts, int64_t n, float* sdf_out) {

@@ -67,6 +67,54 @@ struct MlpArgs {
     float* dbg;                 // development aid: [pass][wave][128][64] slab dump of tile 0 (nullptr = off)
 };
 
+
+// ---- low-precision prepass (mlp_lp_kernel.hip): f16 / bf16 MFMA forward used ONLY to classify ray samples ------------
+// Occupancy is exactly 0 for sdf >= th and exactly 1 for sdf <= -th (loss_utils.py:40-48), so a sample whose low-precision
+// sdf is farther than a calibrated margin from the band needs no fp32 decode at all (DESIGN.md "Prepass").
+constexpr int LP_TILE_PTS = 128;    // points per workgroup tile (4 waves x 32)
+constexpr int LP_WAVE_PTS = 32;
+constexpr int LP_NBUF = 8;          // LDS ring depth in 16 KiB chunks
+constexpr int LP_KSTEPS_PER_CHUNK = 8;   // chunk = 8 k-steps (of 16 slab rows) x 2 row tiles (of 32 output rows) x 1 KiB
+constexpr int LP_MAX_PASSES = 12;
+constexpr int LP_XYZ_KSTEPS = 2;    // k-steps reserved for the split-precision xyz products (f16 uses one, bf16 two)
+
+// xyz enters layer 0 and the latent_in layer as sums of low-precision parts: x = x1 + x2 (+ x3), w = w1 + w2 (+ w3),
+// x.w ~ sum of the listed (x part, w part) products -- 22-24 significant bits, so the prepass error is set by the hidden
+// layers' activation rounding only.  Entry [kstep][term] = 4 * xpart + wpart (parts 1-based), 0 = unused; MFMA k index
+// of (term t, coordinate c) = 3 t + c.
+constexpr unsigned char LP_XYZ_TERMS[2][LP_XYZ_KSTEPS][5] = {
+    {{4 * 1 + 1, 4 * 2 + 1, 4 * 1 + 2, 4 * 2 + 2, 0}, {0, 0, 0, 0, 0}},                                   // f16
+    {{4 * 1 + 1, 4 * 2 + 1, 4 * 3 + 1, 4 * 1 + 2, 4 * 2 + 2}, {4 * 1 + 3, 4 * 3 + 2, 4 * 2 + 3, 0, 0}},   // bf16
+};
+
+struct LpPass {
+    int16_t nog;        // 64-row output groups (2 MFMA row tiles each)
+    int16_t nchunks;    // chunks per group = ceil(k-steps / 8)
+    int16_t bias_row;   // row of the fp32 bias table; -2 = per-object latent_in code bias, -3 = per-object layer-0 code bias
+    int16_t kind;       // 0 first layer (xyz k-steps only), 1 hidden, 2 latent_in (slab k-steps, then xyz k-steps)
+    int16_t npad;       // latent_in layer: padding k-steps between the slab rows and the xyz k-steps (the xyz B operands sit at
+                        // fixed k-steps: 0, 1 of the first layer; the last two of the latent_in layer's groups)
+    int16_t last;       // 1: final 512->1 layer + tanh follow in the epilogue
+    int32_t chunk_base;
+};
+
+struct LpArgs {
+    const void* wstream;        // packed 16-bit weight stream, chunk-major (pack_decoder_lp)
+    const float* bias_tab;      // the fp32 kernel's table: hidden biases, final-layer weights (row wlast_row)
+    float b_last;
+    int n_bias_rows, wlast_row;
+    int n_pass, total_chunks;
+    LpPass pass[LP_MAX_PASSES];
+    const int* n_tiles;
+    const int4* tiles;          // {first point, n points (<= 128), object, output offset}
+    const float4* pts;
+    const int* index;           // optional indirection, as MlpArgs::index
+    const float* code_bias;     // per object [2][512] fp32 (k_code_bias)
+    int code_bias_stride;
+    float* out_sdf;
+    unsigned long long* clk;
+};
+
 // ---- Gauss-Newton batch state ------------------------------------------------------------------
 constexpr int DSP_STATUS_GOOD = 0;
 constexpr int DSP_STATUS_FEW = 1;    // < 10 in-sphere samples (loss.py:73-74)
@@ -108,6 +156,8 @@ hipError_t mlp_prepare_device();
 hipError_t launch_mlp(int mode, const MlpArgs& args, int n_blocks, hipStream_t stream);   // mode: see mlp_kernel
 hipError_t mlp_split_prepare_device();
 hipError_t launch_mlp_split(bool bwd, const MlpArgs& args, int n_blocks, hipStream_t stream);   // 16-point tiles; forward (+ backward)
+hipError_t mlp_lp_prepare_device();
+hipError_t launch_mlp_lp(bool bf16, const LpArgs& args, int n_blocks, hipStream_t stream);   // 128-point tiles, forward only
 void launch_init_state(ObjState* st, const float* t, const float* codes, const float* scale, int B, int D, int pose_only, hipStream_t s);
 void launch_sample_count(const ObjConst* oc, ObjState* st, const float* rays, unsigned long long* m, int* c, int D, int maxR, int B, hipStream_t s);
 void launch_scan_rays(const ObjConst* oc, ObjState* st, const int* cnt, int* off, int which, int B, hipStream_t s);

@@ -1,0 +1,338 @@
+// DeepSDF decoder forward in f16 / bf16 MFMA for gfx950 (MI355X): the PREPASS that classifies ray samples.
+//
+// Not a replacement for the fp32 decoder (mlp_kernel.hip) -- an exact filter in front of it.  The render term only looks at
+// clamp(sdf, -th, th) (reconstruct/loss_utils.py:40-48, reconstruct/loss.py:84-96): occupancy is exactly 0 for sdf >= th
+// and exactly 1 for sdf <= -th.  A sample whose low-precision sdf is farther than a calibrated margin delta from the band
+// |sdf| < th is therefore classified for good, bit-exactly, and only the samples inside the widened band are decoded in
+// fp32 (dsp_gn.hip, "prepass").  v_mfma_f32_32x32x16_{f16,bf16} runs at 16x the fp32 MFMA rate.
+//
+// Structure (DESIGN.md "K0"): one workgroup = 4 waves = one 128-point tile, one wave per SIMD.  A wave owns 32 points and
+// keeps its [512 rows x 32 points] activation slab in registers as packed 16-bit pairs (128 registers): the D layout of
+// v_mfma_f32_32x32x16 (lane = point + 32 hh holds rows 8 i + 4 hh + r of each 32-row tile) IS, after v_cvt_pk, the B-operand
+// layout of two k-steps of the next layer if that layer's weights are packed with the k order
+// krow(s, hh, e) = 16 s + 8 (e >> 2) + 4 hh + (e & 3).  Two slabs (X, Y) ping-pong between layers.  Weights stream through
+// an 8-slot LDS ring of 16 KiB chunks (8 k-steps x 2 row tiles x 1 KiB A fragment) by LDS-DMA, one piece per k-step behind
+// an MFMA, counted vmcnt + one s_barrier per chunk -- the protocol of mlp_kernel.hip at 4x the chunk rate.  The relu /
+// v_cvt_pk epilogue of output group g-1 is interleaved with the MFMAs of group g (two accumulator sets).  xyz enters
+// layer 0 and the latent_in layer through one or two extra k-steps as split-precision products (LP_XYZ_TERMS), the code
+// through the fp32 per-object bias (k_code_bias), biases are the fp32 C operand of each tile's first MFMA, and the final
+// 512 -> 1 layer + tanh is an fp32 VALU dot product on the un-rounded accumulators of the last hidden layer.
+#include "dsp_internal.h"
+#include "mlp_common.h"
+
+namespace dsp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+
+constexpr int LP_PREFETCH = 2;     // A fragments are read this many k-steps ahead of their MFMAs (4 rotating buffers)
+constexpr int LP_KSTEP_BYTES = 2048;   // two 1 KiB A fragments (row tiles 2g, 2g+1) per k-step
+
+template <bool BF>
+__device__ __forceinline__ f32x16 lp_mfma(u32x4 a, u32x4 b, f32x16 c) {
+    if constexpr (BF)
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, a), __builtin_bit_cast(b8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+}
+
+// two fp32 -> one register holding two 16-bit values (element 0 in the low half), round to nearest even:
+// v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32
+template <bool BF>
+__device__ __forceinline__ unsigned lp_pack(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    if constexpr (BF)
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(v, b2));
+    else
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(v, h2));
+}
+
+template <bool BF>
+__device__ __forceinline__ float lp_round(float x) {
+    if constexpr (BF)
+        return (float)(__bf16)x;
+    else
+        return (float)(_Float16)x;
+}
+
+struct LpRing {            // weight-stream state, all wave-uniform
+    int issue_pos, issue_slot, rd_slot, total_chunks;
+    const char* wbase;     // this lane's source address inside chunk 0
+    const char* isrc;      // ... inside the chunk being issued
+    unsigned ring0, idst;  // LDS byte addresses: ring start + this wave's quarter; destination of the chunk being issued
+    char* ring_ptr;
+};
+
+__device__ __forceinline__ void lp_issue_next(LpRing& rg) {
+    rg.issue_pos = (rg.issue_pos + 1 == rg.total_chunks) ? 0 : rg.issue_pos + 1;
+    rg.issue_slot = (rg.issue_slot + 1 == LP_NBUF) ? 0 : rg.issue_slot + 1;
+    rg.isrc = rg.wbase + (size_t)rg.issue_pos * CHUNK_BYTES;
+    rg.idst = rg.ring0 + rg.issue_slot * CHUNK_BYTES;
+}
+
+// rows 64 g + 32 j + 8 i + 4 hh + r of a fp32 table, in accumulator (D) order: acc[j][4 i + r]
+__device__ __forceinline__ void lp_load_rows(const float* tab, int g, int hh, f32x16 (&dst)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(tab + 64 * g + 32 * j + 8 * i + 4 * hh);
+            dst[j][4 * i + 0] = v.x; dst[j][4 * i + 1] = v.y; dst[j][4 * i + 2] = v.z; dst[j][4 * i + 3] = v.w;
+        }
+}
+
+// relu + round + pack accumulator pairs [q0, q1) of output group g into the next layer's input slab:
+// pair q of row tile j = registers (2 q, 2 q + 1) -> k-step 2 (2 g + j) + (q >> 2), component q & 3.
+// (g, q0, q1 are compile-time constants after the callers' loops are unrolled; the loop bounds here are literal so that
+// every register index folds.)
+template <bool BF>
+__device__ __forceinline__ void lp_epilogue(int g, int q0, int q1, const f32x16 (&acc)[2], u32x4 (&out)[32]) {
+#pragma unroll
+    for (int qq = 0; qq < 16; ++qq) {
+        if (qq >= q0 && qq < q1) {
+            const int j = qq >> 3, q = qq & 7;
+            const float lo = relu1(acc[j][2 * q]), hi = relu1(acc[j][2 * q + 1]);
+            out[2 * (2 * g + j) + (q >> 2)][q & 3] = lp_pack<BF>(lo, hi);
+        }
+    }
+}
+
+// One dense layer: out = relu(W . in + bias) for this wave's 32 points.  `in` / `out` are the two register slabs.
+// MODE 0 = first layer (one chunk per group: the xyz k-steps), 1 = hidden / latent_in layer, 2 = last hidden layer (the
+// 512 -> 1 layer + tanh follow on the VALU instead of the slab epilogue).  Compile-time, so that a pass is straight-line code
+// between its (at most one) conditional group.
+template <bool BF, int NCH, int MODE>
+__device__ __forceinline__ void lp_pass(const LpPass pd, u32x4 (&in)[32], u32x4 (&out)[32], f32x16 (&acc)[2][2],
+                                        u32x4 (&abuf)[4][2], LpRing& rg, const u32x4 (&xb)[LP_XYZ_KSTEPS], const float* bias_l,
+                                        const float* cb_l, const float* wl, int lane, int hh, float& part) {
+    const bool last = MODE < 0 ? pd.last != 0 : MODE == 2;     // MODE -1: everything from the pass descriptor at run time
+    const int nch = MODE < 0 ? (int)pd.nchunks : (MODE == 0 ? 1 : NCH);
+    // ---- prologue: place the xyz B operands at their fixed k-steps ---------------------------------------------------
+    // first layer: k-steps 0, 1 (the rest of its single chunk is padding); latent_in layer: the last two k-steps, behind the
+    // slab rows and pd.npad padding k-steps.  Padding k-steps meet zero A fragments: clear them so that no stale inf / nan
+    // of an earlier layer does.
+    // (Written as selects, not branches: hipcc sinks the stores of two branches into one store through a pointer phi, which
+    // pins the whole slab in scratch memory.)
+    {
+        const u32x4 zero = (u32x4){0u, 0u, 0u, 0u};
+        const bool first = pd.kind == 0, lat = pd.kind == 2;
+#pragma unroll
+        for (int s = 0; s < LP_KSTEPS_PER_CHUNK; ++s) in[s] = first ? (s < LP_XYZ_KSTEPS ? xb[s < LP_XYZ_KSTEPS ? s : 0] : zero) : in[s];
+#pragma unroll
+        for (int u = 0; u < LP_XYZ_KSTEPS; ++u) in[8 * NCH - LP_XYZ_KSTEPS + u] = lat ? xb[u] : in[8 * NCH - LP_XYZ_KSTEPS + u];
+#pragma unroll
+        for (int t = 1; t <= 3; ++t)
+            in[8 * NCH - LP_XYZ_KSTEPS - t] = (lat && pd.npad >= t) ? zero : in[8 * NCH - LP_XYZ_KSTEPS - t];
+    }
+    const float* bp = pd.bias_row == -2 ? cb_l + WIDTH : (pd.bias_row == -3 ? cb_l : bias_l + pd.bias_row * WIDTH);
+    f32x16 bias[2];
+    lp_load_rows(bp, 0, hh, bias);
+
+    // Output groups: every pass has NOG = 2 NCH groups except the layer in front of the latent_in layer, which has one fewer
+    // (its last 64 rows are the space the re-injected input takes).  Only the last group is conditional, and no slab store
+    // is: hipcc turns stores to slab slots selected by a run-time group count into dynamically indexed scratch accesses.
+    constexpr int NOG = 2 * NCH;
+#pragma unroll
+    for (int g = 0; g < NOG; ++g) {
+        if (g < NOG - 1 || pd.nog == NOG) {
+            const int par = g & 1;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                if (c < nch) {
+                    const int nx_slot = (rg.rd_slot + 1 == LP_NBUF) ? 0 : rg.rd_slot + 1;
+                    const char* cbp = rg.ring_ptr + rg.rd_slot * CHUNK_BYTES + lane * 16;
+                    const char* nbp = rg.ring_ptr + nx_slot * CHUNK_BYTES + lane * 16;
+#pragma unroll
+                    for (int sl = 0; sl < LP_KSTEPS_PER_CHUNK; ++sl) {
+                        const int s = LP_KSTEPS_PER_CHUNK * c + sl;
+                        if (sl == LP_KSTEPS_PER_CHUNK / 2) {
+                            // chunk q+1 has landed for this wave once <= LP_NBUF-3 younger chunks are in flight; the barrier
+                            // publishes every wave's quarter and proves all reads of chunk q-1 retired (mlp_kernel.hip)
+                            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(GLDS_PER_CHUNK * (LP_NBUF - 3)) : "memory");
+                        }
+                        const int sp = sl + LP_PREFETCH;
+                        const char* src = (sp < LP_KSTEPS_PER_CHUNK) ? cbp + sp * LP_KSTEP_BYTES : nbp + (sp - LP_KSTEPS_PER_CHUNK) * LP_KSTEP_BYTES;
+                        abuf[sp % 4][0] = *reinterpret_cast<const u32x4*>(src);
+                        abuf[sp % 4][1] = *reinterpret_cast<const u32x4*>(src + 1024);
+                        const u32x4 a0 = abuf[sl % 4][0], a1 = abuf[sl % 4][1];
+                        const u32x4 b = in[s];
+                        acc[par][0] = lp_mfma<BF>(a0, b, s == 0 ? bias[0] : acc[par][0]);
+                        // refill of the slot freed by the barrier above: one DMA piece per k-step, behind an MFMA
+                        if (sl == LP_KSTEPS_PER_CHUNK / 2 + 0) glds_piece<0>(rg.isrc, rg.idst);
+                        if (sl == LP_KSTEPS_PER_CHUNK / 2 + 1) glds_piece<1>(rg.isrc, rg.idst);
+                        if (sl == LP_KSTEPS_PER_CHUNK / 2 + 2) glds_piece<2>(rg.isrc, rg.idst);
+                        if (sl == LP_KSTEPS_PER_CHUNK / 2 + 3) { glds_piece<3>(rg.isrc, rg.idst); lp_issue_next(rg); }
+                        acc[par][1] = lp_mfma<BF>(a1, b, s == 0 ? bias[1] : acc[par][1]);
+                        if (s == 1 && g + 1 < NOG) lp_load_rows(bp, g + 1, hh, bias);   // the next group's bias, a whole group ahead
+                        // epilogue of the previous group, three accumulator pairs per k-step behind this group's MFMAs
+                        if (g > 0 && !last) {
+                            if (s == 2) lp_epilogue<BF>(g - 1, 0, 3, acc[par ^ 1], out);
+                            if (s == 3) lp_epilogue<BF>(g - 1, 3, 6, acc[par ^ 1], out);
+                            if (s == 4) lp_epilogue<BF>(g - 1, 6, 9, acc[par ^ 1], out);
+                            if (s == 5) lp_epilogue<BF>(g - 1, 9, 12, acc[par ^ 1], out);
+                            if (s == 6) lp_epilogue<BF>(g - 1, 12, 15, acc[par ^ 1], out);
+                            if (s == 7) lp_epilogue<BF>(g - 1, 15, 16, acc[par ^ 1], out);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    rg.rd_slot = nx_slot;
+                }
+            }
+            if (last) {
+                // final layer (512 -> 1) on the VALU, straight from the fp32 accumulators  (deep_sdf_decoder.py:93,107-108)
+                f32x16 w[2];
+                lp_load_rows(wl, g, hh, w);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) part = fmaf(relu1(acc[par][j][r]), w[j][r], part);
+            }
+        }
+    }
+    // The last group's epilogue has no MFMAs of its own pass to hide behind.  Unconditional for the last TWO groups: with
+    // NOG groups, group NOG-2 is merely converted again (same accumulators, same result); with NOG-1 groups, group NOG-1
+    // converts stale accumulators into slab k-steps 4 NOG - 4 .. 4 NOG - 1, exactly the padding + xyz k-steps the latent_in
+    // layer's prologue overwrites.
+    if (!last) {
+        lp_epilogue<BF>(NOG - 2, 0, 16, acc[(NOG - 2) & 1], out);
+        lp_epilogue<BF>(NOG - 1, 0, 16, acc[(NOG - 1) & 1], out);
+    }
+}
+
+template <bool BF, int NCH>
+__global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = lane >> 5;    // which half of each 8-row block / of each k-step's 16 k indices this lane holds
+    const int pl = lane & 31;    // point of this lane inside the wave
+
+    float* bias_l = reinterpret_cast<float*>(smem);
+    float* cb_l = reinterpret_cast<float*>(smem + BIAS_BYTES);
+    char* ring_ptr = smem + BIAS_BYTES + CODEBIAS_BYTES;
+
+    const int n_tiles = *a.n_tiles;
+    if ((int)blockIdx.x >= n_tiles) return;
+    if (a.clk && blockIdx.x == 0 && tid == 0) { a.clk[0] = clock64(); a.clk[1] = wall_clock64(); }
+    for (int i = tid; i < a.n_bias_rows * WIDTH; i += 256) bias_l[i] = a.bias_tab[i];
+    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    LpRing rg;
+    rg.issue_pos = 0; rg.issue_slot = 0; rg.rd_slot = 0; rg.total_chunks = a.total_chunks;
+    rg.wbase = reinterpret_cast<const char*>(a.wstream) + wave * 4096 + lane * 16;
+    rg.isrc = rg.wbase;
+    rg.ring0 = lds_addr(ring_ptr) + wave * 4096;
+    rg.idst = rg.ring0;
+    rg.ring_ptr = ring_ptr;
+#pragma unroll
+    for (int i = 0; i < LP_NBUF - 1; ++i) {
+        glds_quarter(rg.isrc, rg.idst);
+        lp_issue_next(rg);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(GLDS_PER_CHUNK * (LP_NBUF - 2)) : "memory");
+    u32x4 abuf[4][2];
+#pragma unroll
+    for (int i = 0; i < LP_PREFETCH; ++i) {
+        abuf[i][0] = *reinterpret_cast<const u32x4*>(ring_ptr + lane * 16 + i * LP_KSTEP_BYTES);
+        abuf[i][1] = *reinterpret_cast<const u32x4*>(ring_ptr + lane * 16 + i * LP_KSTEP_BYTES + 1024);
+    }
+
+    u32x4 X[32], Y[32];
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { X[i] = (u32x4){0u, 0u, 0u, 0u}; Y[i] = (u32x4){0u, 0u, 0u, 0u}; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const float* wl = bias_l + a.wlast_row * WIDTH;
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int4 td = a.tiles[tile];
+        const int local = wave * LP_WAVE_PTS + pl;
+        const bool valid = local < td.y;
+        const int pidx = td.x + (valid ? local : 0);
+        const int src = a.index ? a.index[pidx] : pidx;
+        float4 pt = a.pts[src];
+        if (!valid) pt = make_float4(0.f, 0.f, 0.f, 0.f);
+        reinterpret_cast<float4*>(cb_l)[tid] = reinterpret_cast<const float4*>(a.code_bias + (size_t)td.z * a.code_bias_stride)[tid];
+        __syncthreads();
+
+        // split-precision xyz operands (LP_XYZ_TERMS): MFMA k index 3 t + c of k-step u carries part xpart(t) of coordinate c
+        u32x4 xb[LP_XYZ_KSTEPS];
+        {
+            float xp[4][3];
+            const float xyz[3] = {pt.x, pt.y, pt.z};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                xp[0][c] = 0.f;
+                xp[1][c] = lp_round<BF>(xyz[c]);
+                xp[2][c] = lp_round<BF>(xyz[c] - xp[1][c]);
+                xp[3][c] = lp_round<BF>(xyz[c] - xp[1][c] - xp[2][c]);
+            }
+#pragma unroll
+            for (int u = 0; u < LP_XYZ_KSTEPS; ++u) {
+                float kv[16];
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) {
+                    const int t = kk / 3;
+                    const int ent = (t < 5) ? LP_XYZ_TERMS[BF ? 1 : 0][u][t] : 0;
+                    kv[kk] = ent ? xp[ent >> 2][kk % 3] : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned lo = lp_pack<BF>(kv[2 * q], kv[2 * q + 1]);
+                    const unsigned hi = lp_pack<BF>(kv[8 + 2 * q], kv[8 + 2 * q + 1]);
+                    xb[u][q] = hh ? hi : lo;
+                }
+            }
+        }
+
+        float part = 0.f;
+        // slabs ping-pong: pass ps reads Y and writes X when ps is even, the other way round when odd
+        for (int ps = 0; ps < a.n_pass; ps += 2) {
+            lp_pass<BF, NCH, -1>(a.pass[ps], Y, X, acc, abuf, rg, xb, bias_l, cb_l, wl, lane, hh, part);
+            if (ps + 1 < a.n_pass) lp_pass<BF, NCH, -1>(a.pass[ps + 1], X, Y, acc, abuf, rg, xb, bias_l, cb_l, wl, lane, hh, part);
+        }
+        part += __shfl_xor(part, 32);
+        const float y = tanhf(part + a.b_last);
+        if (valid && hh == 0) a.out_sdf[a.index ? src : pidx + td.w] = y;
+        // stores and LDS-DMA share vmcnt and may retire out of order: drain before counting again
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (a.clk && blockIdx.x == 0 && tid == 0) { a.clk[2] = clock64(); a.clk[3] = wall_clock64(); }
+}
+
+template __global__ void mlp_lp_kernel<false, 4>(const LpArgs);
+template __global__ void mlp_lp_kernel<true, 4>(const LpArgs);
+
+static size_t mlp_lp_lds_bytes() { return BIAS_BYTES + CODEBIAS_BYTES + LP_NBUF * CHUNK_BYTES; }
+
+hipError_t mlp_lp_prepare_device() {
+    const void* fns[2] = {reinterpret_cast<const void*>(&mlp_lp_kernel<false, 4>), reinterpret_cast<const void*>(&mlp_lp_kernel<true, 4>)};
+    for (int i = 0; i < 2; ++i) {
+        const hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlp_lp_lds_bytes());
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_mlp_lp(bool bf16, const LpArgs& args, int n_blocks, hipStream_t stream) {
+    if (bf16)
+        hipLaunchKernelGGL((mlp_lp_kernel<true, 4>), dim3(n_blocks), dim3(256), mlp_lp_lds_bytes(), stream, args);
+    else
+        hipLaunchKernelGGL((mlp_lp_kernel<false, 4>), dim3(n_blocks), dim3(256), mlp_lp_lds_bytes(), stream, args);
+    return hipGetLastError();
+}
+
+}  // namespace dsp

@@ -158,6 +158,16 @@ class Engine(object):
         L.check(L.load().dsp_decode_sdf(self._h, L.ptr(code), L.ptr(pts), pts.shape[0], L.ptr(out)), self._h, "dsp_decode_sdf")
         return out
 
+    def decode_sdf_prepass(self, code, pts, dtype=L.PREPASS_F16):
+        """The decoder through the low-precision prepass kernel (f16 / bf16 MFMA).  Calibration and tests only: the optimiser
+        uses these values to classify samples, never as results."""
+        pts = L.f32(pts).reshape(-1, 3)
+        code = L.f32(code).reshape(-1)[:L.CODE_LEN]
+        out = np.zeros(pts.shape[0], np.float32)
+        L.check(L.load().dsp_decode_sdf_prepass(self._h, int(dtype), L.ptr(code), L.ptr(pts), pts.shape[0], L.ptr(out)), self._h,
+                "dsp_decode_sdf_prepass")
+        return out
+
     def decode_sdf_multi(self, codes, pts):
         """(n_codes, 64) codes x one shared (n, 3) point set -> (n_codes, n) sdf, one kernel launch."""
         pts = L.f32(pts).reshape(-1, 3)

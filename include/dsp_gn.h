@@ -90,6 +90,14 @@ int dsp_abi_version(void);
 /* ---- decoder ---------------------------------------------------------------------------------- */
 /* decode_sdf(decoder, lat_vec, x)  -- reconstruct/loss_utils.py:51-79.  pts (n,3) object frame -> sdf (n). */
 int dsp_decode_sdf(dsp_handle* h, const float* code, const float* pts, int64_t n, float* sdf_out);
+/* The same decoder evaluated by the low-precision PREPASS kernel (v_mfma_f32_32x32x16_f16 / _bf16, fp32 accumulation; xyz, code
+ * and biases enter at fp32 accuracy, hidden activations are rounded to 16 bits per layer).  Never used for results: the optimiser
+ * uses it only to classify ray samples whose occupancy is exactly 0 or 1 (sdf outside the cut-off band by more than a calibrated
+ * margin, reconstruct/loss_utils.py:40-48); exposed for calibration and tests. */
+#define DSP_PREPASS_OFF 0
+#define DSP_PREPASS_F16 1
+#define DSP_PREPASS_BF16 2
+int dsp_decode_sdf_prepass(dsp_handle* h, int dtype, const float* code, const float* pts, int64_t n, float* sdf_out);
 /* The same point set decoded for n_codes shape codes in ONE launch: sdf_out[c * n + i].  Batched form of the
  * MeshExtractor grid decode (reconstruct/optimizer.py:217-218) / the per-object loop of extract_map_objects.py:46-63. */
 int dsp_decode_sdf_multi(dsp_handle* h, const float* codes, int64_t n_codes, const float* pts, int64_t n, float* sdf_out);

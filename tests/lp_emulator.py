@@ -1,0 +1,155 @@
+"""Numpy model of ONE WAVE of dsp_slam_amd/csrc/mlp_lp_kernel.hip (32 points, 64 lanes): the low-precision prepass.
+
+Test infrastructure.  It consumes the exact packed 16-bit weight stream / pass table the library uploads
+(dsp_debug_pack_prepass, host-only) and replays the kernel's register-level data flow: slabs indexed
+[k-step][lane][8 halves], v_mfma_f32_32x32x16 operand / result lane maps, the split-precision xyz k-steps,
+fp32 bias as accumulator seed, relu + round-to-nearest-even packing into the next layer's slab, the final
+fp32 dot product.  Lane maps (cdna_hip_programming.md section 3):
+  A[i = l & 31][k = 8 (l >> 5) + e],  B[k = 8 (l >> 5) + e][j = l & 31],
+  D[row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][col = l & 31]  for accumulator register r in [0, 16).
+"""
+import ctypes as C
+
+import numpy as np
+
+from dsp_slam_amd import _lib as L
+
+LANES = np.arange(64)
+HH = LANES >> 5
+PL = LANES & 31
+NCH = 4
+XYZ_KSTEPS = 2
+# dsp_internal.h LP_XYZ_TERMS: [dtype][k-step][term] = 4 * xpart + wpart, 0 = unused
+XYZ_TERMS = {
+    L.PREPASS_F16: [[5, 9, 6, 10, 0], [0, 0, 0, 0, 0]],
+    L.PREPASS_BF16: [[5, 9, 13, 6, 10], [7, 14, 11, 0, 0]],
+}
+
+
+def lp_round(x, dtype):
+    """fp32 -> f16 / bf16 -> fp32, round to nearest even."""
+    x = np.ascontiguousarray(x, np.float32)
+    if dtype == L.PREPASS_F16:
+        return x.astype(np.float16).astype(np.float32)
+    u = x.view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) >> 16
+    return (u.astype(np.uint32) << 16).view(np.float32)
+
+
+def lp_decode(bits, dtype):
+    bits = np.ascontiguousarray(bits, np.uint16)
+    if dtype == L.PREPASS_F16:
+        return bits.view(np.float16).astype(np.float32)
+    return (bits.astype(np.uint32) << 16).view(np.float32)
+
+
+def debug_pack(holder, dtype):
+    lib = L.load()
+    slen = C.c_int64(0)
+    meta = np.zeros(2, np.int32)
+    L.check(lib.dsp_debug_pack_prepass(C.byref(holder.desc), dtype, None, C.byref(slen), None, L.ptr(meta, L.c_i32p)), None,
+            "dsp_debug_pack_prepass(size)")
+    stream = np.zeros(slen.value, np.uint16)
+    passes = np.zeros((meta[0], 8), np.int32)
+    L.check(lib.dsp_debug_pack_prepass(C.byref(holder.desc), dtype, stream.ctypes.data_as(C.POINTER(C.c_uint16)), C.byref(slen),
+                                       L.ptr(passes, L.c_i32p), L.ptr(meta, L.c_i32p)), None, "dsp_debug_pack_prepass")
+    # [chunk][k-step 8][row tile 2][lane 64][8 halves]
+    return dict(stream=lp_decode(stream, dtype).reshape(-1, 8, 2, 64, 8), passes=passes, n_pass=int(meta[0]), chunks=int(meta[1]))
+
+
+def mfma32(a, b, acc):
+    """a, b: (64, 8) per-lane operands; acc (16, 64) [reg][lane] fp32.  D = A @ B + C in the lane maps above (fp64 sum, rounded once)."""
+    A = np.zeros((32, 16), np.float64)
+    B = np.zeros((16, 32), np.float64)
+    for e in range(8):
+        A[PL, 8 * HH + e] = a[:, e]
+        B[8 * HH + e, PL] = b[:, e]
+    D = A @ B
+    out = acc.astype(np.float64).copy()
+    for r in range(16):
+        out[r] += D[(r & 3) + 8 * (r >> 2) + 4 * HH, PL]
+    return out.astype(np.float32)
+
+
+def rows_in_d_order(tab512, g, j):
+    """fp32 table rows of group g, row tile j as [reg][lane]."""
+    out = np.zeros((16, 64), np.float32)
+    for r in range(16):
+        out[r] = tab512[64 * g + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * HH]
+    return out
+
+
+def run_wave(pk_fp32, pk_lp, code, pts32, dtype):
+    """pk_fp32: kernel_emulator.debug_pack(...) (bias table, code bias, b_last); pk_lp: debug_pack above.
+    pts32: (32,3) object-frame points.  Returns the prepass sdf (32,)."""
+    bias = pk_fp32["bias"]
+    cb = pk_fp32["code_bias"](code)               # [0:512] layer 0, [512:1024] latent_in layer
+    wl = bias[pk_fp32["wlast_row"]]
+    p = np.asarray(pts32, np.float32)[PL]          # (64, 3): both half-lanes of a point hold it
+    xp = np.zeros((4, 64, 3), np.float32)
+    xp[1] = lp_round(p, dtype)
+    xp[2] = lp_round(p - xp[1], dtype)
+    xp[3] = lp_round(p - xp[1] - xp[2], dtype)
+    xb = np.zeros((XYZ_KSTEPS, 64, 8), np.float32)
+    for u in range(XYZ_KSTEPS):
+        for e in range(8):
+            kk = 8 * HH + e
+            for lane in range(64):
+                t = kk[lane] // 3
+                ent = XYZ_TERMS[dtype][u][t] if t < 5 else 0
+                xb[u, lane, e] = xp[ent >> 2, lane, kk[lane] % 3] if ent else 0.0
+    slabs = [np.zeros((32, 64, 8), np.float32), np.zeros((32, 64, 8), np.float32)]   # X, Y
+    part = np.zeros(64, np.float32)
+    for ps in range(pk_lp["n_pass"]):
+        nog, nchunks, bias_row, kind, npad, last, chunk_base, _ = [int(v) for v in pk_lp["passes"][ps]]
+        src, dst = (slabs[1], slabs[0]) if ps % 2 == 0 else (slabs[0], slabs[1])      # even passes read Y, write X
+        if kind == 0:
+            src[:8] = 0.0
+            src[:XYZ_KSTEPS] = xb
+        elif kind == 2:
+            src[8 * NCH - XYZ_KSTEPS:8 * NCH] = xb
+            for t in range(1, npad + 1):
+                src[8 * NCH - XYZ_KSTEPS - t] = 0.0
+        tab = cb[512:] if bias_row == -2 else (cb[:512] if bias_row == -3 else bias[bias_row])
+        for g in range(nog):
+            acc = [rows_in_d_order(tab, g, 0), rows_in_d_order(tab, g, 1)]
+            for c in range(nchunks):
+                chunk = pk_lp["stream"][chunk_base + g * nchunks + c]
+                for sl in range(8):
+                    s = 8 * c + sl
+                    for j in range(2):
+                        acc[j] = mfma32(chunk[sl, j], src[s], acc[j])
+            for j in range(2):
+                if last:
+                    w = rows_in_d_order(wl, g, j)
+                    for r in range(16):
+                        part = (part + np.maximum(acc[j][r], 0) * w[r]).astype(np.float32)
+                else:
+                    v = lp_round(np.maximum(acc[j], 0.0), dtype)           # (16, 64)
+                    for r in range(16):
+                        dst[4 * g + 2 * j + (r >> 3), :, r & 7] = v[r]
+    tot = part[:32] + part[32:]
+    return np.tanh(tot + np.float32(pk_fp32["b_last"])).astype(np.float32)
+
+
+def reference_forward(dec, code, pts, dtype):
+    """The prepass arithmetic stated directly on the folded decoder (no packing): layer 0 and the xyz / code columns of the
+    latent_in layer at fp32 accuracy, hidden activations and hidden weights rounded to 16 bits, fp32 accumulation."""
+    pts = np.asarray(pts, np.float32)
+    n = pts.shape[0]
+    x = np.concatenate([np.broadcast_to(np.asarray(code, np.float32), (n, dec.code_len)), pts], -1).astype(np.float64)
+    h = None
+    n_lin = len(dec.layers)
+    for k, (w, b) in enumerate(dec.layers):
+        w64 = w.astype(np.float64)
+        if k == 0:
+            a = x @ w64.T + b
+        elif k == n_lin - 1:
+            a = h @ w64.T + b
+        elif k in dec.latent_in:
+            p = w.shape[1] - dec.in_dim
+            a = lp_round(h[:, :p], dtype).astype(np.float64) @ lp_round(w[:, :p], dtype).astype(np.float64).T + x @ w64[:, p:].T + b
+        else:
+            a = lp_round(h, dtype).astype(np.float64) @ lp_round(w, dtype).astype(np.float64).T + b
+        h = np.maximum(a, 0.0).astype(np.float32) if k < n_lin - 1 else a
+    return np.tanh(h[:, 0]).astype(np.float32)
