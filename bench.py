@@ -1,23 +1,31 @@
 #!/usr/bin/env python3
 """Benchmark of the DeepSDF shape/pose Gauss-Newton hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 5 --warmup 1
+    python bench.py --gpus 1 --steps 5 --warmup 1 [--config cfg2x64|cfg4|cfg5] [--prepass auto|off|f16|bf16]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path (Optimizer.reconstruct_object, all 10 GN iterations) over one batch of
-synthetic cfg2 objects (2000 surface points + 500 background rays x 50 depth samples, 64-D code) per GPU, inputs
-already resident in HBM (dsp_batch_create uploads them before the timed region), followed by one RCCL gather
-of the per-object results (pose 16 + code 64 + loss + status floats) to rank 0.  Objects are independent, so
+One "step" = one pass of the hot path (Optimizer.reconstruct_object, every GN iteration) over one batch of synthetic
+objects per GPU, inputs already resident in HBM (dsp_batch_create uploads them before the timed region), followed by one
+RCCL gather of the per-object results (pose 16 + code 64 + loss + status floats) to rank 0.  Objects are independent, so
 ranks shard them with no other collective: weak scaling, value = objects of all ranks / max-over-ranks time.
 
+Workloads (BASELINE.json configs):
+  cfg2x64 (default; the configuration the metric is quoted on): 64 cfg2 objects per GPU -- 2000 surface points + 500
+          background rays x 50 depth samples, 64-D code, 10 iterations, KITTI hyper-parameters;
+  cfg4    1024 cfg2 objects over 8 GPUs = 128 x N objects block-sharded by estimated cost (distributed.shard_objects);
+  cfg5    4000-point objects, Redwood hyper-parameters (5 iterations), a mixed batch on two resident decoders (cars + a second
+          decoder), 32 + 32 objects per GPU.
+
 The JSON line also carries
-  roofline      fp32-MFMA roofline of the dominant kernel (forward-only decoder, mlp_kernel<false>): algorithmic
-                FLOPs = points the launches actually decode x 3 671 040 FLOP / HIP-event time of those
-                launches.  The path decodes fewer points than the reference's V in-sphere samples: samples behind the
-                first solid sample of a ray have exactly zero transmittance and are skipped (results identical);
-  cpu_baseline  the CPU oracle (oracle/dsp_oracle.py, torch-CPU sgemm) timed on this box's host cores on ONE cfg2
-                object (rank 0, N=1 only) -- a reported baseline, not a target.
+  roofline      fp32-MFMA roofline of the dominant fp32 kernel (forward decoder with relu-mask export, mlp_kernel<1>):
+                algorithmic FLOPs = points the launches actually decode x 3 671 040 FLOP / HIP-event time
+                of those launches;
+  prepass       the low-precision classification kernel in front of it (mlp_lp_kernel, f16 MFMA), priced SEPARATELY
+                against the dense 16-bit MFMA peak -- never mixed into the fp32 fraction;
+  cpu_baseline  the reference itself (kind "reference") when DSP_REFERENCE_ROOT points at a DSP-SLAM checkout, else the
+                CPU oracle (kind "port": oracle/dsp_oracle.py, torch-CPU sgemm), timed on this box's host cores on ONE
+                cfg2 object (rank 0, N=1 only) -- a reported baseline, not a target.
 """
 import argparse
 import json
@@ -34,6 +42,56 @@ sys.path.insert(0, ROOT)
 F_FWD = 3671040.0          # FLOP / point, decoder forward                
 F_JAC = 7342080.0          # FLOP / point, forward + input-gradient
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: 256 CU x 256 FLOP/clk x 2.4 GHz
+PEAK_16BIT_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / f16 MFMA (no sparsity)
+REDWOOD = dict(k1=10.0, k2=100.0, k3=2.5, k4=0.0, b1=0.2, b2=0.02, lr=1.0, s_damp=100.0, num_iterations=5)   # config_redwood_01053.json
+PREPASS = {"auto": -1, "off": 0, "f16": 1, "bf16": 2}
+
+
+def second_decoder_layers(layers):
+    """A second resident weight set for cfg5 (no chairs weights exist offline): the cars decoder composed with a 90-degree roll
+    about z, f'(x, y, z) = f(-y, x, z), applied to the xyz columns of the two layers that see xyz."""
+    out = [(np.array(w, np.float32, copy=True), np.array(b, np.float32, copy=True)) for w, b in layers]
+    for k in (0, 4):
+        w = out[k][0]
+        wx, wy = w[:, -3].copy(), w[:, -2].copy()
+        w[:, -3] = wy
+        w[:, -2] = -wx
+    return out
+
+
+def reference_cpu_baseline(obj, threads):
+    """Time the UNMODIFIED reference (reconstruct/optimizer.py, torch CPU) on one object on the host cores.  Only attempted when
+    DSP_REFERENCE_ROOT names a DSP-SLAM checkout (oracle/ref_shim.py imports it in place); returns None otherwise."""
+    try:
+        import tempfile
+        import torch
+        from oracle import ref_shim         # stubs addict / plyfile / skimage, neutralises the reference's .cuda() calls
+        from dsp_slam_amd import fixtures
+        if not ref_shim.reference_available():
+            return None
+        ref_shim.install(force_cpu=True)
+        from reconstruct.utils import get_configs, get_decoder
+        from reconstruct.optimizer import Optimizer
+        d = tempfile.mkdtemp(prefix="dsp_ref_")
+        cars_dir = fixtures.materialize_decoder_dir("cars", os.path.join(d, "cars_64"))
+        cfg = json.load(open(os.path.join(ROOT, "tests", "golden", "config_kitti_optimizer.json")))
+        cfg["DeepSDF_DIR"] = cars_dir
+        with open(os.path.join(d, "cfg.json"), "w") as f:
+            json.dump(cfg, f)
+        cfg = get_configs(os.path.join(d, "cfg.json"))
+        torch.set_num_threads(threads)
+        opt = Optimizer(get_decoder(cfg), cfg)
+        args = [np.array(obj[k], np.float32, copy=True) for k in ("t_cam_obj_init", "pts", "rays", "depth")]
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):                # the reference prints its own timing line
+            opt.reconstruct_object(args[0].copy(), args[1][:200].copy(), args[2][:200].copy(), args[3][:200].copy())   # warm-up
+            t1 = time.perf_counter()
+            opt.reconstruct_object(*args)
+        return time.perf_counter() - t1
+    except Exception as e:
+        sys.stderr.write("reference cpu baseline unavailable: %r\n" % (e,))
+        return None
 
 
 def main():
@@ -41,7 +99,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--objects-per-gpu", type=int, default=64)   # BASELINE configs[2]: batches of 64 cfg2 objects saturate the matrix pipe
+    ap.add_argument("--config", choices=("cfg2x64", "cfg4", "cfg5"), default="cfg2x64")
+    ap.add_argument("--objects-per-gpu", type=int, default=0)   # 0 = the config's own size
+    ap.add_argument("--prepass", choices=sorted(PREPASS), default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency-runs", type=int, default=9)
     args = ap.parse_args()
@@ -64,26 +124,66 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    from dsp_slam_amd import fixtures, synth, engine as E
+    from dsp_slam_amd import fixtures, synth, engine as E, distributed as D
     from dsp_slam_amd.deep_sdf.deep_sdf_decoder import fold_weight_norm
 
     sd = fixtures.load_decoder_npz(fixtures.fixture_path("cars"))
     layers = fold_weight_norm(sd, len(fixtures.SPECS["NetworkSpecs"]["dims"]) + 1)
-    eng = E.Engine(layers, fixtures.SPECS["NetworkSpecs"]["latent_in"], fixtures.SPECS["CodeLength"], device=local_rank)
-    prm = E.gn_params()      # KITTI hyper-parameters (configs/config_kitti.json:21-40 of the reference)
-    B = args.objects_per_gpu
-    objs = synth.make_batch(B, first_seed=1 + rank * B, n_surface=2000, n_background=500)
-    batch = eng.batch(prm, [o["t_cam_obj_init"] for o in objs], [o["pts"] for o in objs], [o["rays"] for o in objs],
-                      [o["depth"] for o in objs])
+    lat_in, code_len = fixtures.SPECS["NetworkSpecs"]["latent_in"], fixtures.SPECS["CodeLength"]
+    eng = E.Engine(layers, lat_in, code_len, device=local_rank)
+    engines = [eng]
+
+    # ---- workload -------------------------------------------------------------------------------------------------------
+    if args.config == "cfg2x64":
+        B = args.objects_per_gpu or 64
+        prm = E.gn_params()      # KITTI hyper-parameters (configs/config_kitti.json:21-40 of the reference)
+        shards = [(r * B, (r + 1) * B) for r in range(world)]
+        objs = synth.make_batch(B, first_seed=1 + rank * B, n_surface=2000, n_background=500)
+        groups = [(eng, objs)]
+        workload = ("cfg2: single KITTI-like car per object -- 2000 surface pts + 500 free-space rays (2500 rays x 50 depth "
+                    "samples), 64-D code, 10 joint GN iterations (Optimizer.reconstruct_object), batch of %d objects per GPU" % B)
+    elif args.config == "cfg4":
+        per = args.objects_per_gpu or 128
+        total = per * world
+        prm = E.gn_params()
+        costs = [D.object_cost(2000, 2500)] * total
+        shards = D.shard_objects(costs, world)            # the production partitioner (uneven shards are padded in the gather)
+        a, b = shards[rank]
+        objs = [synth.make_object(1 + i, n_surface=2000, n_background=500) for i in range(a, b)]
+        B = b - a
+        groups = [(eng, objs)]
+        workload = ("cfg4: %d cfg2 objects block-sharded over %d GPU(s) by estimated cost (distributed.shard_objects), one RCCL gather "
+                    "of codes + poses per step" % (total, world))
+    else:
+        half = (args.objects_per_gpu or 64) // 2
+        B = 2 * half
+        prm = E.gn_params(**REDWOOD)
+        shards = [(r * B, (r + 1) * B) for r in range(world)]
+        eng2 = E.Engine(second_decoder_layers(layers), lat_in, code_len, device=local_rank)
+        engines.append(eng2)
+        cars = synth.make_batch(half, first_seed=1 + rank * B, n_surface=4000, n_background=500)
+        p = np.array([[0, -1, 0, 0], [1, 0, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float32)
+        others = []
+        for o in synth.make_batch(half, first_seed=1 + rank * B + half, n_surface=4000, n_background=500):
+            o = dict(o)
+            o["t_cam_obj_init"] = (o["t_cam_obj_init"] @ p).astype(np.float32)     # the same world points seen by the rolled decoder
+            others.append(o)
+        groups = [(eng, cars), (eng2, others)]
+        objs = cars
+        workload = ("cfg5: 4000 surface pts + 500 free-space rays x 50 samples, Redwood hyper-parameters (5 iterations), mixed batch on two "
+                    "resident decoders, %d + %d objects per GPU" % (half, half))
+    batches = []
+    for e, ol in groups:
+        bt = e.batch(prm, [o["t_cam_obj_init"] for o in ol], [o["pts"] for o in ol], [o["rays"] for o in ol], [o["depth"] for o in ol])
+        bt.set_prepass(PREPASS[args.prepass])
+        batches.append(bt)
 
     gathered = [None]
 
-    from dsp_slam_amd import distributed as D
-    shards = [(r * B, (r + 1) * B) for r in range(world)]     # weak scaling: B objects on every rank
-
     def step():
-        batch.run()
-        packed = D.pack_results(*batch.results())
+        for bt in batches:
+            bt.run()
+        packed = np.concatenate([D.pack_results(*bt.results()) for bt in batches], 0)
         if dist is not None:     # the single collective of the path: results to rank 0 over RCCL / xGMI
             gathered[0] = D.gather_results(packed, shards, dist, device=torch.device("cuda", local_rank))
         else:
@@ -99,35 +199,41 @@ def main():
         step()
     sync()
     t0 = time.perf_counter()
-    fwd_ms = jac_ms = fwd_pts = jac_pts = ren_rows = insphere_pts = 0.0
-    n_fwd = n_jac = 0
+    acc = {}
     for _ in range(args.steps):
         step()
-        st = batch.stats()
-        fwd_ms += st["ms_mlp_fwd"]; jac_ms += st["ms_mlp_jac"]
-        fwd_pts += st["n_fwd_points"]; jac_pts += st["n_jac_points"]; ren_rows += st["n_render_rows"]; insphere_pts += st["n_insphere_points"]
-        n_fwd += st["n_mlp_fwd_launches"]; n_jac += st["n_mlp_jac_launches"]
+        for bt in batches:
+            st = bt.stats()
+            for k, v in st.items():
+                acc[k] = acc.get(k, 0.0) + v if k not in ("prepass_mode", "prepass_delta", "prepass_max_err") else v
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    n_good = int((batch.results()[3] == 0).sum())
+    n_good = int(sum(int((bt.results()[3] == 0).sum()) for bt in batches))
+    n_total = sum(b - a for a, b in shards)
 
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
 
-    value = world * B * args.steps / elapsed
+    value = n_total * args.steps / elapsed
     # fabric bytes per decoded point from the last committed rocprofv3 --pmc pass (tools/rocpd_pmc.py, FETCH_SIZE x 2 on gfx950)
-    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     pmc = json.load(open(pmc_path)) if os.path.exists(pmc_path) else {}
+    fwd_ms, jac_ms, lp_ms = acc["ms_mlp_fwd"], acc["ms_mlp_jac"], acc["ms_mlp_prepass"]
+    fwd_pts, jac_pts, ren_rows, lp_pts = acc["n_fwd_points"], acc["n_jac_points"], acc["n_render_rows"], acc["n_prepass_points"]
+    n_fwd, n_jac, n_lp = acc["n_mlp_fwd_launches"], acc["n_mlp_jac_launches"], acc["n_mlp_prepass_launches"]
+    insphere_pts = acc["n_insphere_points"]
     fwd_tflops = fwd_pts * F_FWD / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else 0.0
+    lp_tflops = lp_pts * F_FWD / (lp_ms * 1e-3) / 1e12 if lp_ms > 0 else 0.0
     # surface points run forward + backward; render rows only the backward sweep (masks come from the forward launches)
     jac_flop = jac_pts * F_JAC + ren_rows * (F_JAC - F_FWD)
     jac_tflops = jac_flop / (jac_ms * 1e-3) / 1e12 if jac_ms > 0 else 0.0
+    mode = int(acc.get("prepass_mode", 0))
     result = {
         "metric": "objects/sec (2000 pts, 64-D code, 10 GN iters)",
         "value": round(value, 3),
@@ -142,11 +248,12 @@ def main():
         "dtype": "f32",
         "data": "synthetic (seeded rounded-box objects, decoder fixture fitted to them; no real weights/datasets offline)",
         "config": {
-            "workload": "cfg2: single KITTI-like car per object -- 2000 surface pts + 500 free-space rays (2500 rays x 50 depth "
-                        "samples), 64-D code, 10 joint GN iterations (Optimizer.reconstruct_object), batch of %d objects per GPU" % B,
+            "workload": workload,
+            "name": args.config,
             "objects_per_gpu": B,
             "objects_good": n_good,
             "parallelism": "object-sharded x%d, one RCCL gather of results per step" % world,
+            "prepass": ["off", "f16", "bf16"][mode] + (" (exact pre-classification of ray samples; results bit-identical to off)" if mode else ""),
         },
         "roofline": {
             "bound": "mfma",
@@ -163,14 +270,33 @@ def main():
             "jac_kernel_tflops": round(jac_tflops, 2),
             "jac_kernel_frac": round(jac_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
             "jac_avg_launch_ms": round(jac_ms / max(n_jac, 1), 4),
-            "whole_path_tflops": round((fwd_pts * F_FWD + jac_flop) / elapsed / 1e12 * world, 2),
+            "whole_path_fp32_tflops": round((fwd_pts * F_FWD + jac_flop) / elapsed / 1e12 * world, 2),
+            "ms_per_step_by_kernel": {"prepass": round(lp_ms / args.steps, 2), "fwd_fp32": round(fwd_ms / args.steps, 2),
+                                      "jacobian_fp32": round(jac_ms / args.steps, 2),
+                                      "other": round((acc["ms_total"] - lp_ms - fwd_ms - jac_ms) / args.steps, 2)},
         },
     }
+    if mode:
+        result["prepass"] = {
+            "bound": "mfma",
+            "kernel": "mlp_lp_kernel<%s> (decoder forward, v_mfma_f32_32x32x16_%s, classification only)" % (("false", "f16") if mode == 1 else ("true", "bf16")),
+            "dtype": "f16" if mode == 1 else "bf16",
+            "achieved": round(lp_tflops, 1),
+            "peak": PEAK_16BIT_MFMA_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": round(lp_tflops / PEAK_16BIT_MFMA_TFLOPS, 4),
+            "avg_launch_ms": round(lp_ms / max(n_lp, 1), 4),
+            "alg_flop_per_launch": round(lp_pts * F_FWD / max(n_lp, 1)),
+            "points_over_insphere": round(lp_pts / max(insphere_pts, 1.0), 4),
+            "delta": acc.get("prepass_delta"),
+            "traffic": pmc.get("lp_fetch_bytes_per_point", 0.0) * lp_pts / max(n_lp, 1) or None,
+        }
 
-    if world == 1:
+    if world == 1 and args.config == "cfg2x64":
         # single-object latency (ms/object p50): batch of ONE cfg2 object
         o = objs[0]
         one = eng.batch(prm, [o["t_cam_obj_init"]], [o["pts"]], [o["rays"]], [o["depth"]])
+        one.set_prepass(PREPASS[args.prepass])
         one.run()
         lat = []
         for _ in range(max(args.latency_runs, 1)):
@@ -180,6 +306,19 @@ def main():
             lat.append((time.perf_counter() - t1) * 1e3)
         one.close()
         result["latency_ms_p50"] = round(statistics.median(lat), 3)
+        # a detection of the reference's real KITTI size (config_kitti.json:17 num_lidar_max 250, kitti_sequence.py:203-205 <= 200 background rays)
+        k = synth.make_object(4242, n_surface=250, n_background=200)
+        one = eng.batch(prm, [k["t_cam_obj_init"]], [k["pts"]], [k["rays"]], [k["depth"]])
+        one.set_prepass(PREPASS[args.prepass])
+        one.run()
+        lat = []
+        for _ in range(max(args.latency_runs, 1)):
+            t1 = time.perf_counter()
+            one.run()
+            one.results()
+            lat.append((time.perf_counter() - t1) * 1e3)
+        one.close()
+        result["latency_kitti_size_ms_p50"] = round(statistics.median(lat), 3)
         # sdf-only workload: Optimizer.estimate_pose_cam_obj on the same objects -- 5 Gauss-Newton iterations of the
         # surface term alone, through the one-shot entry point (host buffers in, so this figure includes upload and download)
         try:
@@ -205,7 +344,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         from oracle import dsp_oracle as O      # checker/baseline only -- never on the product path
         dec = O.fold_decoder(sd, fixtures.SPECS)
-        oprm = O.GNParams()
+        oprm = O.GNParams(**(dict(k1=10.0, k2=100.0, k3=2.5, k4=0.0, b1=0.2, b2=0.02, lr=1.0, s_damp=100.0, num_iterations=5) if args.config == "cfg5" else {}))
         # pick the intra-op thread count that runs a small object fastest (128-thread hosts are slower at 128 than at 16-32)
         small = synth.make_object(999, n_surface=500, n_background=0)
         oprm5 = O.GNParams(num_iterations=2)
@@ -221,22 +360,34 @@ def main():
                 best_threads, best_t = nt, dt_s
         torch.set_num_threads(best_threads)
         o = objs[0]
+        kind, dt = "port", None
+        if args.config != "cfg5" and os.environ.get("DSP_REFERENCE_ROOT"):     # never probed unless asked for: the GPU box has no checkout
+            dt = reference_cpu_baseline(o, best_threads)
+            if dt is not None:
+                kind = "reference"
         t1 = time.perf_counter()
         r = O.reconstruct_object(dec, oprm, o["t_cam_obj_init"], o["pts"], o["rays"], o["depth"])
-        dt = time.perf_counter() - t1
+        dt_port = time.perf_counter() - t1
+        if dt is None:
+            dt = dt_port
         gpu_t = D.unpack_results(gathered[0])[0][0]
         result["cpu_baseline"] = {
             "value": round(1.0 / dt, 4),
             "unit": "objects/s",
             "cores": int(best_threads),
-            "kind": "port",
-            "sample": "1 cfg2 object (seed %d), all 10 GN iterations, oracle/dsp_oracle.py with torch-CPU sgemm on %d of %d host threads "
-                      "(fastest of a small sweep); %.2f s" % (1 + rank * B, best_threads, ncpu, dt),
+            "kind": kind,
+            "sample": "1 %s object (seed %d), all %d GN iterations, %s on %d of %d host threads (fastest of a small sweep); %.2f s%s" % (
+                "cfg5 (4000-pt)" if args.config == "cfg5" else "cfg2", 1 + rank * B, oprm.num_iterations,
+                "the unmodified reference (reconstruct/optimizer.py via oracle/ref_shim.py, torch CPU)" if kind == "reference"
+                else "oracle/dsp_oracle.py with torch-CPU sgemm (no reference checkout on this box: DSP_REFERENCE_ROOT unset)",
+                best_threads, ncpu, dt, "; the oracle port took %.2f s" % dt_port if kind == "reference" else ""),
             "gpu_vs_cpu": round(value * dt, 1),
             "pose_max_abs_diff_vs_gpu": float(np.abs(r["t_cam_obj"] - gpu_t).max()) if r["is_good"] else None,
         }
-    batch.close()
-    eng.close()
+    for bt in batches:
+        bt.close()
+    for e in engines:
+        e.close()
     if dist is not None:
         dist.destroy_process_group()
     try:    # RCCL prints its banner through C stdio; flush it so that the JSON is the LAST line of stdout

@@ -37,7 +37,10 @@ class GnParams(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("n_fwd_points", C.c_double), ("n_jac_points", C.c_double), ("ms_total", C.c_double),
                 ("ms_mlp_fwd", C.c_double), ("ms_mlp_jac", C.c_double),
-                ("n_mlp_fwd_launches", C.c_int32), ("n_mlp_jac_launches", C.c_int32), ("n_insphere_points", C.c_double), ("n_render_rows", C.c_double)]
+                ("n_mlp_fwd_launches", C.c_int32), ("n_mlp_jac_launches", C.c_int32), ("n_insphere_points", C.c_double), ("n_render_rows", C.c_double),
+                ("n_prepass_points", C.c_double), ("ms_mlp_prepass", C.c_double), ("n_mlp_prepass_launches", C.c_int32),
+                ("prepass_mode", C.c_int32), ("prepass_delta", C.c_float), ("prepass_max_err", C.c_float),
+                ("prepass_misclassified", C.c_double), ("prepass_audited", C.c_double)]
 
 
 class DspError(RuntimeError):
@@ -72,6 +75,8 @@ SYMBOLS = [
     ("dsp_batch_set_ray_passes", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_set_ray_pass_bounds", C.c_int, [_VP, c_i32p, C.c_int]),
     ("dsp_batch_set_mask_reuse", C.c_int, [_VP, C.c_int]),
+    ("dsp_batch_set_prepass", C.c_int, [_VP, C.c_int, C.c_float]),
+    ("dsp_batch_set_prepass_audit", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_set_split_rows", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_enable_trace", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_trace", C.c_int, [_VP, C.c_int32, c_f32p, c_f32p, c_f32p, c_i64p, c_i64p, c_i64p, c_f32p, c_f32p, C.POINTER(C.c_uint32), c_f32p]),

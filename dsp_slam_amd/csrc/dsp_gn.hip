@@ -576,6 +576,11 @@ struct dsp_batch {
     int n_ray_passes = 0;     // front-to-back forward passes per iteration (0 = pick from the batch size)
     std::vector<int> pass_bounds;   // optional explicit depth-index boundaries (n_passes + 1 entries, 0 .. D)
     int hint_margin = 2, hint_step = 8;   // adaptive passes: pass 0 = [0, hint + margin), middle pass = next `step` indices
+    int prepass = -1;         // low-precision classification pass in front of the fp32 forward decoder: -1 auto, 0 off, 1 f16, 2 bf16
+    float prepass_delta = -1.f;   // margin added to cut_off on both sides (< 0: the dtype's default)
+    bool prepass_audit = false;   // also decode every sample in fp32 and compare (tests / calibration)
+    DevBuf<float> saudit;
+    DevBuf<unsigned> audit_out;
     DevBuf<float> ray_res, ssdf, sdeds, jgrad, partials, trace, out_t, out_code, out_loss, rows;
     DevBuf<float4> spts, jpts;
     DevBuf<float2> jaux;
@@ -671,7 +676,8 @@ dsp_batch* batch_build(dsp_handle* h, const dsp_gn_params* prm, int B, const int
     b->jgrad.alloc((size_t)cap_j * GRAD_STRIDE);
     b->tiles_j.alloc(cap_j / SPLIT_TILE_PTS + 2 * B);     // sized for the latency form's 16-point tiles
     b->n_tiles.alloc(4);
-    b->counters.alloc(4);
+    b->counters.alloc(8);
+    b->audit_out.alloc(4);
     b->partials.alloc((size_t)B * 2 * b->n_slices * 72 * 72);
     b->gsum.alloc((size_t)B * 2 * 72 * 72);
     b->cbias.alloc((size_t)B * 2 * WIDTH);
@@ -726,11 +732,54 @@ bool use_split_fwd(const dsp_batch* b) {
     return 0.30 * rounds16 <= 0.8 * rounds64;
 }
 
+// Prepass default margins: 4x the largest |sdf_lp - sdf_fp32| measured on the device over the decoder fixtures
+// (tests/test_gpu_prepass.py prints it; profiles/parity_r02.md records it): f16 1.05e-4, bf16 6.8e-4.
+constexpr float PREPASS_DELTA_F16 = 5e-4f, PREPASS_DELTA_BF16 = 3e-3f;
+
+int prepass_mode(const dsp_batch* b) {      // 0 off, 1 f16, 2 bf16
+    if (b->pose_only || !b->h->lp_ok) return 0;
+    if (b->prepass >= 0) return b->prepass;
+    return DSP_PREPASS_F16;
+}
+float prepass_delta(const dsp_batch* b) {
+    if (b->prepass_delta >= 0.f) return b->prepass_delta;
+    return prepass_mode(b) == DSP_PREPASS_BF16 ? PREPASS_DELTA_BF16 : PREPASS_DELTA_F16;
+}
+
 // what: 0 = forward pass over the current sample list (with mask reuse: relu masks of band samples exported), 1 = jacobian
 // launch, forward + backward (with mask reuse the surface points only, else surface points and render rows), 2 = jacobian
 // of the kept render rows, backward only from the exported masks
+// 3 = low-precision prepass over the current sample list, 4 = audit: fp32 forward over every in-sphere sample into saudit
 void launch_decoder(dsp_batch* b, int what, size_t& cursor) {
     dsp_handle* h = b->h;
+    if (what == 3) {
+        const int pm = prepass_mode(b);
+        LpArgs la = make_lp_args(h, pm == DSP_PREPASS_BF16);
+        la.n_tiles = b->n_tiles.p;
+        la.tiles = b->tiles_f.p;
+        la.pts = b->spts.p;
+        la.index = b->plist.p;
+        la.code_bias = b->cbias.p;
+        la.code_bias_stride = 2 * WIDTH;
+        la.out_sdf = b->ssdf.p;
+        hipEvent_t e0 = next_event(b, cursor), e1 = next_event(b, cursor);
+        b->ev_kind.push_back(2);
+        HIP_TRY(hipEventRecord(e0, h->stream));
+        HIP_TRY(launch_mlp_lp(pm == DSP_PREPASS_BF16, la, h->n_cu, h->stream));
+        HIP_TRY(hipEventRecord(e1, h->stream));
+        return;
+    }
+    if (what == 4) {
+        MlpArgs a = make_mlp_args(h, 0);
+        a.n_tiles = b->n_tiles.p + 3;
+        a.tiles = b->tiles_j.p;                 // free at this point of the iteration (the jacobian list is built later)
+        a.pts = b->spts.p;
+        a.code_bias = b->cbias.p;
+        a.code_bias_stride = 2 * WIDTH;
+        a.out_sdf = b->saudit.p;
+        HIP_TRY(launch_mlp(0, a, h->n_cu, h->stream));
+        return;
+    }
     const bool reuse = use_mask_reuse(b);
     const int mode = what == 0 ? (reuse ? 1 : 0) : (what == 1 ? 2 : 3);
     MlpArgs a = make_mlp_args(h, mode);
@@ -787,8 +836,12 @@ void iteration_front(dsp_batch* b, size_t& cursor, bool do_render) {
         //  * automatic (default): per-ray ranges steered by where each ray terminated in the previous GN iteration -- pass 0
         //    decodes [0, hint + 2), a middle pass the next 8 indices (only with enough tiles to fill the chip), the last
         //    pass the rest.  Fewer launches than fixed ranges and less overshoot behind the surface.
+        // With the prepass on, these passes run the LOW-PRECISION kernel (a ray stops behind its first certainly-solid
+        // sample), and one fp32 launch follows over the samples the prepass could not classify (k_band_count).
+        const int pm = prepass_mode(b);
+        const float thd = b->prm.cut_off + prepass_delta(b);
         std::vector<PassSpec> specs;
-        const double tiles = 0.75 * (double)b->cap_s / TILE_PTS;     // expected forward tiles per iteration
+        const double tiles = 0.75 * (double)b->cap_s / (pm ? LP_TILE_PTS : TILE_PTS);     // expected forward tiles per iteration
         int fixed_passes = b->n_ray_passes;
         if (fixed_passes <= 0 && tiles >= 100.0 * h->n_cu) fixed_passes = 10;   // large batches: ten uniform ranges measured best
         if (fixed_passes > 0) {
@@ -807,14 +860,26 @@ void iteration_front(dsp_batch* b, size_t& cursor, bool do_render) {
             for (int p = 0; p < n_passes; ++p)
                 specs.push_back(PassSpec{b->hint_margin, b->hint_step, b->D, p, p == n_passes - 1, b->ray_hint.p, b->ray_plo.p});
         }
+        const int fwd_tile = pm ? LP_TILE_PTS : (use_split_fwd(b) ? SPLIT_TILE_PTS : TILE_PTS);
         for (const PassSpec& ps : specs) {
             launch_pass_select(b->oc.p, b->st.p, b->raymask.p, b->rayoff.p, b->ray_alive.p, b->pcnt.p, ps, b->maxR, B, s);
             launch_scan_rays(b->oc.p, b->st.p, b->pcnt.p, b->poff.p, 2, B, s);
             launch_pass_write(b->oc.p, b->st.p, b->raymask.p, b->rayoff.p, b->ray_alive.p, b->poff.p, b->plist.p, ps, b->maxR, B, s);
-            launch_build_tiles(b->oc.p, b->st.p, B, 2, b->tiles_f.p, b->n_tiles.p, b->counters.p, ps.pass == 0 ? 1 : 0, use_split_fwd(b) ? SPLIT_TILE_PTS : TILE_PTS, s);
-            launch_decoder(b, 0, cursor);
+            launch_build_tiles(b->oc.p, b->st.p, B, 2, b->tiles_f.p, b->n_tiles.p, b->counters.p, ps.pass == 0 ? 1 : 0, fwd_tile, pm ? 4 : 0, s);
+            launch_decoder(b, pm ? 3 : 0, cursor);
             if (!ps.last || ps.hint)
-                launch_pass_update(b->oc.p, b->st.p, b->raymask.p, b->rayoff.p, b->ray_alive.p, b->ssdf.p, b->prm.cut_off, ps, b->maxR, B, s);
+                launch_pass_update(b->oc.p, b->st.p, b->raymask.p, b->rayoff.p, b->ray_alive.p, b->ssdf.p, pm ? thd : b->prm.cut_off, ps, b->maxR, B, s);
+        }
+        if (pm) {
+            if (b->prepass_audit) {
+                b->saudit.ensure(b->cap_s);
+                launch_build_tiles(b->oc.p, b->st.p, B, 0, b->tiles_j.p, b->n_tiles.p + 3, b->counters.p, 0, TILE_PTS, 5, s);
+                launch_decoder(b, 4, cursor);
+                launch_prepass_audit(b->oc.p, b->st.p, b->ssdf.p, b->saudit.p, b->prm.cut_off, thd, b->audit_out.p, B, s);
+            }
+            launch_band_select(b->oc.p, b->st.p, b->raymask.p, b->rayoff.p, b->ssdf.p, thd, b->pcnt.p, b->poff.p, b->plist.p, b->maxR, B, s);
+            launch_build_tiles(b->oc.p, b->st.p, B, 2, b->tiles_f.p, b->n_tiles.p, b->counters.p, 0, use_split_fwd(b) ? SPLIT_TILE_PTS : TILE_PTS, 0, s);
+            launch_decoder(b, 0, cursor);
         }
         launch_render_scan(b->oc.p, b->st.p, b->raymask.p, b->rayoff.p, b->ssdf.p, b->depth.p, b->sdeds.p, b->ray_res.p,
                            b->kcnt.p, b->mcnt.p, b->D, b->prm.cut_off, b->maxR, B, s);
@@ -824,7 +889,7 @@ void iteration_front(dsp_batch* b, size_t& cursor, bool do_render) {
                             b->jpts.p, b->jaux.p, b->maxR, B, s);
     }
     launch_surface(b->oc.p, b->st.p, b->pts.p, b->jpts.p, b->jaux.p, b->maxM, B, s);
-    launch_build_tiles(b->oc.p, b->st.p, B, 1, b->tiles_j.p, b->n_tiles.p + 1, b->counters.p, 0, use_split_rows(b) ? SPLIT_TILE_PTS : TILE_PTS, s);
+    launch_build_tiles(b->oc.p, b->st.p, B, 1, b->tiles_j.p, b->n_tiles.p + 1, b->counters.p, 0, use_split_rows(b) ? SPLIT_TILE_PTS : TILE_PTS, 1, s);
     launch_decoder(b, 1, cursor);
     if (do_render && use_mask_reuse(b)) launch_decoder(b, 2, cursor);
 }
@@ -840,7 +905,8 @@ void batch_run(dsp_batch* b) {
     b->ev_kind.clear();
     hipEvent_t e_start = next_event(b, cursor);
     HIP_TRY(hipEventRecord(e_start, s));
-    HIP_TRY(hipMemsetAsync(b->counters.p, 0, 4 * sizeof(double), s));
+    HIP_TRY(hipMemsetAsync(b->counters.p, 0, 8 * sizeof(double), s));
+    HIP_TRY(hipMemsetAsync(b->audit_out.p, 0, 4 * sizeof(unsigned), s));
     HIP_TRY(hipMemsetAsync(b->st.p, 0, (size_t)B * sizeof(ObjState), s));
     launch_init_state(b->st.p, b->t_in.p, b->have_codes ? b->codes_in.p : nullptr, b->scale_in.p, B, b->D, b->pose_only ? 1 : 0, s);
     if (b->pose_only) HIP_TRY(hipMemsetAsync(b->alive.p, 1, b->cap_j, s));
@@ -862,8 +928,16 @@ void batch_run(dsp_batch* b) {
     // stats
     dsp_stats st;
     memset(&st, 0, sizeof st);
-    double cnt[4];
+    double cnt[8];
     HIP_TRY(hipMemcpy(cnt, b->counters.p, sizeof cnt, hipMemcpyDeviceToHost));
+    unsigned aud[4];
+    HIP_TRY(hipMemcpy(aud, b->audit_out.p, sizeof aud, hipMemcpyDeviceToHost));
+    st.n_prepass_points = cnt[4];
+    st.prepass_mode = prepass_mode(b);
+    st.prepass_delta = st.prepass_mode ? prepass_delta(b) : 0.f;
+    memcpy(&st.prepass_max_err, &aud[0], 4);
+    st.prepass_misclassified = aud[1];
+    st.prepass_audited = aud[2];
     st.n_fwd_points = cnt[0];
     const bool reuse = use_mask_reuse(b);
     st.n_jac_points = reuse ? cnt[1] : cnt[1] + cnt[3];
@@ -874,7 +948,8 @@ void batch_run(dsp_batch* b) {
     st.ms_total = ms;
     for (size_t i = 0; i < b->ev_kind.size(); ++i) {
         HIP_TRY(hipEventElapsedTime(&ms, b->ev[1 + 2 * i], b->ev[2 + 2 * i]));
-        if (b->ev_kind[i]) { st.ms_mlp_jac += ms; st.n_mlp_jac_launches++; }
+        if (b->ev_kind[i] == 1) { st.ms_mlp_jac += ms; st.n_mlp_jac_launches++; }
+        else if (b->ev_kind[i] == 2) { st.ms_mlp_prepass += ms; st.n_mlp_prepass_launches++; }
         else { st.ms_mlp_fwd += ms; st.n_mlp_fwd_launches++; }
     }
     b->stats = st;
@@ -934,7 +1009,8 @@ void run_terms(dsp_handle* h, const float* pts_cam, int64_t n_pts, const float* 
     st.n_alive = -1;
     HIP_TRY(hipMemcpyAsync(b->st.p, &st, sizeof st, hipMemcpyHostToDevice, h->stream));
     if (render) HIP_TRY(hipMemsetAsync(b->ray_hint.p, b->D, b->sum_rays, h->stream));   // no history: decode whole rays in pass 0
-    HIP_TRY(hipMemsetAsync(b->counters.p, 0, 4 * sizeof(double), h->stream));
+    HIP_TRY(hipMemsetAsync(b->counters.p, 0, 8 * sizeof(double), h->stream));
+    HIP_TRY(hipMemsetAsync(b->audit_out.p, 0, 4 * sizeof(unsigned), h->stream));
     size_t cursor = 0;
     b->ev_kind.clear();
     (void)next_event(b.get(), cursor);
@@ -968,7 +1044,7 @@ void run_terms(dsp_handle* h, const float* pts_cam, int64_t n_pts, const float* 
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-int dsp_abi_version(void) { return 1; }
+int dsp_abi_version(void) { return 2; }
 
 /* Development aid: {shader-clock ticks, 100 MHz wall ticks} spent by workgroup 0 of the last dsp_decode_sdf /
  * dsp_sdf_jacobian launch -> effective shader clock under load. */
@@ -1253,6 +1329,20 @@ int dsp_batch_set_ray_pass_bounds(dsp_batch* b, const int32_t* bounds, int n_pas
     for (int p = 0; p < n_passes; ++p) if (bounds[p + 1] < bounds[p]) return DSP_E_ARG;
     b->n_ray_passes = n_passes;
     b->pass_bounds.assign(bounds, bounds + n_passes + 1);
+    return DSP_OK;
+}
+
+int dsp_batch_set_prepass(dsp_batch* b, int mode, float delta) {
+    if (!b || mode < -1 || mode > DSP_PREPASS_BF16 || !(delta < 0.5f)) return DSP_E_ARG;
+    if (mode > 0 && !b->h->lp_ok) return DSP_E_ARG;
+    b->prepass = mode;
+    b->prepass_delta = delta;
+    return DSP_OK;
+}
+
+int dsp_batch_set_prepass_audit(dsp_batch* b, int on) {
+    if (!b) return DSP_E_ARG;
+    b->prepass_audit = on != 0;
     return DSP_OK;
 }
 

@@ -165,7 +165,11 @@ void launch_sample_write(const ObjConst* oc, const ObjState* st, const float* ra
                          float* ssdf, unsigned char* alive, int D, int maxR, int B, hipStream_t s);
 void launch_surface(const ObjConst* oc, const ObjState* st, const float* pts, float4* jpts, float2* jaux, int maxM, int B, hipStream_t s);
 void launch_build_tiles(const ObjConst* oc, const ObjState* st, int B, int mode, int4* tiles, int* n_tiles, double* counters, int add_v, int tile_pts,
-                        hipStream_t s);
+                        int cnt_slot, hipStream_t s);   // cnt_slot: counter the point count of a mode 0 / 2 list is added to
+void launch_band_select(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff, const float* ssdf, float thd,
+                        int* pcnt, int* poff, int* plist, int maxR, int B, hipStream_t s);
+void launch_prepass_audit(const ObjConst* oc, const ObjState* st, const float* ssdf, const float* saudit, float th, float thd, unsigned* out,
+                          int B, hipStream_t s);
 void launch_render_scan(const ObjConst* oc, ObjState* st, const unsigned long long* m, const int* off, const float* ssdf, const float* depth,
                         float* sdeds, float* ray_res, int* kcnt, int* mcnt, int D, float th, int maxR, int B, hipStream_t s);
 void launch_render_write(const ObjConst* oc, const ObjState* st, const int* raycnt, const int* rayoff, const int* koff, const float4* spts,

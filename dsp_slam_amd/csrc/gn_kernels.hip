@@ -300,6 +300,78 @@ __global__ void k_pass_update(const ObjConst* oc, const ObjState* st, const unsi
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// prepass: which samples still need the fp32 decoder
+// ------------------------------------------------------------------------------------------------
+// After the low-precision front-to-back passes ssdf holds sdf_lp for every sample they decoded (+1 elsewhere).  With
+// |sdf_lp - sdf_fp32| < delta (calibrated margin), sdf_lp >= th + delta means occupancy exactly 0 and sdf_lp <= -(th + delta)
+// means occupancy exactly 1 (loss_utils.py:40-48) -- and behind the first such sample of a ray the transmittance is exactly
+// 0, so nothing there can reach the result.  What is left for the fp32 kernel: the samples IN FRONT of a ray's first
+// certainly-solid sample whose |sdf_lp| < th + delta.  Their exact values then replace the low-precision ones in ssdf; the
+// classified samples keep sdf_lp (any value beyond +-th gives the same occupancy bit for bit).
+__global__ void k_band_count(const ObjConst* oc, const ObjState* st, const unsigned long long* raymask, const int* rayoff,
+                             const float* ssdf, float thd, int* pcnt) {
+    const int b = blockIdx.y;
+    const ObjConst c = oc[b];
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= c.n_rays) return;
+    const int gr = c.ray_off + r;
+    int n = 0;
+    if (st[b].status == DSP_STATUS_GOOD) {
+        const int cnt = __popcll(raymask[gr]);
+        const float* sd = ssdf + c.samp_off + rayoff[gr];
+        for (int i = 0; i < cnt; ++i) {
+            const float v = sd[i];
+            if (v <= -thd) break;
+            n += (fabsf(v) < thd) ? 1 : 0;
+        }
+    }
+    pcnt[gr] = n;
+}
+
+__global__ void k_band_write(const ObjConst* oc, const ObjState* st, const unsigned long long* raymask, const int* rayoff,
+                             const float* ssdf, float thd, const int* poff, int* plist) {
+    const int b = blockIdx.y;
+    const ObjConst c = oc[b];
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= c.n_rays) return;
+    const int gr = c.ray_off + r;
+    if (st[b].status != DSP_STATUS_GOOD) return;
+    const int cnt = __popcll(raymask[gr]);
+    const int base = c.samp_off + rayoff[gr];
+    int* dst = plist + c.samp_off + poff[gr];
+    for (int i = 0; i < cnt; ++i) {
+        const float v = ssdf[base + i];
+        if (v <= -thd) break;
+        if (fabsf(v) < thd) *dst++ = base + i;
+    }
+}
+
+// audit (tests / calibration): saudit = fp32 sdf of EVERY in-sphere sample, ssdf = prepass values (+1 where not decoded).
+// out[0] = max |sdf_lp - sdf_fp32| (float bits), out[1] = samples the prepass classified against the fp32 value
+// (sdf_lp >= thd but sdf_fp32 < th, or sdf_lp <= -thd but sdf_fp32 > -th), out[2] = samples compared.
+__global__ void k_prepass_audit(const ObjConst* oc, const ObjState* st, const float* ssdf, const float* saudit, float th, float thd,
+                                unsigned* out) {
+    const int b = blockIdx.y;
+    const ObjConst c = oc[b];
+    const ObjState& s = st[b];
+    if (s.status != DSP_STATUS_GOOD) return;
+    float worst = 0.f;
+    unsigned bad = 0, n = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < s.V; i += gridDim.x * blockDim.x) {
+        const float lp = ssdf[c.samp_off + i], ex = saudit[c.samp_off + i];
+        if (lp == 1.0f) continue;                       // not decoded by the prepass
+        ++n;
+        worst = fmaxf(worst, fabsf(lp - ex));
+        if ((lp >= thd && ex < th) || (lp <= -thd && ex > -th)) ++bad;
+    }
+    if (n) {
+        atomicMax(out + 0, __float_as_uint(worst));
+        if (bad) atomicAdd(out + 1, bad);
+        atomicAdd(out + 2, n);
+    }
+}
+
 // surface points -> object frame (loss.py:31-32); also the pose-only inlier bookkeeping (optimizer.py:76-78)
 __global__ void k_surface(const ObjConst* oc, const ObjState* st, const float* pts, float4* jpts, float2* jaux) {
     const int b = blockIdx.y;
@@ -318,7 +390,7 @@ __global__ void k_surface(const ObjConst* oc, const ObjState* st, const float* p
 // tile lists for the decoder kernels (single workgroup; counts live on the device)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_build_tiles(const ObjConst* oc, const ObjState* st, int n_obj, int mode, int4* tiles,
-                                                     int* n_tiles, double* counters, int add_v, int tile_pts) {
+                                                     int* n_tiles, double* counters, int add_v, int tile_pts, int cnt_slot) {
     // mode 0: forward tiles over the V in-sphere samples; mode 1: jacobian tiles over M surface + K render points;
     // mode 2: forward tiles over the P samples selected for the current front-to-back pass (indexed through plist)
     __shared__ int base;
@@ -356,7 +428,7 @@ __global__ __launch_bounds__(256) void k_build_tiles(const ObjConst* oc, const O
     if (threadIdx.x == 0) {
         n_tiles[0] = base;
         if (mode == 1) n_tiles[1] = n_surface_tiles;
-        counters[mode == 2 ? 0 : mode] += cnt;
+        counters[mode == 1 ? 1 : cnt_slot] += cnt;
         if (add_v) counters[2] += vtot;
         if (mode == 1) counters[3] += rows;
     }
@@ -990,12 +1062,22 @@ void launch_pass_update(const ObjConst* oc, const ObjState* st, const unsigned l
     hipLaunchKernelGGL(k_pass_update, GRID2(maxR, B), dim3(256), 0, s, oc, st, raymask, rayoff, alive, ssdf, th, ps.j0, ps.j1, ps.n_depth,
                        ps.pass, ps.last, ps.hint, ps.plo);
 }
+void launch_band_select(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff, const float* ssdf, float thd,
+                        int* pcnt, int* poff, int* plist, int maxR, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_band_count, GRID2(maxR, B), dim3(256), 0, s, oc, st, raymask, rayoff, ssdf, thd, pcnt);
+    hipLaunchKernelGGL(k_scan_rays, dim3(B), dim3(256), 0, s, oc, st, pcnt, poff, 2);
+    hipLaunchKernelGGL(k_band_write, GRID2(maxR, B), dim3(256), 0, s, oc, st, raymask, rayoff, ssdf, thd, poff, plist);
+}
+void launch_prepass_audit(const ObjConst* oc, const ObjState* st, const float* ssdf, const float* saudit, float th, float thd, unsigned* out,
+                          int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_prepass_audit, dim3(64, B), dim3(256), 0, s, oc, st, ssdf, saudit, th, thd, out);
+}
 void launch_surface(const ObjConst* oc, const ObjState* st, const float* pts, float4* jpts, float2* jaux, int maxM, int B, hipStream_t s) {
     hipLaunchKernelGGL(k_surface, GRID2(maxM, B), dim3(256), 0, s, oc, st, pts, jpts, jaux);
 }
 void launch_build_tiles(const ObjConst* oc, const ObjState* st, int B, int mode, int4* tiles, int* n_tiles, double* counters, int add_v, int tile_pts,
-                        hipStream_t s) {
-    hipLaunchKernelGGL(k_build_tiles, dim3(1), dim3(256), 0, s, oc, st, B, mode, tiles, n_tiles, counters, add_v, tile_pts);
+                        int cnt_slot, hipStream_t s) {
+    hipLaunchKernelGGL(k_build_tiles, dim3(1), dim3(256), 0, s, oc, st, B, mode, tiles, n_tiles, counters, add_v, tile_pts, cnt_slot);
 }
 void launch_render_scan(const ObjConst* oc, ObjState* st, const unsigned long long* m, const int* off, const float* ssdf, const float* depth,
                         float* sdeds, float* ray_res, int* kcnt, int* mcnt, int D, float th, int maxR, int B, hipStream_t s) {

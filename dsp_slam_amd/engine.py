@@ -75,6 +75,14 @@ class Batch(object):
         """-1 = automatic, 0 = render rows share the surface points' forward+backward launch, 1 = backward-only from exported masks."""
         L.check(L.load().dsp_batch_set_mask_reuse(self._h, int(mode)), self.engine._h, "dsp_batch_set_mask_reuse")
 
+    def set_prepass(self, mode=-1, delta=-1.0):
+        """Low-precision pre-classification of the forward ray samples: -1 automatic, 0 off, 1 f16, 2 bf16; delta < 0 = default margin.
+        Results are bit-identical for every setting whose delta exceeds the decoder's prepass error."""
+        L.check(L.load().dsp_batch_set_prepass(self._h, int(mode), float(delta)), self.engine._h, "dsp_batch_set_prepass")
+
+    def set_prepass_audit(self, on=True):
+        L.check(L.load().dsp_batch_set_prepass_audit(self._h, int(bool(on))), self.engine._h, "dsp_batch_set_prepass_audit")
+
     def set_split_rows(self, mode):
         """-1 = automatic, 0 = 64-point throughput tiles, 1 = 16-point latency tiles for the jacobian launch (when mask reuse is off)."""
         L.check(L.load().dsp_batch_set_split_rows(self._h, int(mode)), self.engine._h, "dsp_batch_set_split_rows")

@@ -77,6 +77,15 @@ typedef struct dsp_stats {
     int32_t n_mlp_jac_launches;
     double n_insphere_points;    /* sum over iterations and objects of V, the in-sphere sample count the reference decodes */
     double n_render_rows;        /* render rows that ran the backward sweep only (mask reuse on): sum of K, else 0 */
+    /* prepass (ABI version 2): with it on, n_fwd_points counts only the samples that still needed the fp32 kernel */
+    double n_prepass_points;     /* samples decoded by the low-precision prepass kernel */
+    double ms_mlp_prepass;       /* summed time of the prepass kernel launches */
+    int32_t n_mlp_prepass_launches;
+    int32_t prepass_mode;        /* DSP_PREPASS_* the run used */
+    float prepass_delta;         /* margin the run used: samples with |sdf_lp| < cut_off + delta went to the fp32 kernel */
+    float prepass_max_err;       /* audit only: max |sdf_lp - sdf_fp32| over the audited samples */
+    double prepass_misclassified;/* audit only: samples classified against their fp32 value (must be 0) */
+    double prepass_audited;      /* audit only: samples compared */
 } dsp_stats;
 
 /* ---- lifetime --------------------------------------------------------------------------------- */
@@ -164,10 +173,22 @@ int dsp_batch_stats(dsp_batch* b, dsp_stats* out);
 /* Number of front-to-back depth ranges the forward decoder is run in per iteration (exact early ray termination: a ray
  * stops being sampled behind its first solid sample, where the transmittance is exactly 0).  0 = automatic (ten uniform
  * ranges for large batches; otherwise 2-3 per-ray ranges steered by where each ray stopped in the previous iteration); 1 = decode every in-sphere sample like the reference does.  Results are identical
- * for every setting. */
+ * for every setting.  With the prepass on (dsp_batch_set_prepass) these are the ranges of the low-precision kernel; the fp32 kernel then
+ * runs once per iteration over the samples the prepass could not classify. */
 int dsp_batch_set_ray_passes(dsp_batch* b, int n_passes);
 /* The same with explicit depth-index boundaries: bounds[0] = 0 <= ... <= bounds[n_passes] = num_depth_samples. */
 int dsp_batch_set_ray_pass_bounds(dsp_batch* b, const int32_t* bounds, int n_passes);
+/* Exact low-precision pre-classification of the forward ray samples.  The render term only sees clamp(sdf, -cut_off, cut_off)
+ * (reconstruct/loss_utils.py:40-48): occupancy is exactly 0 for sdf >= cut_off and exactly 1 for sdf <= -cut_off.  With the
+ * prepass on, every candidate sample is first decoded by an f16 (or bf16) MFMA kernel at 16x the fp32 matrix rate; samples with
+ * |sdf_lp| >= cut_off + delta are classified by that value alone, rays stop behind their first certainly-solid sample, and only the
+ * samples inside the widened band are decoded by the fp32 kernel (one launch per iteration).  delta must exceed the largest
+ * |sdf_lp - sdf_fp32| of the decoder (dsp_decode_sdf_prepass / the audit below measure it; default = 4x the measured maximum of
+ * the dtype: 5e-4 f16, 3e-3 bf16); results are then identical, bit for bit, to prepass off.
+ * mode: -1 automatic (f16 when the decoder geometry is supported), DSP_PREPASS_OFF / _F16 / _BF16; delta < 0 = default. */
+int dsp_batch_set_prepass(dsp_batch* b, int mode, float delta);
+/* Audit: every run also decodes all in-sphere samples in fp32 and fills dsp_stats.prepass_max_err / _misclassified / _audited. */
+int dsp_batch_set_prepass_audit(dsp_batch* b, int on);
 /* Render rows (kept ray samples) need the decoder's input gradient at points the forward launches of the same iteration
  * already decoded.  With mask reuse on, those launches export the relu masks of band samples (|sdf| < cut_off, 512 B each)
  * and the render rows run the backward sweep only, in a launch of their own after the surface points' forward + backward

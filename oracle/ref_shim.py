@@ -57,8 +57,9 @@ class _Dict(dict):
 _installed = False
 
 
-def install():
-    """Make `import reconstruct...` / `import deep_sdf...` resolve to the reference."""
+def install(force_cpu=False):
+    """Make `import reconstruct...` / `import deep_sdf...` resolve to the reference.
+    force_cpu: neutralise the reference's `.cuda()` calls even when a GPU is visible (the CPU-baseline leg of bench.py)."""
     global _installed
     if _installed:
         return
@@ -82,7 +83,7 @@ def install():
     sys.modules["skimage"] = sk
     sys.modules["skimage.measure"] = sk.measure
 
-    if not torch.cuda.is_available():
+    if force_cpu or not torch.cuda.is_available():
         torch.Tensor.cuda = lambda self, *a, **k: self
         torch.nn.Module.cuda = lambda self, *a, **k: self
         torch.cuda.synchronize = lambda *a, **k: None

@@ -197,6 +197,7 @@ def test_early_ray_termination_is_exact(eng):
     evaluated = {}
     for n_passes in (1, 0, 2, 5, 10, 50):      # 0 = automatic: per-ray ranges steered by the previous iteration's hits
         b = eng.batch(prm, *args, trace=True)
+        b.set_prepass(0)              # this test is about the fp32 passes (tests/test_gpu_prepass.py covers the prepass)
         b.set_ray_passes(n_passes)
         b.run()
         res = b.results()
