@@ -285,8 +285,8 @@ bool pack_decoder_lp_host(PackedLp* out, const dsp_decoder_desc* d, bool bf) {
         const int od = d->out_dims[k], id = d->in_dims[k];
         const float* W = d->weights[k];
         p.kind = (int16_t)(k == 0 ? 0 : (k == lat ? 2 : 1));
-        p.nog = (int16_t)((od + 63) / 64);
-        if (p.nog != NOG && p.nog != NOG - 1) return false;
+        if ((od + 63) / 64 != NOG && (od + 63) / 64 != NOG - 1) return false;
+        p.nog = NOG;               // the layer in front of the latent_in layer is padded with zero rows: every pass is the same straight-line code
         p.nchunks = (int16_t)(k == 0 ? 1 : NCH);
         p.bias_row = (int16_t)(k == 0 ? -3 : (k == lat ? -2 : k - 1));
         p.npad = (int16_t)(k == lat ? xyz0 - lat_ksteps : 0);

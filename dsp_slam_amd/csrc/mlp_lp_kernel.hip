@@ -32,6 +32,9 @@ typedef __bf16 b2 __attribute__((ext_vector_type(2)));
 
 constexpr int LP_PREFETCH = 2;     // A fragments are read this many k-steps ahead of their MFMAs (4 rotating buffers)
 constexpr int LP_KSTEP_BYTES = 2048;   // two 1 KiB A fragments (row tiles 2g, 2g+1) per k-step
+constexpr int LP_NCH = 4;              // chunks per output group of a hidden layer: 32 k-steps = 512 slab rows
+constexpr int LP_NOG = 8;              // 64-row output groups per layer
+constexpr int LP_ZERO_BYTES = WIDTH * 4;
 
 template <bool BF>
 __device__ __forceinline__ f32x16 lp_mfma(u32x4 a, u32x4 b, f32x16 c) {
@@ -86,125 +89,121 @@ __device__ __forceinline__ void lp_load_rows(const float* tab, int g, int hh, f3
         }
 }
 
-// relu + round + pack accumulator pairs [q0, q1) of output group g into the next layer's input slab:
+// relu + round + pack accumulator pairs [q0, q1) of output group g into the next layer's input slab, and the same values
+// times the rows of `w` into the final-layer dot product (w = 0 except in the last hidden layer):
 // pair q of row tile j = registers (2 q, 2 q + 1) -> k-step 2 (2 g + j) + (q >> 2), component q & 3.
 // (g, q0, q1 are compile-time constants after the callers' loops are unrolled; the loop bounds here are literal so that
 // every register index folds.)
 template <bool BF>
-__device__ __forceinline__ void lp_epilogue(int g, int q0, int q1, const f32x16 (&acc)[2], u32x4 (&out)[32]) {
+__device__ __forceinline__ void lp_epilogue(int g, int q0, int q1, const f32x16 (&acc)[2], const float* dp, int hh, u32x4 (&out)[32], float& part) {
+    // quad qd = 4 consecutive accumulator registers of row tile j = rows 64 g + 32 j + 8 i + 4 hh + 0..3 = one float4 of the dot row
 #pragma unroll
-    for (int qq = 0; qq < 16; ++qq) {
-        if (qq >= q0 && qq < q1) {
-            const int j = qq >> 3, q = qq & 7;
-            const float lo = relu1(acc[j][2 * q]), hi = relu1(acc[j][2 * q + 1]);
-            out[2 * (2 * g + j) + (q >> 2)][q & 3] = lp_pack<BF>(lo, hi);
+    for (int qd = 0; qd < 8; ++qd) {
+        if (qd >= q0 && qd < q1) {
+            const int j = qd >> 2, i = qd & 3;
+            const f32x4 w = *reinterpret_cast<const f32x4*>(dp + 64 * g + 32 * j + 8 * i + 4 * hh);
+            const float v0 = relu1(acc[j][4 * i + 0]), v1 = relu1(acc[j][4 * i + 1]), v2 = relu1(acc[j][4 * i + 2]), v3 = relu1(acc[j][4 * i + 3]);
+            out[2 * (2 * g + j) + (i >> 1)][2 * (i & 1) + 0] = lp_pack<BF>(v0, v1);
+            out[2 * (2 * g + j) + (i >> 1)][2 * (i & 1) + 1] = lp_pack<BF>(v2, v3);
+            part = fmaf(v0, w.x, part);
+            part = fmaf(v1, w.y, part);
+            part = fmaf(v2, w.z, part);
+            part = fmaf(v3, w.w, part);
         }
     }
 }
 
-// One dense layer: out = relu(W . in + bias) for this wave's 32 points.  `in` / `out` are the two register slabs.
-// MODE 0 = first layer (one chunk per group: the xyz k-steps), 1 = hidden / latent_in layer, 2 = last hidden layer (the
-// 512 -> 1 layer + tanh follow on the VALU instead of the slab epilogue).  Compile-time, so that a pass is straight-line code
-// between its (at most one) conditional group.
-template <bool BF, int NCH, int MODE>
+// One dense layer: out = relu(W . in + bias) for this wave's 32 points; part += relu(.) . dot row.  `in` / `out` are the two
+// register slabs.  A pass is 8 output groups x NCH chunks of straight-line code: everything that differs between layers is
+// data (bias / dot-row pointers, prologue selects) -- hipcc answers run-time control flow inside this body with hundreds of
+// register moves at every join.  NCH = 1 for the first layer (its K is the xyz k-steps only), LP_NCH for the others.
+template <bool BF, int NCH>
 __device__ __forceinline__ void lp_pass(const LpPass pd, u32x4 (&in)[32], u32x4 (&out)[32], f32x16 (&acc)[2][2],
-                                        u32x4 (&abuf)[4][2], LpRing& rg, const u32x4 (&xb)[LP_XYZ_KSTEPS], const float* bias_l,
-                                        const float* cb_l, const float* wl, int lane, int hh, float& part) {
-    const bool last = MODE < 0 ? pd.last != 0 : MODE == 2;     // MODE -1: everything from the pass descriptor at run time
-    const int nch = MODE < 0 ? (int)pd.nchunks : (MODE == 0 ? 1 : NCH);
+                                        u32x4 (&abuf)[4][2], LpRing& rg, const u32x4 (&xb)[LP_XYZ_KSTEPS], const float* bp,
+                                        const float* dp, int lane, int hh, float& part) {
     // ---- prologue: place the xyz B operands at their fixed k-steps ---------------------------------------------------
     // first layer: k-steps 0, 1 (the rest of its single chunk is padding); latent_in layer: the last two k-steps, behind the
     // slab rows and pd.npad padding k-steps.  Padding k-steps meet zero A fragments: clear them so that no stale inf / nan
-    // of an earlier layer does.
-    // (Written as selects, not branches: hipcc sinks the stores of two branches into one store through a pointer phi, which
-    // pins the whole slab in scratch memory.)
+    // of an earlier layer does.  (Selects, not branches: hipcc sinks the stores of two branches into one store through a
+    // pointer phi, which pins the whole slab in scratch memory.)
     {
         const u32x4 zero = (u32x4){0u, 0u, 0u, 0u};
-        const bool first = pd.kind == 0, lat = pd.kind == 2;
+        if (NCH == 1) {
 #pragma unroll
-        for (int s = 0; s < LP_KSTEPS_PER_CHUNK; ++s) in[s] = first ? (s < LP_XYZ_KSTEPS ? xb[s < LP_XYZ_KSTEPS ? s : 0] : zero) : in[s];
+            for (int s = 0; s < LP_KSTEPS_PER_CHUNK; ++s) in[s] = s < LP_XYZ_KSTEPS ? xb[s < LP_XYZ_KSTEPS ? s : 0] : zero;
+        } else {
+            const bool lat = pd.kind == 2;
 #pragma unroll
-        for (int u = 0; u < LP_XYZ_KSTEPS; ++u) in[8 * NCH - LP_XYZ_KSTEPS + u] = lat ? xb[u] : in[8 * NCH - LP_XYZ_KSTEPS + u];
+            for (int u = 0; u < LP_XYZ_KSTEPS; ++u) in[8 * NCH - LP_XYZ_KSTEPS + u] = lat ? xb[u] : in[8 * NCH - LP_XYZ_KSTEPS + u];
 #pragma unroll
-        for (int t = 1; t <= 3; ++t)
-            in[8 * NCH - LP_XYZ_KSTEPS - t] = (lat && pd.npad >= t) ? zero : in[8 * NCH - LP_XYZ_KSTEPS - t];
+            for (int t = 1; t <= 3; ++t)
+                in[8 * NCH - LP_XYZ_KSTEPS - t] = (lat && pd.npad >= t) ? zero : in[8 * NCH - LP_XYZ_KSTEPS - t];
+        }
     }
-    const float* bp = pd.bias_row == -2 ? cb_l + WIDTH : (pd.bias_row == -3 ? cb_l : bias_l + pd.bias_row * WIDTH);
     f32x16 bias[2];
     lp_load_rows(bp, 0, hh, bias);
 
-    // Output groups: every pass has NOG = 2 NCH groups except the layer in front of the latent_in layer, which has one fewer
-    // (its last 64 rows are the space the re-injected input takes).  Only the last group is conditional, and no slab store
-    // is: hipcc turns stores to slab slots selected by a run-time group count into dynamically indexed scratch accesses.
-    constexpr int NOG = 2 * NCH;
 #pragma unroll
-    for (int g = 0; g < NOG; ++g) {
-        if (g < NOG - 1 || pd.nog == NOG) {
-            const int par = g & 1;
+    for (int g = 0; g < LP_NOG; ++g) {
+        const int par = g & 1;
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                if (c < nch) {
-                    const int nx_slot = (rg.rd_slot + 1 == LP_NBUF) ? 0 : rg.rd_slot + 1;
-                    const char* cbp = rg.ring_ptr + rg.rd_slot * CHUNK_BYTES + lane * 16;
-                    const char* nbp = rg.ring_ptr + nx_slot * CHUNK_BYTES + lane * 16;
+        for (int c = 0; c < NCH; ++c) {
+            const int nx_slot = (rg.rd_slot + 1 == LP_NBUF) ? 0 : rg.rd_slot + 1;
+            const char* cbp = rg.ring_ptr + rg.rd_slot * CHUNK_BYTES + lane * 16;
+            const char* nbp = rg.ring_ptr + nx_slot * CHUNK_BYTES + lane * 16;
 #pragma unroll
-                    for (int sl = 0; sl < LP_KSTEPS_PER_CHUNK; ++sl) {
-                        const int s = LP_KSTEPS_PER_CHUNK * c + sl;
-                        if (sl == LP_KSTEPS_PER_CHUNK / 2) {
-                            // chunk q+1 has landed for this wave once <= LP_NBUF-3 younger chunks are in flight; the barrier
-                            // publishes every wave's quarter and proves all reads of chunk q-1 retired (mlp_kernel.hip)
-                            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(GLDS_PER_CHUNK * (LP_NBUF - 3)) : "memory");
-                        }
-                        const int sp = sl + LP_PREFETCH;
-                        const char* src = (sp < LP_KSTEPS_PER_CHUNK) ? cbp + sp * LP_KSTEP_BYTES : nbp + (sp - LP_KSTEPS_PER_CHUNK) * LP_KSTEP_BYTES;
-                        abuf[sp % 4][0] = *reinterpret_cast<const u32x4*>(src);
-                        abuf[sp % 4][1] = *reinterpret_cast<const u32x4*>(src + 1024);
-                        const u32x4 a0 = abuf[sl % 4][0], a1 = abuf[sl % 4][1];
-                        const u32x4 b = in[s];
-                        acc[par][0] = lp_mfma<BF>(a0, b, s == 0 ? bias[0] : acc[par][0]);
-                        // refill of the slot freed by the barrier above: one DMA piece per k-step, behind an MFMA
-                        if (sl == LP_KSTEPS_PER_CHUNK / 2 + 0) glds_piece<0>(rg.isrc, rg.idst);
-                        if (sl == LP_KSTEPS_PER_CHUNK / 2 + 1) glds_piece<1>(rg.isrc, rg.idst);
-                        if (sl == LP_KSTEPS_PER_CHUNK / 2 + 2) glds_piece<2>(rg.isrc, rg.idst);
-                        if (sl == LP_KSTEPS_PER_CHUNK / 2 + 3) { glds_piece<3>(rg.isrc, rg.idst); lp_issue_next(rg); }
-                        acc[par][1] = lp_mfma<BF>(a1, b, s == 0 ? bias[1] : acc[par][1]);
-                        if (s == 1 && g + 1 < NOG) lp_load_rows(bp, g + 1, hh, bias);   // the next group's bias, a whole group ahead
-                        // epilogue of the previous group, three accumulator pairs per k-step behind this group's MFMAs
-                        if (g > 0 && !last) {
-                            if (s == 2) lp_epilogue<BF>(g - 1, 0, 3, acc[par ^ 1], out);
-                            if (s == 3) lp_epilogue<BF>(g - 1, 3, 6, acc[par ^ 1], out);
-                            if (s == 4) lp_epilogue<BF>(g - 1, 6, 9, acc[par ^ 1], out);
-                            if (s == 5) lp_epilogue<BF>(g - 1, 9, 12, acc[par ^ 1], out);
-                            if (s == 6) lp_epilogue<BF>(g - 1, 12, 15, acc[par ^ 1], out);
-                            if (s == 7) lp_epilogue<BF>(g - 1, 15, 16, acc[par ^ 1], out);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    rg.rd_slot = nx_slot;
+            for (int sl = 0; sl < LP_KSTEPS_PER_CHUNK; ++sl) {
+                const int s = LP_KSTEPS_PER_CHUNK * c + sl;
+                if (sl == LP_KSTEPS_PER_CHUNK / 2) {
+                    // chunk q+1 has landed for this wave once <= LP_NBUF-3 younger chunks are in flight; the barrier
+                    // publishes every wave's quarter and proves all reads of chunk q-1 retired (mlp_kernel.hip)
+#if defined(LP_ABL_NOBAR)
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GLDS_PER_CHUNK * (LP_NBUF - 3)) : "memory");
+#else
+                    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(GLDS_PER_CHUNK * (LP_NBUF - 3)) : "memory");
+#endif
                 }
+                const int sp = sl + LP_PREFETCH;
+                const char* src = (sp < LP_KSTEPS_PER_CHUNK) ? cbp + sp * LP_KSTEP_BYTES : nbp + (sp - LP_KSTEPS_PER_CHUNK) * LP_KSTEP_BYTES;
+#if !defined(LP_ABL_NOLDS)
+                abuf[sp % 4][0] = *reinterpret_cast<const u32x4*>(src);
+                abuf[sp % 4][1] = *reinterpret_cast<const u32x4*>(src + 1024);
+#endif
+                const u32x4 a0 = abuf[sl % 4][0], a1 = abuf[sl % 4][1];
+                const u32x4 b = in[s];
+#if !defined(LP_ABL_NOMFMA)
+                acc[par][0] = lp_mfma<BF>(a0, b, s == 0 ? bias[0] : acc[par][0]);
+#endif
+#if !defined(LP_ABL_NOISSUE)
+                // refill of the slot freed by the barrier above: one DMA piece per k-step, behind an MFMA
+                if (sl == LP_KSTEPS_PER_CHUNK / 2 + 0) glds_piece<0>(rg.isrc, rg.idst);
+                if (sl == LP_KSTEPS_PER_CHUNK / 2 + 1) glds_piece<1>(rg.isrc, rg.idst);
+                if (sl == LP_KSTEPS_PER_CHUNK / 2 + 2) glds_piece<2>(rg.isrc, rg.idst);
+                if (sl == LP_KSTEPS_PER_CHUNK / 2 + 3) { glds_piece<3>(rg.isrc, rg.idst); lp_issue_next(rg); }
+#endif
+#if !defined(LP_ABL_NOMFMA)
+                acc[par][1] = lp_mfma<BF>(a1, b, s == 0 ? bias[1] : acc[par][1]);
+#endif
+                if (s == LP_KSTEPS_PER_CHUNK * NCH - 2 && g + 1 < LP_NOG) lp_load_rows(bp, g + 1, hh, bias);   // the next group's bias, two k-steps ahead
+#if !defined(LP_ABL_NOEPI)
+                // epilogue of the previous group, two accumulator quads per k-step behind this group's MFMAs
+                if (g > 0) {
+                    if (s == 2) lp_epilogue<BF>(g - 1, 0, 2, acc[par ^ 1], dp, hh, out, part);
+                    if (s == 3) lp_epilogue<BF>(g - 1, 2, 4, acc[par ^ 1], dp, hh, out, part);
+                    if (s == 4) lp_epilogue<BF>(g - 1, 4, 6, acc[par ^ 1], dp, hh, out, part);
+                    if (s == 5) lp_epilogue<BF>(g - 1, 6, 8, acc[par ^ 1], dp, hh, out, part);
+                }
+#endif
+                __builtin_amdgcn_sched_barrier(0);
             }
-            if (last) {
-                // final layer (512 -> 1) on the VALU, straight from the fp32 accumulators  (deep_sdf_decoder.py:93,107-108)
-                f32x16 w[2];
-                lp_load_rows(wl, g, hh, w);
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) part = fmaf(relu1(acc[par][j][r]), w[j][r], part);
-            }
+            rg.rd_slot = nx_slot;
         }
     }
-    // The last group's epilogue has no MFMAs of its own pass to hide behind.  Unconditional for the last TWO groups: with
-    // NOG groups, group NOG-2 is merely converted again (same accumulators, same result); with NOG-1 groups, group NOG-1
-    // converts stale accumulators into slab k-steps 4 NOG - 4 .. 4 NOG - 1, exactly the padding + xyz k-steps the latent_in
-    // layer's prologue overwrites.
-    if (!last) {
-        lp_epilogue<BF>(NOG - 2, 0, 16, acc[(NOG - 2) & 1], out);
-        lp_epilogue<BF>(NOG - 1, 0, 16, acc[(NOG - 1) & 1], out);
-    }
+    // the last group's epilogue has no MFMAs of its own pass to hide behind
+    lp_epilogue<BF>(LP_NOG - 1, 0, 8, acc[(LP_NOG - 1) & 1], dp, hh, out, part);
 }
 
-template <bool BF, int NCH>
+template <bool BF>
 __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -215,12 +214,14 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpArgs a) {
 
     float* bias_l = reinterpret_cast<float*>(smem);
     float* cb_l = reinterpret_cast<float*>(smem + BIAS_BYTES);
-    char* ring_ptr = smem + BIAS_BYTES + CODEBIAS_BYTES;
+    float* zero_l = reinterpret_cast<float*>(smem + BIAS_BYTES + CODEBIAS_BYTES);     // a row of zeros: the "final-layer weights" of every layer but the last
+    char* ring_ptr = smem + BIAS_BYTES + CODEBIAS_BYTES + LP_ZERO_BYTES;
 
     const int n_tiles = *a.n_tiles;
     if ((int)blockIdx.x >= n_tiles) return;
     if (a.clk && blockIdx.x == 0 && tid == 0) { a.clk[0] = clock64(); a.clk[1] = wall_clock64(); }
     for (int i = tid; i < a.n_bias_rows * WIDTH; i += 256) bias_l[i] = a.bias_tab[i];
+    for (int i = tid; i < WIDTH; i += 256) zero_l[i] = 0.f;
     __syncthreads();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -298,10 +299,14 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpArgs a) {
         }
 
         float part = 0.f;
-        // slabs ping-pong: pass ps reads Y and writes X when ps is even, the other way round when odd
-        for (int ps = 0; ps < a.n_pass; ps += 2) {
-            lp_pass<BF, NCH, -1>(a.pass[ps], Y, X, acc, abuf, rg, xb, bias_l, cb_l, wl, lane, hh, part);
-            if (ps + 1 < a.n_pass) lp_pass<BF, NCH, -1>(a.pass[ps + 1], X, Y, acc, abuf, rg, xb, bias_l, cb_l, wl, lane, hh, part);
+        // slabs ping-pong: the first layer reads Y (its xyz k-steps) and writes X, layer 1 reads X and writes Y, ...
+        auto bias_of = [&](const LpPass& pd) { return pd.bias_row == -2 ? cb_l + WIDTH : (pd.bias_row == -3 ? cb_l : bias_l + pd.bias_row * WIDTH); };
+        auto dot_of = [&](const LpPass& pd) { return pd.last ? wl : zero_l; };
+        lp_pass<BF, 1>(a.pass[0], Y, X, acc, abuf, rg, xb, bias_of(a.pass[0]), dot_of(a.pass[0]), lane, hh, part);
+        for (int ps = 1; ps < a.n_pass; ps += 2) {
+            lp_pass<BF, LP_NCH>(a.pass[ps], X, Y, acc, abuf, rg, xb, bias_of(a.pass[ps]), dot_of(a.pass[ps]), lane, hh, part);
+            if (ps + 1 < a.n_pass)
+                lp_pass<BF, LP_NCH>(a.pass[ps + 1], Y, X, acc, abuf, rg, xb, bias_of(a.pass[ps + 1]), dot_of(a.pass[ps + 1]), lane, hh, part);
         }
         part += __shfl_xor(part, 32);
         const float y = tanhf(part + a.b_last);
@@ -313,13 +318,13 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpArgs a) {
     if (a.clk && blockIdx.x == 0 && tid == 0) { a.clk[2] = clock64(); a.clk[3] = wall_clock64(); }
 }
 
-template __global__ void mlp_lp_kernel<false, 4>(const LpArgs);
-template __global__ void mlp_lp_kernel<true, 4>(const LpArgs);
+template __global__ void mlp_lp_kernel<false>(const LpArgs);
+template __global__ void mlp_lp_kernel<true>(const LpArgs);
 
-static size_t mlp_lp_lds_bytes() { return BIAS_BYTES + CODEBIAS_BYTES + LP_NBUF * CHUNK_BYTES; }
+static size_t mlp_lp_lds_bytes() { return BIAS_BYTES + CODEBIAS_BYTES + LP_ZERO_BYTES + LP_NBUF * CHUNK_BYTES; }
 
 hipError_t mlp_lp_prepare_device() {
-    const void* fns[2] = {reinterpret_cast<const void*>(&mlp_lp_kernel<false, 4>), reinterpret_cast<const void*>(&mlp_lp_kernel<true, 4>)};
+    const void* fns[2] = {reinterpret_cast<const void*>(&mlp_lp_kernel<false>), reinterpret_cast<const void*>(&mlp_lp_kernel<true>)};
     for (int i = 0; i < 2; ++i) {
         const hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlp_lp_lds_bytes());
         if (e != hipSuccess) return e;
@@ -329,9 +334,9 @@ hipError_t mlp_lp_prepare_device() {
 
 hipError_t launch_mlp_lp(bool bf16, const LpArgs& args, int n_blocks, hipStream_t stream) {
     if (bf16)
-        hipLaunchKernelGGL((mlp_lp_kernel<true, 4>), dim3(n_blocks), dim3(256), mlp_lp_lds_bytes(), stream, args);
+        hipLaunchKernelGGL((mlp_lp_kernel<true>), dim3(n_blocks), dim3(256), mlp_lp_lds_bytes(), stream, args);
     else
-        hipLaunchKernelGGL((mlp_lp_kernel<false, 4>), dim3(n_blocks), dim3(256), mlp_lp_lds_bytes(), stream, args);
+        hipLaunchKernelGGL((mlp_lp_kernel<false>), dim3(n_blocks), dim3(256), mlp_lp_lds_bytes(), stream, args);
     return hipGetLastError();
 }
 
