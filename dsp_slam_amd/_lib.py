@@ -81,9 +81,9 @@ SYMBOLS = [
     ("dsp_batch_enable_trace", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_trace", C.c_int, [_VP, C.c_int32, c_f32p, c_f32p, c_f32p, c_i64p, c_i64p, c_i64p, c_f32p, c_f32p, C.POINTER(C.c_uint32), c_f32p]),
     ("dsp_batch_destroy", None, [_VP]),
-    ("dsp_extract_mesh", C.c_int, [_VP, c_f32p, C.c_int32, c_i64p, c_i64p]),
+    ("dsp_extract_mesh", C.c_int, [_VP, c_f32p, C.c_int32, C.c_int32, c_i64p, c_i64p]),
     ("dsp_marching_cubes", C.c_int, [_VP, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, c_i64p, c_i64p]),
-    ("dsp_mesh_fetch", C.c_int, [_VP, c_f32p, c_i32p]),
+    ("dsp_mesh_fetch", C.c_int, [_VP, c_f32p, C.c_int64, c_i32p, C.c_int64]),
     ("dsp_debug_split_layout", C.c_int, [C.POINTER(DecoderDesc), c_i32p, c_i32p, c_i64p]),
     ("dsp_debug_mc_table", C.c_int, [C.POINTER(C.c_uint8), C.POINTER(C.c_uint8)]),
     ("dsp_debug_code_bias", C.c_int, [C.POINTER(DecoderDesc), c_f32p, c_f32p]),
@@ -103,7 +103,7 @@ def load():
     path = lib_path()
     if path == _build.LIB_PATH and _build.is_stale():
         try:
-            _build.build()
+            _build.build_locked()     # one rank builds, the others wait on the lock file and find it fresh
         except Exception as e:  # stale-but-present is usable on a box without hipcc
             if not os.path.exists(path):
                 raise DspError("libdspgn.so is not built and cannot be built here: %s" % e)

@@ -74,5 +74,20 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+def build_locked(force=False, verbose=False):
+    """build() under an inter-process lock: with one process per GPU every rank of a fresh checkout would otherwise run hipcc
+    into the same temporary files at once.  The first holder builds; the others block, then see a fresh library."""
+    import fcntl
+    os.makedirs(LIB_DIR, exist_ok=True)
+    with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or is_stale():
+                return build(force=force, verbose=verbose)
+            return LIB_PATH
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))

@@ -1195,14 +1195,14 @@ int dsp_decode_sdf_multi(dsp_handle* h, const float* codes, int64_t n_codes, con
     return guarded(h, [&] { run_decoder_points(h, codes, n_codes, pts, n, false, sdf_out, nullptr); });
 }
 
-int dsp_extract_mesh(dsp_handle* h, const float* code, int32_t vol_dim, int64_t* n_vertices, int64_t* n_faces) {
-    if (!h || !code || vol_dim < 2 || vol_dim > 512 || !n_vertices || !n_faces) return DSP_E_ARG;
+int dsp_extract_mesh(dsp_handle* h, const float* code, int32_t vol_dim, int32_t flags, int64_t* n_vertices, int64_t* n_faces) {
+    if (!h || !code || vol_dim < 2 || vol_dim > 512 || !n_vertices || !n_faces || (flags & ~DSP_MESH_REGULAR_GRID)) return DSP_E_ARG;
     return guarded(h, [&] {
         HIP_TRY(hipSetDevice(h->device));
         const int64_t n = (int64_t)vol_dim * vol_dim * vol_dim;
         const float voxel_size = (float)(2.0 / (vol_dim - 1));
         h->s_pts.ensure(n);
-        HIP_TRY(launch_grid_points(h->s_pts.p, vol_dim, voxel_size, h->stream));
+        HIP_TRY(launch_grid_points(h->s_pts.p, vol_dim, voxel_size, (flags & DSP_MESH_REGULAR_GRID) ? 1 : 0, h->stream));
         decode_resident_points(h, code, 1, n, false);
         extract_mesh_device(h, h->s_out.p, vol_dim, vol_dim, vol_dim, 0.f, voxel_size, -1.f);
         *n_vertices = h->mesh_nv;
@@ -1224,16 +1224,20 @@ int dsp_marching_cubes(dsp_handle* h, const float* volume, int32_t n0, int32_t n
     });
 }
 
-int dsp_mesh_fetch(dsp_handle* h, float* vertices, int32_t* faces) {
-    if (!h) return DSP_E_ARG;
-    if (h->mesh_nv < 0) return DSP_E_STATE;
-    if ((h->mesh_nv > 0 && !vertices) || (h->mesh_nf > 0 && !faces)) return DSP_E_ARG;
-    return guarded(h, [&] {
+int dsp_mesh_fetch(dsp_handle* h, float* vertices, int64_t n_vertices, int32_t* faces, int64_t n_faces) {
+    if (!h || n_vertices < 0 || n_faces < 0 || (n_vertices > 0 && !vertices) || (n_faces > 0 && !faces)) return DSP_E_ARG;
+    int state = 0;
+    const int rc = guarded(h, [&] {
+        // the counts are read under the handle's lock and must be the ones the caller sized its buffers for: another thread's
+        // dsp_extract_mesh between this caller's extract and fetch is reported, never copied into the wrong-sized buffers
+        if (h->mesh_nv < 0 || h->mesh_nv != n_vertices || h->mesh_nf != n_faces) { state = 1; return; }
         HIP_TRY(hipSetDevice(h->device));
         if (h->mesh_nv > 0) HIP_TRY(hipMemcpyAsync(vertices, h->mc_verts.p, (size_t)h->mesh_nv * 12, hipMemcpyDeviceToHost, h->stream));
         if (h->mesh_nf > 0) HIP_TRY(hipMemcpyAsync(faces, h->mc_faces.p, (size_t)h->mesh_nf * 12, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
     });
+    if (rc == DSP_OK && state) { h->err = "no mesh of that size on this handle (another extract ran in between?)"; return DSP_E_STATE; }
+    return rc;
 }
 
 // host-only: the per-wave chunk order of the latency-form weight stream.  layout12 = off[4] | len[4] | len_fwd[4]; chunk_ids may be

@@ -207,7 +207,7 @@ struct McTables {                        // marching-cubes case table, generated
 };
 void mc_build_tables(McTables& t);
 int mc_num_blocks(int n_pts);
-hipError_t launch_grid_points(float4* pts, int n, float voxel_size, hipStream_t s);
+hipError_t launch_grid_points(float4* pts, int n, float voxel_size, int regular, hipStream_t s);
 hipError_t launch_mc_count(const float* vol, int n0, int n1, int n2, float level, const McTables* tab, int2* block_sums, long long* totals,
                            hipStream_t s);
 hipError_t launch_mc_emit(const float* vol, int n0, int n1, int n2, float level, const McTables* tab, const int2* block_off, float spacing,

@@ -323,22 +323,34 @@ __global__ __launch_bounds__(MC_BLOCK) void k_mc_faces(const float* vol, Dims d,
         }
 }
 
-// voxel grid of MeshExtractor (reference utils.py:97-116): point g = (i, j, k) * voxel_size + (-1), x slowest
-__global__ void k_grid_points(float4* pts, int n, float voxel_size) {
+// voxel grid of MeshExtractor (reference utils.py:97-116), x slowest.  regular: point g = (i, j, k) * voxel_size + (-1).
+// Otherwise the grid the reference really samples: `overall_index.long() / vol_dim` is true division under torch >= 1.6, so in
+// float32 q1 = g / n, y index = fmod(q1, n), x index = fmod(q1 / n, n) (sheared by up to one voxel; golden_voxel_grid.npz).
+__global__ void k_grid_points(float4* pts, int n, float voxel_size, int regular) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n * n * n) return;
-    const int k = g % n, j = (g / n) % n, i = g / (n * n);
-    pts[g] = make_float4(__fadd_rn(__fmul_rn((float)i, voxel_size), -1.f), __fadd_rn(__fmul_rn((float)j, voxel_size), -1.f),
-                         __fadd_rn(__fmul_rn((float)k, voxel_size), -1.f), 0.f);
+    float fi, fj;
+    const float fk = (float)(g % n);
+    if (regular) {
+        fj = (float)((g / n) % n);
+        fi = (float)(g / (n * n));
+    } else {
+        const float fn = (float)n;
+        const float q1 = __fdiv_rn((float)g, fn);
+        fj = fmodf(q1, fn);
+        fi = fmodf(__fdiv_rn(q1, fn), fn);
+    }
+    pts[g] = make_float4(__fadd_rn(__fmul_rn(fi, voxel_size), -1.f), __fadd_rn(__fmul_rn(fj, voxel_size), -1.f),
+                         __fadd_rn(__fmul_rn(fk, voxel_size), -1.f), 0.f);
 }
 
 }  // namespace
 
 int mc_num_blocks(int n_pts) { return (n_pts + MC_BLOCK - 1) / MC_BLOCK; }
 
-hipError_t launch_grid_points(float4* pts, int n, float voxel_size, hipStream_t s) {
+hipError_t launch_grid_points(float4* pts, int n, float voxel_size, int regular, hipStream_t s) {
     const int total = n * n * n;
-    hipLaunchKernelGGL(k_grid_points, dim3((total + 255) / 256), dim3(256), 0, s, pts, n, voxel_size);
+    hipLaunchKernelGGL(k_grid_points, dim3((total + 255) / 256), dim3(256), 0, s, pts, n, voxel_size, regular);
     return hipGetLastError();
 }
 

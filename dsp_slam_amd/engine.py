@@ -189,15 +189,16 @@ class Engine(object):
     def _fetch_mesh(self, nv, nf):
         verts = np.zeros((nv.value, 3), np.float32)
         faces = np.zeros((nf.value, 3), np.int32)
-        L.check(L.load().dsp_mesh_fetch(self._h, L.ptr(verts), L.ptr(faces, L.c_i32p)), self._h, "dsp_mesh_fetch")
+        L.check(L.load().dsp_mesh_fetch(self._h, L.ptr(verts), nv.value, L.ptr(faces, L.c_i32p), nf.value), self._h, "dsp_mesh_fetch")
         return verts, faces
 
-    def extract_mesh(self, code, vol_dim):
+    def extract_mesh(self, code, vol_dim, regular_grid=False):
         """Grid decode + marching cubes on the device (the SDF volume never leaves HBM): vertices (V,3) float32 in the
-        decoder's [-1,1]^3 frame, faces (F,3) int32.  Empty when the surface does not cross the grid."""
+        decoder's [-1,1]^3 frame, faces (F,3) int32.  Empty when the surface does not cross the grid.  regular_grid=False
+        samples the reference's (sheared) grid, see reconstruct.utils.create_voxel_grid."""
         code = L.f32(code).reshape(-1)[:L.CODE_LEN]
         nv, nf = C.c_int64(0), C.c_int64(0)
-        L.check(L.load().dsp_extract_mesh(self._h, L.ptr(code), int(vol_dim), C.byref(nv), C.byref(nf)), self._h, "dsp_extract_mesh")
+        L.check(L.load().dsp_extract_mesh(self._h, L.ptr(code), int(vol_dim), 1 if regular_grid else 0, C.byref(nv), C.byref(nf)), self._h, "dsp_extract_mesh")
         return self._fetch_mesh(nv, nf)
 
     def marching_cubes(self, volume, level=0.0, spacing=1.0, origin=0.0):
@@ -258,6 +259,8 @@ class Engine(object):
         return Batch(self, prm, t_cam_obj, pts, rays, depth, codes, trace)
 
     def reconstruct_batch(self, prm, t_cam_obj, pts, rays, depth, codes=None):
+        if len(pts) == 0:      # an empty shard (more ranks than objects): nothing to run, but the caller still joins the gather
+            return (np.zeros((0, 4, 4), np.float32), np.zeros((0, L.CODE_LEN), np.float32), np.zeros(0, np.float32), np.zeros(0, np.int32))
         b = Batch(self, prm, t_cam_obj, pts, rays, depth, codes)
         try:
             b.run()
@@ -267,6 +270,8 @@ class Engine(object):
 
     def estimate_pose_batch(self, prm, t_co_se3, scale, pts, codes):
         n = len(pts)
+        if n == 0:
+            return np.zeros((0, 4, 4), np.float32)
         po, p = _ragged(pts, 3)
         t = L.f32(np.stack([np.asarray(x, np.float32).reshape(4, 4) for x in t_co_se3]))
         sc = L.f32(np.asarray(scale, np.float32).reshape(n))

@@ -108,11 +108,14 @@ class Optimizer(object):
 
 
 class MeshExtractor(object):
-    def __init__(self, decoder, code_len=64, voxels_dim=64):
+    def __init__(self, decoder, code_len=64, voxels_dim=64, regular_grid=False):
+        """regular_grid=False samples the SDF exactly where the reference does (its grid is sheared by a true-division quirk,
+        see reconstruct.utils.create_voxel_grid); True samples the regular lattice.  (Addition; the reference has no such switch.)"""
         self.decoder = decoder
         self.code_len = code_len
         self.voxels_dim = voxels_dim
-        self.voxel_points = create_voxel_grid(vol_dim=self.voxels_dim)
+        self.regular_grid = bool(regular_grid)
+        self.voxel_points = create_voxel_grid(vol_dim=self.voxels_dim, regular=self.regular_grid)
 
     def decode_grid(self, code):
         """SDF on the voxels_dim^3 grid, decoded on the GPU (the part of extract_mesh_from_code that is
@@ -131,7 +134,7 @@ class MeshExtractor(object):
         """Grid decode + marching cubes, both on the GPU without the volume leaving HBM (reference optimizer.py:214-223;
         there: GPU decode, then scikit-image marching cubes on the CPU)."""
         start = get_time()
-        vertices, faces = self.decoder.engine.extract_mesh(_f32(code)[:self.code_len], self.voxels_dim)
+        vertices, faces = self.decoder.engine.extract_mesh(_f32(code)[:self.code_len], self.voxels_dim, regular_grid=self.regular_grid)
         if vertices.shape[0] == 0:
             raise ValueError("Surface level must be within volume data range.")   # what scikit-image raises in the reference
         print("Extract mesh takes %f seconds" % (get_time() - start))

@@ -45,15 +45,28 @@ def get_decoder(configs):
     return config_decoder(configs.DeepSDF_DIR)
 
 
-def create_voxel_grid(vol_dim=128):
-    """(vol_dim^3, 3) float32 grid over [-1,1]^3, x slowest (reference utils.py:97-116)."""
-    voxel_size = 2.0 / (vol_dim - 1)
+def create_voxel_grid(vol_dim=128, regular=False):
+    """(vol_dim^3, 3) float32 sample points of MeshExtractor over [-1,1]^3, x slowest (reference utils.py:97-116).
+
+    regular=False (default) reproduces what the reference computes under its pinned torch 1.10 (and any torch >= 1.6):
+    `overall_index.long() / vol_dim` is TRUE division there, so the y index is y + z / N and the x index x + y / N + z / N^2 --
+    a grid sheared by up to one voxel, in float32 arithmetic restated here operation by operation (pinned by
+    tests/golden/golden_voxel_grid.npz, recorded from the reference).  regular=True is the grid the code was evidently
+    meant to build (integer division).  The marching-cubes vertices are placed on the regular lattice either way, as in
+    the reference (utils.py:131-138)."""
+    n = np.float32(vol_dim)
+    voxel_size = np.float32(2.0 / (vol_dim - 1))
     idx = np.arange(vol_dim ** 3, dtype=np.int64)
     v = np.zeros((vol_dim ** 3, 3), np.float32)
     v[:, 2] = idx % vol_dim
-    v[:, 1] = (idx // vol_dim) % vol_dim
-    v[:, 0] = (idx // vol_dim // vol_dim) % vol_dim
-    return (v * np.float32(voxel_size) + np.float32(-1.0)).astype(np.float32)
+    if regular:
+        v[:, 1] = (idx // vol_dim) % vol_dim
+        v[:, 0] = (idx // vol_dim // vol_dim) % vol_dim
+    else:
+        q1 = idx.astype(np.float32) / n                   # LongTensor / int -> float32 true division
+        v[:, 1] = np.fmod(q1, n)
+        v[:, 0] = np.fmod(q1 / n, n)
+    return (v * voxel_size + np.float32(-1.0)).astype(np.float32)
 
 
 def convert_sdf_voxels_to_mesh(sdf_volume, engine=None):

@@ -150,18 +150,24 @@ int dsp_estimate_pose_batch(dsp_handle* h, const dsp_gn_params* prm, int32_t n_o
 /* ---- mesh extraction (reference MeshExtractor.extract_mesh_from_code, reconstruct/optimizer.py:206-223 ->
  *      create_voxel_grid / decode_sdf / convert_sdf_voxels_to_mesh, reconstruct/utils.py:97-140) -----------------------------------
  * dsp_extract_mesh decodes the vol_dim^3 grid over [-1,1]^3 and runs marching cubes (level 0) on the device; the SDF volume
- * never leaves HBM.  It returns the mesh size; dsp_mesh_fetch then copies the last mesh extracted on this handle:
+ * never leaves HBM.  The sample points are the ones the reference's create_voxel_grid really produces: under torch >= 1.6 its
+ * `overall_index.long() / vol_dim` is true division, so the grid is sheared by up to one voxel (y index + z / N, x index + y / N + z / N^2);
+ * DSP_MESH_REGULAR_GRID samples the regular lattice instead.  Vertices are placed on the regular lattice either way, as in the reference.  It returns the mesh size; dsp_mesh_fetch then copies the last mesh extracted on this handle:
  * vertices (n_vertices x 3 float32, object frame: index * voxel_size - 1, voxel_size = 2 / (vol_dim - 1)) and faces
  * (n_faces x 3 int32 vertex ids, normals by the right-hand rule along +grad sdf, i.e. outward).  One vertex per sign-changing grid
  * edge (shared between faces, like scikit-image's output); order: vertices by (grid point, axis), faces by (cell, case-table order).
  * An empty mesh (no sign change) is n_vertices = n_faces = 0 and not an error here (the Python mirror raises scikit-image's
  * ValueError for it).  The case table is a generated classic table, not Lewiner's: see oracle/mc_oracle.py. */
-int dsp_extract_mesh(dsp_handle* h, const float* code, int32_t vol_dim, int64_t* n_vertices, int64_t* n_faces);
+#define DSP_MESH_REGULAR_GRID 1   /* flags: sample the regular lattice instead of the reference's sheared grid (see below) */
+int dsp_extract_mesh(dsp_handle* h, const float* code, int32_t vol_dim, int32_t flags, int64_t* n_vertices, int64_t* n_faces);
 /* The marching-cubes step alone on a host volume (n0 x n1 x n2, axis 0 slowest): vertices = index * spacing + origin
  * (replaces convert_sdf_voxels_to_mesh, utils.py:119-140, with spacing = 2 / (n - 1), origin = -1, level = 0). */
 int dsp_marching_cubes(dsp_handle* h, const float* volume, int32_t n0, int32_t n1, int32_t n2, float level, float spacing, float origin,
                        int64_t* n_vertices, int64_t* n_faces);
-int dsp_mesh_fetch(dsp_handle* h, float* vertices, int32_t* faces);
+/* Copies the last mesh extracted on this handle.  n_vertices / n_faces are the counts the caller sized its buffers for (as returned by
+ * its dsp_extract_mesh / dsp_marching_cubes call); if the handle's last mesh has other counts -- another thread extracted in between --
+ * nothing is copied and DSP_E_STATE is returned. */
+int dsp_mesh_fetch(dsp_handle* h, float* vertices, int64_t n_vertices, int32_t* faces, int64_t n_faces);
 
 /* ---- device-resident batches (bench / steady-state serving: inputs stay in HBM between runs) --- */
 int dsp_batch_create(dsp_handle* h, const dsp_gn_params* prm, int32_t n_objects, const int64_t* pts_off,

@@ -7,10 +7,10 @@ import json
 import numpy as np
 import pytest
 
-from conftest import golden
+from conftest import golden, parity_log
 from oracle import dsp_oracle as O
 from dsp_slam_amd import fixtures, synth, engine as E, distributed as D
-from test_gpu_parity import compare_linearisation, one_iteration_oracle
+from test_gpu_parity import compare_linearisation, one_iteration_oracle, LAST_LINEARISATION
 
 pytestmark = pytest.mark.gpu
 
@@ -60,13 +60,40 @@ def test_cfg2_full_size_first_iteration_vs_reference(eng, oracle_decoder):
     mask[3:6] = False
     assert np.abs(tr0["b"][0][mask] - g["it_b"][0][mask]).max() < tol * np.abs(g["it_b"][0]).max()
     oprm = O.GNParams.from_configs(cfg)
-    strict = 0
+    strict, per_iter = 0, []
     for e in (3, 6, 9):
         tr = b.trace(e)
         obj = dict(pts=g["in_pts"], rays=g["in_rays"], depth=g["in_depth"])
         strict += bool(compare_linearisation(tr, 0, one_iteration_oracle(oracle_decoder, oprm, obj, tr), oprm.k4))
+        per_iter.append(dict(LAST_LINEARISATION, iteration=e))
+    parity_log(kind="iterations", case="cfg2 single object, iterations 3/6/9 vs oracle", n=3, strict=strict,
+               same_sets=sum(1 for p in per_iter if p["same_sets"]), flips=[p["flips"] for p in per_iter], rel_H=[p["rel_H"] for p in per_iter],
+               rel_b=[p["rel_b"] for p in per_iter], oracle_jitter_rel_H=[p["oracle_jitter_rel_H"] for p in per_iter], K=[p["K"] for p in per_iter],
+               first_iteration_vs_reference=dict(dK=int(dk), rel_H=float(np.abs(tr0["H"][0] - g["it_H"][0]).max() / np.abs(g["it_H"][0]).max())))
     assert strict >= 1
     b.close()
+
+
+def test_cfg3_batch64_objects_vs_oracle(eng, oracle_decoder):
+    """Inside a full 64-object cfg2 batch (the bench workload) the first and the last object, at the first and the last GN
+    iteration, are each one linearisation the oracle reproduces from the device's own state (optimizer.py:118-192) --
+    i.e. parity holds at full batch size, not only for single objects."""
+    prm = E.gn_params()
+    oprm = O.GNParams()
+    objs = synth.make_batch(64, first_seed=300, n_surface=2000, n_background=500)
+    b = eng.batch(prm, [o["t_cam_obj_init"] for o in objs], [o["pts"] for o in objs], [o["rays"] for o in objs],
+                  [o["depth"] for o in objs], trace=True)
+    b.run()
+    assert (b.results()[3] == 0).all()
+    out = []
+    for e in (0, prm.num_iterations - 1):
+        tr = b.trace(e)
+        for i in (0, 63):
+            strict = bool(compare_linearisation(tr, i, one_iteration_oracle(oracle_decoder, oprm, objs[i], tr, i), oprm.k4))
+            out.append(dict(LAST_LINEARISATION, iteration=e, object=i, strict=strict))
+    b.close()
+    parity_log(kind="batch64", case="64 x cfg2 batch: objects 0 and 63, iterations 0 and 9 vs oracle", checks=out)
+    assert sum(1 for o in out if o["same_sets"]) >= 2
 
 
 def test_cfg3_batch64_deterministic_and_permutation_equivariant(eng):

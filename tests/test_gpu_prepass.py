@@ -56,7 +56,7 @@ def test_prepass_matches_fp32_kernel_closely(eng):
 # ---------------------------------------------------------------------------------------------------
 import json
 
-from conftest import golden
+from conftest import golden, parity_log
 from dsp_slam_amd import synth
 
 TRACE_KEYS = ("H", "b", "dx", "V", "K", "set_sums", "t_obj_cam", "code")
@@ -135,6 +135,10 @@ def test_prepass_is_exact_on_reference_goldens(eng, name):
     for mode in (L.PREPASS_F16, L.PREPASS_BF16):
         run = _run_traced(eng, prm, args, mode)
         _assert_identical(run, ref, "%s mode %d" % (name, mode))
+        st = run[2]
+        parity_log(kind="prepass", case=name, dtype=["off", "f16", "bf16"][mode], audited=st["prepass_audited"], max_err=st["prepass_max_err"],
+                   delta=st["prepass_delta"], misclassified=int(st["prepass_misclassified"]),
+                   fwd_over_insphere=st["n_fwd_points"] / st["n_insphere_points"], identical=True)
         assert run[2]["prepass_misclassified"] == 0
         assert 4.0 * run[2]["prepass_max_err"] <= run[2]["prepass_delta"]
 
@@ -149,6 +153,9 @@ def test_prepass_is_exact_on_64_cfg2_objects(eng):
     _assert_identical(run, ref, "64 x cfg2")
     st = run[2]
     assert (run[0][3] == 0).all()
+    parity_log(kind="prepass", case="64 x cfg2 (bench workload), 10 iterations", dtype="f16", audited=st["prepass_audited"],
+               max_err=st["prepass_max_err"], delta=st["prepass_delta"], misclassified=int(st["prepass_misclassified"]),
+               fwd_over_insphere=st["n_fwd_points"] / st["n_insphere_points"], identical=True)
     assert st["prepass_misclassified"] == 0 and 4.0 * st["prepass_max_err"] <= st["prepass_delta"]
     print("64 x cfg2: fp32 forward points %.3g -> %.3g (%.1f %% of in-sphere), prepass points %.3g, max |sdf_lp - sdf_fp32| %.3g, delta %.3g" % (
         ref[2]["n_fwd_points"], st["n_fwd_points"], 100 * st["n_fwd_points"] / st["n_insphere_points"], st["n_prepass_points"],

@@ -94,7 +94,7 @@ def test_synth_deterministic_and_consistent():
 
 def test_voxel_grid(mirror):
     from reconstruct.utils import create_voxel_grid
-    g = create_voxel_grid(4)
+    g = create_voxel_grid(4, regular=True)
     assert g.shape == (64, 3) and g.dtype == np.float32
     assert np.allclose(g[0], [-1, -1, -1]) and np.allclose(g[-1], [1, 1, 1]) and np.allclose(g[1], [-1, -1, -1 + 2 / 3])
 
@@ -153,3 +153,23 @@ def test_ply_writer_layout_and_roundtrip(mirror, tmp_path):
     write_mesh_to_ply(np.zeros((0, 3)), np.zeros((0, 3)), p)
     v2, f2 = read_mesh_from_ply(p)
     assert v2.shape == (0, 3) and f2.shape == (0, 3)
+
+
+def test_voxel_grid_matches_the_reference_including_its_true_division_quirk(mirror):
+    """create_voxel_grid against the grid recorded from the unmodified reference (tools/make_golden.py, section `grid`): under
+    torch >= 1.6 the reference's `LongTensor / int` is true division, so its grid is sheared; the mirror reproduces it bit for
+    bit by default and offers the regular lattice as an option."""
+    from conftest import golden
+    from reconstruct.utils import create_voxel_grid
+    g = golden("golden_voxel_grid.npz")
+    for n in (4, 16):
+        assert np.array_equal(create_voxel_grid(n), g["grid_%d" % n])
+    for n in (32, 64, 128):
+        mine = create_voxel_grid(n)
+        assert np.array_equal(mine[::997], g["sample_%d" % n])
+        assert np.array_equal(mine.astype(np.float64).sum(0), g["sum_%d" % n])
+    reg = create_voxel_grid(16, regular=True)
+    assert not np.array_equal(reg, g["grid_16"])
+    assert np.abs(reg - g["grid_16"]).max() <= 2.0 / 15 * (1 + 1e-6)          # sheared by at most one voxel
+    idx = np.arange(16 ** 3)
+    assert np.array_equal(reg[:, 0], (idx // 256).astype(np.float32) * np.float32(2.0 / 15) + np.float32(-1))

@@ -34,16 +34,16 @@ def _solve(objs):
     return D.pack_results(np.stack(t), np.stack(c), np.array(l, np.float32), np.array(s))
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, n_obj=N_OBJ):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(2)
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    objs = _objects()
+    objs = _objects()[:n_obj]
     shards = D.shard_objects([D.object_cost(o["pts"].shape[0], o["rays"].shape[0]) for o in objs], world)
     a, b = shards[rank]
-    local = _solve(objs[a:b])
+    local = _solve(objs[a:b]) if b > a else np.zeros((0, D.RESULT_WIDTH), np.float32)    # an empty shard still joins the gather
     full = D.gather_results(local, shards, dist)
     dist.barrier()
     if rank == 0:
@@ -69,3 +69,19 @@ def test_two_rank_shard_and_gather(tmp_path):
     want = _solve(_objects())
     assert got.shape == (N_OBJ, D.RESULT_WIDTH)
     assert np.array_equal(got, want)
+
+
+def test_more_ranks_than_objects(tmp_path):
+    """3 ranks, 2 objects: a rank with an empty shard contributes nothing but still takes part in the one collective
+    (otherwise the other ranks hang in it)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "gathered3.npy")
+    mp.spawn(_worker, args=(3, port, out, 2), nprocs=3, join=True)
+    got = np.load(out)
+    shards = np.load(out + ".shards.npy")
+    assert sorted(b - a for a, b in shards) == [0, 1, 1]
+    torch.set_num_threads(2)
+    assert np.array_equal(got, _solve(_objects()[:2]))

@@ -170,6 +170,19 @@ def main():
     def want(name):
         return not only or name in only
 
+    # ---- 0. MeshExtractor voxel grid (utils.py:97-116): under torch >= 1.6 `LongTensor / int` is TRUE division, so the
+    #         reference's grid is sheared (y index gains z / N, x index gains y / N + z / N^2) -- recorded as it is
+    if want("grid"):
+        from reconstruct.utils import create_voxel_grid
+        out = {}
+        for n in (4, 16):
+            out["grid_%d" % n] = create_voxel_grid(n).numpy()
+        for n in (32, 64, 128):
+            gr = create_voxel_grid(n).numpy()
+            out["sample_%d" % n] = gr[::997].copy()
+            out["sum_%d" % n] = gr.astype(np.float64).sum(0)
+        np.savez_compressed(os.path.join(GOLD, "golden_voxel_grid.npz"), **out)
+
     # ---- A. decoder forward / input-Jacobian -------------------------------------------------
     if want("decoder"):
         n = 96

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Round-2 profile sequence on the GPU box (one gpurun call): bench line, rocprofv3 kernel stats of the same command, PMC passes
+# (each in its own run, --pmc only), latency-sized kernel stats.  Outputs under gpurun_out/r02/ ; copy what is to be judged into profiles/.
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+TAG=${1:-r02}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd $R
+timeout 400 python bench.py --steps 5 --warmup 1 2> $OUT/bench.err | tail -1 > $OUT/bench.json
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_stats -o stats -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --latency-runs 1 > $OUT/bench_under_rocprof.txt 2>&1
+DB=$(find /tmp/prof_stats -name "*.db" | head -1)
+python $R/tools/rocpd_stats.py $DB > $OUT/kernel_stats.md 2>&1
+for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "mfma:SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES" "lds:SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
+  name=${pass%%:*}; ctrs=${pass#*:}
+  timeout 300 rocprofv3 --pmc $ctrs -d /tmp/prof_pmc_$name -o pmc -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --latency-runs 1 > $OUT/pmc_$name.log 2>&1
+  DB=$(find /tmp/prof_pmc_$name -name "*.db" | head -1)
+  python $R/tools/rocpd_pmc.py $DB mlp_ > $OUT/pmc_$name.md 2>&1
+done
+# latency-sized: one real-KITTI-size detection per call
+timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_lat -o stats -- python $R/tools/gpu_small_loop.py 250 200 50 > $OUT/latency_run.txt 2>&1
+DB=$(find /tmp/prof_lat -name "*.db" | head -1)
+python $R/tools/rocpd_stats.py $DB > $OUT/latency_kernel_stats.md 2>&1
+cd $R
+cut -c1-600 $OUT/bench.json; head -12 $OUT/kernel_stats.md; tail -4 $OUT/latency_run.txt
