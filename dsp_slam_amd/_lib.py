@@ -75,6 +75,8 @@ SYMBOLS = [
     ("dsp_batch_set_ray_passes", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_set_ray_pass_bounds", C.c_int, [_VP, c_i32p, C.c_int]),
     ("dsp_batch_set_mask_reuse", C.c_int, [_VP, C.c_int]),
+    ("dsp_batch_set_fused_bookkeeping", C.c_int, [_VP, C.c_int]),
+    ("dsp_batch_set_speculative_band", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_set_prepass", C.c_int, [_VP, C.c_int, C.c_float]),
     ("dsp_batch_set_prepass_audit", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_set_split_rows", C.c_int, [_VP, C.c_int]),

@@ -576,6 +576,9 @@ struct dsp_batch {
     int n_ray_passes = 0;     // front-to-back forward passes per iteration (0 = pick from the batch size)
     std::vector<int> pass_bounds;   // optional explicit depth-index boundaries (n_passes + 1 entries, 0 .. D)
     int hint_margin = 2, hint_step = 8;   // adaptive passes: pass 0 = [0, hint + margin), middle pass = next `step` indices
+    int speculative = -1;         // band samples straight into the jacobian launch (latency path): -1 auto, 0 off, 1 on
+    DevBuf<int> srow, jrow;       // speculative band rows: jgrad row of a sample / of a kept render row
+    int fused_bookkeeping = -1;   // per-object fused bookkeeping kernels: -1 auto (latency-sized batches), 0 off, 1 on
     int prepass = -1;         // low-precision classification pass in front of the fp32 forward decoder: -1 auto, 0 off, 1 f16, 2 bf16
     float prepass_delta = -1.f;   // margin added to cut_off on both sides (< 0: the dtype's default)
     bool prepass_audit = false;   // also decode every sample in fp32 and compare (tests / calibration)
@@ -714,10 +717,11 @@ bool use_mask_reuse(const dsp_batch* b) {
 
 // Jacobian launch in the latency form (mlp_split_kernel: 16-point tiles, each layer's rows split over the four waves, a tile
 // takes ~1/3 of a 64-point tile's time)?  Worth it only while the 16-point tiles still fit a round or two over the CUs.
+bool use_speculative_band(const dsp_batch* b);
 bool use_split_rows(const dsp_batch* b) {
     if (use_mask_reuse(b)) return false;               // the backward-only launch has no latency form
     if (b->split_rows >= 0) return b->split_rows != 0;
-    const double rows = (double)b->sum_pts + (b->pose_only ? 0.0 : 0.045 * (double)b->sum_rays * b->D);   // M + typical K
+    const double rows = (double)b->sum_pts + (b->pose_only ? 0.0 : (use_speculative_band(b) ? 0.16 : 0.045) * (double)b->sum_rays * b->D);   // M + typical K (or band)
     const double n_cu = b->h->n_cu;
     const double rounds16 = std::ceil(rows / SPLIT_TILE_PTS / n_cu), rounds64 = std::ceil(rows / TILE_PTS / n_cu);
     return 0.34 * rounds16 <= 0.8 * rounds64;
@@ -730,6 +734,26 @@ bool use_split_fwd(const dsp_batch* b) {
     const double pts = 0.2 * (double)b->cap_s, n_cu = b->h->n_cu;   // tools/gpu_split_probe.py: 4 real-size objects 14.8 vs 17.3 ms forward; 1-2 cfg2 objects: 64-point tiles win
     const double rounds16 = std::ceil(pts / SPLIT_TILE_PTS / n_cu), rounds64 = std::ceil(pts / TILE_PTS / n_cu);
     return 0.30 * rounds16 <= 0.8 * rounds64;
+}
+
+// Latency-sized batches run the per-ray bookkeeping in its fused per-object form (k_front_fused / k_band_fused / k_render_fused:
+// 3 launches instead of 11 per iteration, same device functions, same bits).  Large batches keep one thread block per 256 rays.
+bool use_fused_bookkeeping(const dsp_batch* b) {
+    if (b->pose_only) return false;
+    if (b->fused_bookkeeping >= 0) return b->fused_bookkeeping != 0;
+    return b->B <= 16;
+}
+
+// Latency path, prepass on: the samples the prepass could not classify go STRAIGHT into the jacobian launch (forward + backward,
+// their sdf scattered back for the occupancy scan) instead of a forward launch of their own followed by forward + backward of the
+// kept ones.  One decoder launch less per iteration; the backward sweep of the ~25 % band samples that are not kept afterwards is
+// wasted, so only while surface points + band samples fit one round of 16-point tiles.  The Gram kernel reads each kept row's
+// gradient where that launch left it (jrow), in the same row order: bit-identical results.
+int prepass_mode(const dsp_batch* b);
+bool use_speculative_band(const dsp_batch* b) {
+    if (!use_fused_bookkeeping(b) || !prepass_mode(b) || use_mask_reuse(b)) return false;
+    if (b->speculative >= 0) return b->speculative != 0;
+    return ((double)b->sum_pts + 0.16 * (double)b->cap_s) / SPLIT_TILE_PTS <= 1.0 * b->h->n_cu;
 }
 
 // Prepass default margins: 4x the largest |sdf_lp - sdf_fp32| measured on the device over the decoder fixtures
@@ -750,7 +774,7 @@ float prepass_delta(const dsp_batch* b) {
 // launch, forward + backward (with mask reuse the surface points only, else surface points and render rows), 2 = jacobian
 // of the kept render rows, backward only from the exported masks
 // 3 = low-precision prepass over the current sample list, 4 = audit: fp32 forward over every in-sphere sample into saudit
-void launch_decoder(dsp_batch* b, int what, size_t& cursor) {
+void launch_decoder(dsp_batch* b, int what, size_t& cursor, bool whole_list = false) {
     dsp_handle* h = b->h;
     if (what == 3) {
         const int pm = prepass_mode(b);
@@ -758,7 +782,7 @@ void launch_decoder(dsp_batch* b, int what, size_t& cursor) {
         la.n_tiles = b->n_tiles.p;
         la.tiles = b->tiles_f.p;
         la.pts = b->spts.p;
-        la.index = b->plist.p;
+        la.index = whole_list ? nullptr : b->plist.p;     // whole_list: the tiles cover every in-sphere sample in place
         la.code_bias = b->cbias.p;
         la.code_bias_stride = 2 * WIDTH;
         la.out_sdf = b->ssdf.p;
@@ -803,6 +827,7 @@ void launch_decoder(dsp_batch* b, int what, size_t& cursor) {
     a.mask_buf = b->maskbuf.p;
     a.th = b->prm.cut_off;
     a.out_grad = b->jgrad.p;
+    if (what == 1 && use_speculative_band(b)) { a.sdf_scatter = b->ssdf.p; a.scatter_tile_begin = b->n_tiles.p + 2; }
     hipEvent_t e0 = next_event(b, cursor), e1 = next_event(b, cursor);
     b->ev_kind.push_back(what == 0 ? 0 : 1);
     HIP_TRY(hipEventRecord(e0, h->stream));
@@ -822,15 +847,22 @@ void batch_code_bias(dsp_batch* b) {
 }
 
 // the first half of an iteration up to and including the J rows' inputs (shared with the stand-alone terms)
-void iteration_front(dsp_batch* b, size_t& cursor, bool do_render) {
+void iteration_front(dsp_batch* b, size_t& cursor, bool do_render, bool code_bias = true) {
     dsp_handle* h = b->h;
     hipStream_t s = h->stream;
     const int B = b->B;
-    batch_code_bias(b);   // the code changed in the previous solve (or was just initialised)
+    if (code_bias) batch_code_bias(b);   // first iteration / stand-alone terms; later iterations get it from k_solve, which updated the code
+    const bool fused = do_render && use_fused_bookkeeping(b);
+    const bool spec = do_render && use_speculative_band(b);
     if (do_render) {
-        launch_sample_count(b->oc.p, b->st.p, b->rays.p, b->raymask.p, b->raycnt.p, b->D, b->maxR, B, s);
-        launch_scan_rays(b->oc.p, b->st.p, b->raycnt.p, b->rayoff.p, 0, B, s);
-        launch_sample_write(b->oc.p, b->st.p, b->rays.p, b->raymask.p, b->rayoff.p, b->spts.p, b->ssdf.p, b->ray_alive.p, b->D, b->maxR, B, s);
+        if (fused) {
+            launch_front_fused(b->oc.p, b->st.p, b->rays.p, b->pts.p, b->raymask.p, b->raycnt.p, b->rayoff.p, b->spts.p, b->ssdf.p, b->ray_alive.p,
+                               b->jpts.p, b->jaux.p, b->D, B, s);
+        } else {
+            launch_sample_count(b->oc.p, b->st.p, b->rays.p, b->raymask.p, b->raycnt.p, b->D, b->maxR, B, s);
+            launch_scan_rays(b->oc.p, b->st.p, b->raycnt.p, b->rayoff.p, 0, B, s);
+            launch_sample_write(b->oc.p, b->st.p, b->rays.p, b->raymask.p, b->rayoff.p, b->spts.p, b->ssdf.p, b->ray_alive.p, b->D, b->maxR, B, s);
+        }
         // Forward decoder, front to back with exact early ray termination (gn_kernels.hip, "front-to-back ray passes").
         //  * explicit pass count / boundaries (dsp_batch_set_ray_passes / _bounds): fixed depth-index ranges for all rays;
         //  * automatic (default): per-ray ranges steered by where each ray terminated in the previous GN iteration -- pass 0
@@ -844,6 +876,8 @@ void iteration_front(dsp_batch* b, size_t& cursor, bool do_render) {
         const double tiles = 0.75 * (double)b->cap_s / (pm ? LP_TILE_PTS : TILE_PTS);     // expected forward tiles per iteration
         int fixed_passes = b->n_ray_passes;
         if (fixed_passes <= 0 && tiles >= 100.0 * h->n_cu) fixed_passes = 10;   // large batches: ten uniform ranges measured best
+        // a prepass over every sample that fits a round and a half of 128-point tiles is one launch with no pass bookkeeping at all
+        if (fixed_passes <= 0 && pm && (double)b->cap_s / LP_TILE_PTS <= 1.5 * h->n_cu) fixed_passes = 1;
         if (fixed_passes > 0) {
             const int n_passes = std::max(1, std::min(fixed_passes, b->D));
             std::vector<int> bounds = b->pass_bounds;
@@ -861,6 +895,12 @@ void iteration_front(dsp_batch* b, size_t& cursor, bool do_render) {
                 specs.push_back(PassSpec{b->hint_margin, b->hint_step, b->D, p, p == n_passes - 1, b->ray_hint.p, b->ray_plo.p});
         }
         const int fwd_tile = pm ? LP_TILE_PTS : (use_split_fwd(b) ? SPLIT_TILE_PTS : TILE_PTS);
+        const bool whole = pm && specs.size() == 1 && !specs[0].hint && specs[0].j0 == 0 && specs[0].j1 >= b->D;
+        if (whole) {     // every in-sphere sample, in place: no selection list
+            launch_build_tiles(b->oc.p, b->st.p, B, 0, b->tiles_f.p, b->n_tiles.p, b->counters.p, 1, fwd_tile, 4, s);
+            launch_decoder(b, 3, cursor, true);
+            specs.clear();
+        }
         for (const PassSpec& ps : specs) {
             launch_pass_select(b->oc.p, b->st.p, b->raymask.p, b->rayoff.p, b->ray_alive.p, b->pcnt.p, ps, b->maxR, B, s);
             launch_scan_rays(b->oc.p, b->st.p, b->pcnt.p, b->poff.p, 2, B, s);
@@ -877,18 +917,36 @@ void iteration_front(dsp_batch* b, size_t& cursor, bool do_render) {
                 launch_decoder(b, 4, cursor);
                 launch_prepass_audit(b->oc.p, b->st.p, b->ssdf.p, b->saudit.p, b->prm.cut_off, thd, b->audit_out.p, B, s);
             }
-            launch_band_select(b->oc.p, b->st.p, b->raymask.p, b->rayoff.p, b->ssdf.p, thd, b->pcnt.p, b->poff.p, b->plist.p, b->maxR, B, s);
-            launch_build_tiles(b->oc.p, b->st.p, B, 2, b->tiles_f.p, b->n_tiles.p, b->counters.p, 0, use_split_fwd(b) ? SPLIT_TILE_PTS : TILE_PTS, 0, s);
-            launch_decoder(b, 0, cursor);
+            if (spec) {
+                b->srow.ensure(b->cap_s);
+                b->jrow.ensure(b->cap_j);
+                launch_band_fused(b->oc.p, b->st.p, b->raymask.p, b->rayoff.p, b->ssdf.p, thd, b->pcnt.p, b->poff.p, b->plist.p, b->spts.p, b->jpts.p,
+                                  b->srow.p, B, s);
+                // forward + backward of surface points and band samples in one launch; the band samples' sdf lands in ssdf
+                launch_build_tiles(b->oc.p, b->st.p, B, 3, b->tiles_j.p, b->n_tiles.p + 1, b->counters.p, 0, use_split_rows(b) ? SPLIT_TILE_PTS : TILE_PTS, 1, s);
+                launch_decoder(b, 1, cursor);
+            } else {
+                if (fused) launch_band_fused(b->oc.p, b->st.p, b->raymask.p, b->rayoff.p, b->ssdf.p, thd, b->pcnt.p, b->poff.p, b->plist.p, nullptr, nullptr, nullptr, B, s);
+                else launch_band_select(b->oc.p, b->st.p, b->raymask.p, b->rayoff.p, b->ssdf.p, thd, b->pcnt.p, b->poff.p, b->plist.p, b->maxR, B, s);
+                launch_build_tiles(b->oc.p, b->st.p, B, 2, b->tiles_f.p, b->n_tiles.p, b->counters.p, 0, use_split_fwd(b) ? SPLIT_TILE_PTS : TILE_PTS, 0, s);
+                launch_decoder(b, 0, cursor);
+            }
         }
-        launch_render_scan(b->oc.p, b->st.p, b->raymask.p, b->rayoff.p, b->ssdf.p, b->depth.p, b->sdeds.p, b->ray_res.p,
-                           b->kcnt.p, b->mcnt.p, b->D, b->prm.cut_off, b->maxR, B, s);
-        launch_scan_rays(b->oc.p, b->st.p, b->kcnt.p, b->koff.p, 1, B, s);
-        launch_sum_m(b->oc.p, b->st.p, b->mcnt.p, B, s);
-        launch_render_write(b->oc.p, b->st.p, b->raycnt.p, b->rayoff.p, b->koff.p, b->spts.p, b->sdeds.p, b->ray_res.p,
-                            b->jpts.p, b->jaux.p, b->maxR, B, s);
+        if (fused) {
+            launch_render_fused(b->oc.p, b->st.p, b->raymask.p, b->raycnt.p, b->rayoff.p, b->ssdf.p, b->depth.p, b->spts.p, b->sdeds.p, b->ray_res.p,
+                                b->kcnt.p, b->koff.p, b->mcnt.p, b->jpts.p, b->jaux.p, spec ? b->srow.p : nullptr, spec ? b->jrow.p : nullptr, b->D,
+                                b->prm.cut_off, B, s);
+        } else {
+            launch_render_scan(b->oc.p, b->st.p, b->raymask.p, b->rayoff.p, b->ssdf.p, b->depth.p, b->sdeds.p, b->ray_res.p,
+                               b->kcnt.p, b->mcnt.p, b->D, b->prm.cut_off, b->maxR, B, s);
+            launch_scan_rays(b->oc.p, b->st.p, b->kcnt.p, b->koff.p, 1, B, s);
+            launch_sum_m(b->oc.p, b->st.p, b->mcnt.p, B, s);
+            launch_render_write(b->oc.p, b->st.p, b->raycnt.p, b->rayoff.p, b->koff.p, b->spts.p, b->sdeds.p, b->ray_res.p,
+                                b->jpts.p, b->jaux.p, b->maxR, B, s);
+        }
     }
-    launch_surface(b->oc.p, b->st.p, b->pts.p, b->jpts.p, b->jaux.p, b->maxM, B, s);
+    if (spec) return;       // the jacobian launch already ran, ahead of the occupancy scan
+    if (!fused) launch_surface(b->oc.p, b->st.p, b->pts.p, b->jpts.p, b->jaux.p, b->maxM, B, s);
     launch_build_tiles(b->oc.p, b->st.p, B, 1, b->tiles_j.p, b->n_tiles.p + 1, b->counters.p, 0, use_split_rows(b) ? SPLIT_TILE_PTS : TILE_PTS, 1, s);
     launch_decoder(b, 1, cursor);
     if (do_render && use_mask_reuse(b)) launch_decoder(b, 2, cursor);
@@ -913,10 +971,11 @@ void batch_run(dsp_batch* b) {
     else HIP_TRY(hipMemsetAsync(b->ray_hint.p, b->D / 2, b->sum_rays, s));   // no history yet: first guess = object centre
     const GnParamsDev dp = dev_params(b);
     for (int e = 0; e < iters; ++e) {
-        iteration_front(b, cursor, !b->pose_only);
-        launch_gram(b->oc.p, b->st.p, b->jpts.p, b->jaux.p, b->jgrad.p, b->pose_only ? b->alive.p : nullptr, b->partials.p,
+        iteration_front(b, cursor, !b->pose_only, e == 0);
+        launch_gram(b->oc.p, b->st.p, b->jpts.p, b->jaux.p, b->jgrad.p, use_speculative_band(b) ? b->jrow.p : nullptr, b->pose_only ? b->alive.p : nullptr, b->partials.p,
                     b->n_slices, b->prm.b2, b->prm.b1, b->pose_only ? 0 : 1, b->pose_only ? 1 : 2, B, s);
-        launch_solve(b->oc.p, b->st.p, b->partials.p, b->gsum.p, b->n_slices, dp, e, b->trace_on ? b->trace.p : nullptr, B, s);
+        launch_solve(b->oc.p, b->st.p, b->partials.p, b->gsum.p, b->n_slices, dp, e, b->trace_on ? b->trace.p : nullptr, h->codew.p, h->b0.p, h->blat.p,
+                     b->cbias.p, B, s);
         if (b->pose_only && e == 4) launch_inlier_filter(b->oc.p, b->st.p, b->jgrad.p, b->alive.p, b->maxM, B, s);
     }
     launch_finalize(b->st.p, b->scale_in.p, B, b->pose_only ? 1 : 0, b->out_t.p, b->out_code.p, b->out_loss.p, b->out_status.p, s);
@@ -1017,7 +1076,7 @@ void run_terms(dsp_handle* h, const float* pts_cam, int64_t n_pts, const float* 
     iteration_front(b.get(), cursor, render);
     const int cap = render ? (int)(n_rays * n_depths) : (int)n_pts;
     b->rows.alloc((size_t)std::max(cap, 1) * 72);
-    launch_jrows(b->oc.p, b->st.p, b->jpts.p, b->jaux.p, b->jgrad.p, term, b->rows.p, std::max(cap, 1), h->stream);
+    launch_jrows(b->oc.p, b->st.p, b->jpts.p, b->jaux.p, b->jgrad.p, (render && use_speculative_band(b.get())) ? b->jrow.p : nullptr, term, b->rows.p, std::max(cap, 1), h->stream);
     HIP_TRY(hipMemcpyAsync(&st, b->st.p, sizeof st, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipGetLastError());
@@ -1347,6 +1406,18 @@ int dsp_batch_set_prepass(dsp_batch* b, int mode, float delta) {
 int dsp_batch_set_prepass_audit(dsp_batch* b, int on) {
     if (!b) return DSP_E_ARG;
     b->prepass_audit = on != 0;
+    return DSP_OK;
+}
+
+int dsp_batch_set_speculative_band(dsp_batch* b, int mode) {
+    if (!b || mode < -1 || mode > 1) return DSP_E_ARG;
+    b->speculative = mode;
+    return DSP_OK;
+}
+
+int dsp_batch_set_fused_bookkeeping(dsp_batch* b, int mode) {
+    if (!b || mode < -1 || mode > 1) return DSP_E_ARG;
+    b->fused_bookkeeping = mode;
     return DSP_OK;
 }
 

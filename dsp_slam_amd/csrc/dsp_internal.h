@@ -59,6 +59,8 @@ struct MlpArgs {
     int seed_slot;              // MODE 3: mask slot of the last hidden layer
     float* out_sdf;             // FWD: [n_points]
     float* out_grad;            // BWD: [n_points][GRAD_STRIDE]
+    float* sdf_scatter;         // BWD, optional: tiles from *scatter_tile_begin on also store their sdf at sdf_scatter[int(pt.w)] (speculative band rows)
+    const int* scatter_tile_begin;
     const float* wsplit;        // latency form (mlp_split_kernel): the same chunks laid out per wave (see pack_decoder)
     int split_off[4];           //   first chunk of wave w's stream inside wsplit
     int split_len[4];           //   chunks wave w consumes per tile (forward + backward)
@@ -165,9 +167,18 @@ void launch_sample_write(const ObjConst* oc, const ObjState* st, const float* ra
                          float* ssdf, unsigned char* alive, int D, int maxR, int B, hipStream_t s);
 void launch_surface(const ObjConst* oc, const ObjState* st, const float* pts, float4* jpts, float2* jaux, int maxM, int B, hipStream_t s);
 void launch_build_tiles(const ObjConst* oc, const ObjState* st, int B, int mode, int4* tiles, int* n_tiles, double* counters, int add_v, int tile_pts,
-                        int cnt_slot, hipStream_t s);   // cnt_slot: counter the point count of a mode 0 / 2 list is added to
+                        int cnt_slot, hipStream_t s);   // mode 3 = mode 1 with the band samples (P) in place of the kept render rows (K)   // cnt_slot: counter the point count of a mode 0 / 2 list is added to
 void launch_band_select(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff, const float* ssdf, float thd,
                         int* pcnt, int* poff, int* plist, int maxR, int B, hipStream_t s);
+// fused per-object forms (latency path): front = sample_count + scan + sample_write + surface; band = count + scan + write;
+// render = render_scan + scan + sum_m + render_write
+void launch_front_fused(const ObjConst* oc, ObjState* st, const float* rays, const float* pts, unsigned long long* raymask, int* raycnt, int* rayoff,
+                        float4* spts, float* ssdf, unsigned char* alive, float4* jpts, float2* jaux, int D, int B, hipStream_t s);
+void launch_band_fused(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff, const float* ssdf, float thd, int* pcnt,
+                       int* poff, int* plist, const float4* spts, float4* jpts, int* srow, int B, hipStream_t s);   // jpts / srow: speculative band rows (or null)
+void launch_render_fused(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* raycnt, const int* rayoff, const float* ssdf,
+                         const float* depth, const float4* spts, float* sdeds, float* ray_res, int* kcnt, int* koff, int* mcnt, float4* jpts,
+                         float2* jaux, const int* srow, int* jrow, int D, float th, int B, hipStream_t s);
 void launch_prepass_audit(const ObjConst* oc, const ObjState* st, const float* ssdf, const float* saudit, float th, float thd, unsigned* out,
                           int B, hipStream_t s);
 void launch_render_scan(const ObjConst* oc, ObjState* st, const unsigned long long* m, const int* off, const float* ssdf, const float* depth,
@@ -188,11 +199,12 @@ void launch_pass_write(const ObjConst* oc, const ObjState* st, const unsigned lo
 void launch_pass_update(const ObjConst* oc, const ObjState* st, const unsigned long long* raymask, const int* rayoff, unsigned char* alive,
                         const float* ssdf, float th, const PassSpec& ps, int maxR, int B, hipStream_t s);
 void launch_sum_m(const ObjConst* oc, ObjState* st, const int* mcnt, int B, hipStream_t s);
-void launch_gram(const ObjConst* oc, const ObjState* st, const float4* jpts, const float2* jaux, const float* jgrad, const unsigned char* alive,
-                 float* partials, int n_slices, float b_sdf, float b_render, int robust, int n_terms, int B, hipStream_t s);
-void launch_jrows(const ObjConst* oc, const ObjState* st, const float4* jpts, const float2* jaux, const float* jgrad, int term, float* rows, int cap, hipStream_t s);
+void launch_gram(const ObjConst* oc, const ObjState* st, const float4* jpts, const float2* jaux, const float* jgrad, const int* jrow,
+                 const unsigned char* alive, float* partials, int n_slices, float b_sdf, float b_render, int robust, int n_terms, int B, hipStream_t s);
+void launch_jrows(const ObjConst* oc, const ObjState* st, const float4* jpts, const float2* jaux, const float* jgrad, const int* jrow, int term, float* rows,
+                  int cap, hipStream_t s);   // jrow (optional): render row i takes its gradient from jgrad row jrow[i]
 void launch_solve(const ObjConst* oc, ObjState* st, const float* partials, double* gsum, int n_slices, const GnParamsDev& prm, int iter,
-                  float* trace, int B, hipStream_t s);
+                  float* trace, const float* codew, const float* b0, const float* blat, float* cbias, int B, hipStream_t s);   // cbias: next iteration's code bias
 void launch_inlier_filter(const ObjConst* oc, ObjState* st, const float* jgrad, unsigned char* alive, int maxM, int B, hipStream_t s);
 void launch_finalize(ObjState* st, const float* scale, int B, int pose_only, float* t, float* code, float* loss, int* status, hipStream_t s);
 

@@ -128,12 +128,8 @@ __device__ __forceinline__ unsigned id_hash(unsigned id) { return (id * 26544357
 // ------------------------------------------------------------------------------------------------
 // ray sampling: in-sphere mask + count per ray  (loss.py:60-70)
 // ------------------------------------------------------------------------------------------------
-__global__ void k_sample_count(const ObjConst* oc, ObjState* st, const float* rays, unsigned long long* raymask,
-                               int* raycnt, int n_depth) {
-    const int b = blockIdx.y;
-    const ObjConst c = oc[b];
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= c.n_rays) return;
+__device__ __forceinline__ void sample_count_ray(const ObjConst& c, ObjState* st, int b, const float* rays, unsigned long long* raymask,
+                                                 int* raycnt, int n_depth, int r) {
     const ObjState& s = st[b];
     unsigned long long mask = 0ull;
     if (s.status == DSP_STATUS_GOOD) {
@@ -153,28 +149,49 @@ __global__ void k_sample_count(const ObjConst* oc, ObjState* st, const float* ra
     if (h) atomicAdd(&st[b].vsum, h);
 }
 
-// exclusive scan of per-ray counts inside each object (one workgroup per object)
-__global__ __launch_bounds__(256) void k_scan_rays(const ObjConst* oc, ObjState* st, const int* cnt, int* off, int which) {
-    __shared__ int part[256];
-    const int b = blockIdx.x;
+__global__ void k_sample_count(const ObjConst* oc, ObjState* st, const float* rays, unsigned long long* raymask,
+                               int* raycnt, int n_depth) {
+    const int b = blockIdx.y;
     const ObjConst c = oc[b];
-    const int tid = threadIdx.x;
-    const int per = (c.n_rays + 255) / 256;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= c.n_rays) return;
+    sample_count_ray(c, st, b, rays, raymask, raycnt, n_depth, r);
+}
+
+// exclusive scan of per-ray counts inside each object (one workgroup per object)
+// (NT = threads of the workgroup, a multiple of 64; part = NT ints of LDS.)  Thread t owns a contiguous chunk of rays; chunk sums
+// are scanned inside each wave with shuffles and across the <= 16 waves through LDS: three barriers.
+template <int NT>
+__device__ __forceinline__ void scan_rays_block(const ObjConst& c, ObjState* st, int b, const int* cnt, int* off, int which, int* part) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NWV = NT / 64;
+    const int per = (c.n_rays + NT - 1) / NT;
     const int lo = min(tid * per, c.n_rays), hi = min(lo + per, c.n_rays);
     int sum = 0;
     for (int r = lo; r < hi; ++r) sum += cnt[c.ray_off + r];
-    part[tid] = sum;
-    __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {
-        const int v = (tid >= d) ? part[tid - d] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+    int incl = sum;                                 // inclusive scan of the chunk sums inside the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d);
+        if (lane >= d) incl += v;
     }
-    int run = part[tid] - sum;
+    __syncthreads();                                // part may still be read by an earlier phase of the caller
+    if (lane == 63) part[wave] = incl;
+    __syncthreads();
+    if (wave == 0) {
+        int w = lane < NWV ? part[lane] : 0;
+#pragma unroll
+        for (int d = 1; d < NWV; d <<= 1) {
+            const int v = __shfl_up(w, d);
+            if (lane >= d) w += v;
+        }
+        if (lane < NWV) part[NWV + lane] = w;       // inclusive scan of the wave totals
+    }
+    __syncthreads();
+    int run = incl - sum + (wave ? part[NWV + wave - 1] : 0);
     for (int r = lo; r < hi; ++r) { off[c.ray_off + r] = run; run += cnt[c.ray_off + r]; }
-    if (tid == 255) {
-        const int total = part[255];
+    if (tid == NT - 1) {
+        const int total = part[2 * NWV - 1];
         ObjState& s = st[b];
         if (which == 0) {
             s.V = total;
@@ -187,13 +204,15 @@ __global__ __launch_bounds__(256) void k_scan_rays(const ObjConst* oc, ObjState*
     }
 }
 
-__global__ void k_sample_write(const ObjConst* oc, const ObjState* st, const float* rays, const unsigned long long* raymask,
-                               const int* rayoff, float4* spts, float* ssdf, unsigned char* alive, int n_depth) {
-    const int b = blockIdx.y;
+__global__ __launch_bounds__(256) void k_scan_rays(const ObjConst* oc, ObjState* st, const int* cnt, int* off, int which) {
+    __shared__ int part[256];
+    const int b = blockIdx.x;
     const ObjConst c = oc[b];
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= c.n_rays) return;
-    const ObjState& s = st[b];
+    scan_rays_block<256>(c, st, b, cnt, off, which, part);
+}
+
+__device__ __forceinline__ void sample_write_ray(const ObjConst& c, const ObjState& s, const float* rays, const unsigned long long* raymask,
+                                                 const int* rayoff, float4* spts, float* ssdf, unsigned char* alive, int n_depth, int r) {
     if (s.status != DSP_STATUS_GOOD) return;
     unsigned long long mask = raymask[c.ray_off + r];
     const float* d3 = rays + 3 * (size_t)(c.ray_off + r);
@@ -210,6 +229,15 @@ __global__ void k_sample_write(const ObjConst* oc, const ObjState* st, const flo
         *sd++ = 1.0f;   // "not evaluated": free space (o = 0).  Only samples BEHIND a solid one stay unevaluated, where the
                         // transmittance is exactly 0, so the value cannot reach d_u, de_do, H or b (see k_pass_update).
     }
+}
+
+__global__ void k_sample_write(const ObjConst* oc, const ObjState* st, const float* rays, const unsigned long long* raymask,
+                               const int* rayoff, float4* spts, float* ssdf, unsigned char* alive, int n_depth) {
+    const int b = blockIdx.y;
+    const ObjConst c = oc[b];
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= c.n_rays) return;
+    sample_write_ray(c, st[b], rays, raymask, rayoff, spts, ssdf, alive, n_depth, r);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -309,15 +337,11 @@ __global__ void k_pass_update(const ObjConst* oc, const ObjState* st, const unsi
 // 0, so nothing there can reach the result.  What is left for the fp32 kernel: the samples IN FRONT of a ray's first
 // certainly-solid sample whose |sdf_lp| < th + delta.  Their exact values then replace the low-precision ones in ssdf; the
 // classified samples keep sdf_lp (any value beyond +-th gives the same occupancy bit for bit).
-__global__ void k_band_count(const ObjConst* oc, const ObjState* st, const unsigned long long* raymask, const int* rayoff,
-                             const float* ssdf, float thd, int* pcnt) {
-    const int b = blockIdx.y;
-    const ObjConst c = oc[b];
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= c.n_rays) return;
+__device__ __forceinline__ void band_count_ray(const ObjConst& c, const ObjState& s, const unsigned long long* raymask, const int* rayoff,
+                                               const float* ssdf, float thd, int* pcnt, int r) {
     const int gr = c.ray_off + r;
     int n = 0;
-    if (st[b].status == DSP_STATUS_GOOD) {
+    if (s.status == DSP_STATUS_GOOD) {
         const int cnt = __popcll(raymask[gr]);
         const float* sd = ssdf + c.samp_off + rayoff[gr];
         for (int i = 0; i < cnt; ++i) {
@@ -329,14 +353,10 @@ __global__ void k_band_count(const ObjConst* oc, const ObjState* st, const unsig
     pcnt[gr] = n;
 }
 
-__global__ void k_band_write(const ObjConst* oc, const ObjState* st, const unsigned long long* raymask, const int* rayoff,
-                             const float* ssdf, float thd, const int* poff, int* plist) {
-    const int b = blockIdx.y;
-    const ObjConst c = oc[b];
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= c.n_rays) return;
+__device__ __forceinline__ void band_write_ray(const ObjConst& c, const ObjState& s, const unsigned long long* raymask, const int* rayoff,
+                                               const float* ssdf, float thd, const int* poff, int* plist, int r) {
     const int gr = c.ray_off + r;
-    if (st[b].status != DSP_STATUS_GOOD) return;
+    if (s.status != DSP_STATUS_GOOD) return;
     const int cnt = __popcll(raymask[gr]);
     const int base = c.samp_off + rayoff[gr];
     int* dst = plist + c.samp_off + poff[gr];
@@ -345,6 +365,24 @@ __global__ void k_band_write(const ObjConst* oc, const ObjState* st, const unsig
         if (v <= -thd) break;
         if (fabsf(v) < thd) *dst++ = base + i;
     }
+}
+
+__global__ void k_band_count(const ObjConst* oc, const ObjState* st, const unsigned long long* raymask, const int* rayoff,
+                             const float* ssdf, float thd, int* pcnt) {
+    const int b = blockIdx.y;
+    const ObjConst c = oc[b];
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= c.n_rays) return;
+    band_count_ray(c, st[b], raymask, rayoff, ssdf, thd, pcnt, r);
+}
+
+__global__ void k_band_write(const ObjConst* oc, const ObjState* st, const unsigned long long* raymask, const int* rayoff,
+                             const float* ssdf, float thd, const int* poff, int* plist) {
+    const int b = blockIdx.y;
+    const ObjConst c = oc[b];
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= c.n_rays) return;
+    band_write_ray(c, st[b], raymask, rayoff, ssdf, thd, poff, plist, r);
 }
 
 // audit (tests / calibration): saudit = fp32 sdf of EVERY in-sphere sample, ssdf = prepass values (+1 where not decoded).
@@ -373,17 +411,20 @@ __global__ void k_prepass_audit(const ObjConst* oc, const ObjState* st, const fl
 }
 
 // surface points -> object frame (loss.py:31-32); also the pose-only inlier bookkeeping (optimizer.py:76-78)
-__global__ void k_surface(const ObjConst* oc, const ObjState* st, const float* pts, float4* jpts, float2* jaux) {
-    const int b = blockIdx.y;
-    const ObjConst c = oc[b];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= c.n_pts) return;
-    const ObjState& s = st[b];
+__device__ __forceinline__ void surface_point(const ObjConst& c, const ObjState& s, const float* pts, float4* jpts, float2* jaux, int i) {
     if (s.status != DSP_STATUS_GOOD) return;
     const float* p = pts + 3 * (size_t)(c.pts_off + i);
     const float3 o = xform(s.t_oc, p[0], p[1], p[2]);
     jpts[c.jsdf_off + i] = make_float4(o.x, o.y, o.z, __int_as_float(i));
     jaux[c.jsdf_off + i] = make_float2(1.f, 0.f);
+}
+
+__global__ void k_surface(const ObjConst* oc, const ObjState* st, const float* pts, float4* jpts, float2* jaux) {
+    const int b = blockIdx.y;
+    const ObjConst c = oc[b];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c.n_pts) return;
+    surface_point(c, st[b], pts, jpts, jaux, i);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -400,21 +441,22 @@ __global__ __launch_bounds__(256) void k_build_tiles(const ObjConst* oc, const O
     int n_surface_tiles = 0;
     // mode 1 lists every object's surface tiles first and the render tiles after them, so that the two jacobian launches
     // (forward+backward / backward-only) each take one contiguous range
-    for (int phase = 0; phase < (mode == 1 ? 2 : 1); ++phase) {
+    const bool jac = mode == 1 || mode == 3;   // mode 3: the band samples (P) stand in for the kept render rows (K): speculative band rows
+    for (int phase = 0; phase < (jac ? 2 : 1); ++phase) {
         for (int b = 0; b < n_obj; ++b) {
             const ObjConst c = oc[b];
             const ObjState& s = st[b];
             const bool good = s.status == DSP_STATUS_GOOD;
             const int b0 = base;
             __syncthreads();
-            if (mode != 1) {
+            if (!jac) {
                 const int n = good ? (mode == 0 ? s.V : s.P) : 0;
                 const int nt = (n + tile_pts - 1) / tile_pts;
                 for (int i = threadIdx.x; i < nt; i += 256)
                     tiles[b0 + i] = make_int4(c.samp_off + i * tile_pts, min(tile_pts, n - i * tile_pts), b, 0);
                 if (threadIdx.x == 0) { base = b0 + nt; cnt += n; if (good) vtot += s.V; }
             } else {
-                const int n = good ? (phase == 0 ? c.n_pts : s.K) : 0;
+                const int n = good ? (phase == 0 ? c.n_pts : (mode == 3 ? s.P : s.K)) : 0;
                 const int off = phase == 0 ? c.jsdf_off : c.jren_off;
                 const int nt = (n + tile_pts - 1) / tile_pts;
                 for (int i = threadIdx.x; i < nt; i += 256)
@@ -427,10 +469,10 @@ __global__ __launch_bounds__(256) void k_build_tiles(const ObjConst* oc, const O
     }
     if (threadIdx.x == 0) {
         n_tiles[0] = base;
-        if (mode == 1) n_tiles[1] = n_surface_tiles;
-        counters[mode == 1 ? 1 : cnt_slot] += cnt;
+        if (jac) n_tiles[1] = n_surface_tiles;
+        counters[jac ? 1 : cnt_slot] += cnt;
         if (add_v) counters[2] += vtot;
-        if (mode == 1) counters[3] += rows;
+        if (jac) counters[3] += rows;
     }
 }
 
@@ -440,13 +482,9 @@ __global__ __launch_bounds__(256) void k_build_tiles(const ObjConst* oc, const O
 // One thread per ray, the 50-sample row kept in registers.  Pass 1 (count): occupancy o_j, T_l =
 // prod_{i<=l}(1-o_i), rendered depth d_u, suffix sums for de_do, keeps samples with |sdf| < th and
 // de_do > 1e-2; stores de_ds per compact sample (0 = dropped), d_u per ray and the kept count.
-__global__ __launch_bounds__(256) void k_render_scan(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff,
-                              const float* ssdf, const float* depth_fg, float* sdeds, float* ray_res, int* kcnt, int* mcnt,
-                              int n_depth, float th) {
-    const int b = blockIdx.y;
-    const ObjConst c = oc[b];
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= c.n_rays) return;
+__device__ __forceinline__ void render_scan_ray(const ObjConst& c, ObjState* st, int b, const unsigned long long* raymask, const int* rayoff,
+                                                const float* ssdf, const float* depth_fg, float* sdeds, float* ray_res, int* kcnt, int* mcnt,
+                                                int n_depth, float th, int r) {
     const ObjState& s = st[b];
     const int gr = c.ray_off + r;
     if (s.status != DSP_STATUS_GOOD) { kcnt[gr] = 0; mcnt[gr] = 0; return; }
@@ -454,15 +492,20 @@ __global__ __launch_bounds__(256) void k_render_scan(const ObjConst* oc, ObjStat
     const int base = c.samp_off + rayoff[gr];
     float o[64], T[64];
     unsigned long long wg = 0ull;   // with_grad: -th < sdf < th  (loss.py:88)
+    // the ray's samples first, as 64 INDEPENDENT loads (sample of depth index j sits at compact position popc(mask below j)): loaded
+    // inside the sequential transmittance chain below they cost one memory latency each, 50 in a row
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+        const bool in = j < n_depth && ((mask >> j) & 1ull);
+        o[j] = ssdf[in ? base + __popcll(mask & ((1ull << j) - 1ull)) : c.samp_off];
+    }
     {
-        int k = 0;
         float acc = 1.f;
 #pragma unroll
         for (int j = 0; j < 64; ++j) {
             float oj = 0.f;
             if (j < n_depth && ((mask >> j) & 1ull)) {
-                const float sd = ssdf[base + k];
-                ++k;
+                const float sd = o[j];
                 const float cl = fminf(fmaxf(sd, -th), th);
                 oj = __fsub_rn(0.5f, __fdiv_rn(cl, __fmul_rn(2.f, th)));   // sdf_to_occupancy (loss_utils.py:40-48)
                 if (sd > -th && sd < th) wg |= 1ull << j;
@@ -517,28 +560,208 @@ __global__ __launch_bounds__(256) void k_render_scan(const ObjConst* oc, ObjStat
     if (khash) atomicAdd(&st[b].ksum, khash);
 }
 
-__global__ void k_render_write(const ObjConst* oc, const ObjState* st, const int* raycnt, const int* rayoff, const int* koff,
+__global__ __launch_bounds__(256) void k_render_scan(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff,
+                              const float* ssdf, const float* depth_fg, float* sdeds, float* ray_res, int* kcnt, int* mcnt,
+                              int n_depth, float th) {
+    const int b = blockIdx.y;
+    const ObjConst c = oc[b];
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= c.n_rays) return;
+    render_scan_ray(c, st, b, raymask, rayoff, ssdf, depth_fg, sdeds, ray_res, kcnt, mcnt, n_depth, th, r);
+}
+
+__device__ __forceinline__ void render_write_ray(const ObjConst& c, const ObjState& s, const int* raycnt, const int* rayoff, const int* koff,
+                                                 const float4* spts, const float* sdeds, const float* ray_res, float4* jpts, float2* jaux, int r,
+                                                 const int* srow = nullptr, int* jrow = nullptr) {
+    if (s.status != DSP_STATUS_GOOD) return;
+    const int gr = c.ray_off + r;
+    const int n = raycnt[gr];
+    const int base = c.samp_off + rayoff[gr];
+    const int dst0 = c.jren_off + koff[gr];
+    const float res = ray_res[gr];
+    // kept samples of the ray = those with de_ds != 0: found with independent loads (no pointer chasing along the ray), then the
+    // few kept ones (typically 2-4 of 50) are written
+    unsigned long long kept = 0ull;
+#pragma unroll
+    for (int k = 0; k < 64; ++k) {
+        const float dv = sdeds[k < n ? base + k : c.samp_off];
+        if (k < n && dv != 0.f) kept |= 1ull << k;
+    }
+    int dst = dst0;
+    while (kept) {
+        const int k = __ffsll((long long)kept) - 1;
+        kept &= kept - 1;
+        float4 p = spts[base + k];
+        p.w = __int_as_float(base + k);   // compact sample index: where the forward launch left this sample's sdf and relu masks
+        jpts[dst] = p;
+        jaux[dst] = make_float2(sdeds[base + k], res);
+        if (jrow) jrow[dst] = srow[base + k];     // speculative band rows: this row's gradient already sits in jgrad row srow[sample]
+        ++dst;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_render_write(const ObjConst* oc, const ObjState* st, const int* raycnt, const int* rayoff, const int* koff,
                                const float4* spts, const float* sdeds, const float* ray_res, float4* jpts, float2* jaux) {
     const int b = blockIdx.y;
     const ObjConst c = oc[b];
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= c.n_rays) return;
-    if (st[b].status != DSP_STATUS_GOOD) return;
-    const int gr = c.ray_off + r;
-    const int n = raycnt[gr];
-    const int base = c.samp_off + rayoff[gr];
-    int dst = c.jren_off + koff[gr];
-    const float res = ray_res[gr];
-    for (int k = 0; k < n; ++k) {
-        const float deds = sdeds[base + k];
-        if (deds != 0.f) {
-            float4 p = spts[base + k];
-            p.w = __int_as_float(base + k);   // compact sample index: where the forward launch left this sample's sdf and relu masks
-            jpts[dst] = p;
-            jaux[dst] = make_float2(deds, res);
-            ++dst;
+    render_write_ray(c, st[b], raycnt, rayoff, koff, spts, sdeds, ray_res, jpts, jaux, r);
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused per-object forms of the bookkeeping above (latency path): one workgroup per object runs the per-ray bodies, the scan
+// and the compaction back to back -- the same device functions, so the same bits -- instead of three or four launches.
+// ------------------------------------------------------------------------------------------------
+constexpr int FUSED_THREADS = 1024;
+
+// k_sample_count + k_scan_rays(0) + k_sample_write (+ k_surface)
+// One wave per ray, lane = depth index.  Everything a ray needs besides its direction is loaded once (this lane's depth sample, the
+// pose), and the next ray's direction / mask / offset are fetched before the current ray is processed, so no iteration waits for memory.
+__global__ __launch_bounds__(FUSED_THREADS) void k_front_fused(const ObjConst* oc, ObjState* st, const float* __restrict__ rays, const float* pts,
+                                                               unsigned long long* raymask, int* raycnt, int* rayoff, float4* spts, float* ssdf,
+                                                               unsigned char* alive, float4* jpts, float2* jaux, int n_depth) {
+    __shared__ int part[FUSED_THREADS];
+    const int b = blockIdx.x;
+    const ObjConst c = oc[b];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NW = FUSED_THREADS / 64;
+    const bool good0 = st[b].status == DSP_STATUS_GOOD;
+    float T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = st[b].t_oc[i];
+    const float dj = st[b].depths[lane < n_depth ? lane : 0];
+    const float* rbase = rays + 3 * (size_t)c.ray_off;
+    unsigned hsum = 0;
+    {
+        float nx = 0.f, ny = 0.f, nz = 0.f;
+        if (wave < c.n_rays) { nx = rbase[3 * wave]; ny = rbase[3 * wave + 1]; nz = rbase[3 * wave + 2]; }
+        for (int r = wave; r < c.n_rays; r += NW) {
+            const float dx = nx, dy = ny, dz = nz;
+            if (r + NW < c.n_rays) { nx = rbase[3 * (r + NW)]; ny = rbase[3 * (r + NW) + 1]; nz = rbase[3 * (r + NW) + 2]; }
+            bool in = false;
+            if (good0 && lane < n_depth) {
+                const float3 p = xform(T, __fmul_rn(dx, dj), __fmul_rn(dy, dj), __fmul_rn(dz, dj));
+                const float n2 = __fadd_rn(__fadd_rn(__fmul_rn(p.x, p.x), __fmul_rn(p.y, p.y)), __fmul_rn(p.z, p.z));
+                in = __fsqrt_rn(n2) < 1.0f;
+            }
+            const unsigned long long mask = __ballot(in);
+            if (in) hsum += id_hash(((unsigned)r << 6) | (unsigned)lane);
+            if (lane == 0) { raymask[c.ray_off + r] = mask; raycnt[c.ray_off + r] = __popcll(mask); }
         }
     }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) hsum += __shfl_xor(hsum, d);
+    if (lane == 0 && hsum) atomicAdd(&st[b].vsum, hsum);
+    __syncthreads();
+    scan_rays_block<FUSED_THREADS>(c, st, b, raycnt, rayoff, 0, part);
+    __syncthreads();
+    if (st[b].status == DSP_STATUS_GOOD) {
+        float nx = 0.f, ny = 0.f, nz = 0.f;
+        unsigned long long nmask = 0ull;
+        int noff = 0;
+        if (wave < c.n_rays) {
+            nx = rbase[3 * wave]; ny = rbase[3 * wave + 1]; nz = rbase[3 * wave + 2];
+            nmask = raymask[c.ray_off + wave]; noff = rayoff[c.ray_off + wave];
+        }
+        for (int r = wave; r < c.n_rays; r += NW) {
+            const float dx = nx, dy = ny, dz = nz;
+            const unsigned long long mask = nmask;
+            const int dst = c.samp_off + noff;
+            if (r + NW < c.n_rays) {
+                nx = rbase[3 * (r + NW)]; ny = rbase[3 * (r + NW) + 1]; nz = rbase[3 * (r + NW) + 2];
+                nmask = raymask[c.ray_off + r + NW]; noff = rayoff[c.ray_off + r + NW];
+            }
+            if (lane == 0) alive[c.ray_off + r] = mask ? 1 : 0;
+            if ((mask >> lane) & 1ull) {
+                const float3 p = xform(T, __fmul_rn(dx, dj), __fmul_rn(dy, dj), __fmul_rn(dz, dj));
+                const int k = __popcll(mask & ((1ull << lane) - 1ull));
+                spts[dst + k] = make_float4(p.x, p.y, p.z, __int_as_float((r << 6) | lane));
+                ssdf[dst + k] = 1.0f;   // "not evaluated": free space (see sample_write_ray)
+            }
+        }
+    }
+    for (int i = threadIdx.x; i < c.n_pts; i += FUSED_THREADS) surface_point(c, st[b], pts, jpts, jaux, i);
+}
+
+// k_band_count + k_scan_rays(2) + k_band_write: one THREAD per ray, the ray's <= 64 sample values as independent loads (the
+// front-to-back walk of band_count_ray becomes mask arithmetic: first certainly-solid sample = lowest set bit)
+__device__ __forceinline__ unsigned long long band_select_thread(const ObjConst& c, const unsigned long long* raymask, const int* rayoff,
+                                                                 const float* ssdf, float thd, int r, int& base) {
+    const int gr = c.ray_off + r;
+    const int cnt = __popcll(raymask[gr]);
+    base = c.samp_off + rayoff[gr];
+    unsigned long long solid = 0ull, band = 0ull;
+#pragma unroll
+    for (int k = 0; k < 64; ++k) {
+        const float v = ssdf[k < cnt ? base + k : c.samp_off];
+        if (k < cnt && v <= -thd) solid |= 1ull << k;
+        if (k < cnt && fabsf(v) < thd) band |= 1ull << k;
+    }
+    const int first = solid ? __ffsll((long long)solid) - 1 : 64;     // samples from the first certainly-solid one on are skipped
+    return first >= 64 ? band : band & ((1ull << first) - 1ull);
+}
+
+__global__ __launch_bounds__(FUSED_THREADS) void k_band_fused(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff,
+                                                              const float* ssdf, float thd, int* pcnt, int* poff, int* plist, const float4* spts,
+                                                              float4* jpts, int* srow) {
+    __shared__ int part[FUSED_THREADS];
+    const int b = blockIdx.x;
+    const ObjConst c = oc[b];
+    const bool good = st[b].status == DSP_STATUS_GOOD;
+    int base;
+    for (int r = threadIdx.x; r < c.n_rays; r += FUSED_THREADS) pcnt[c.ray_off + r] = good ? __popcll(band_select_thread(c, raymask, rayoff, ssdf, thd, r, base)) : 0;
+    __syncthreads();
+    scan_rays_block<FUSED_THREADS>(c, st, b, pcnt, poff, 2, part);
+    __syncthreads();
+    if (good) {
+        for (int r = threadIdx.x; r < c.n_rays; r += FUSED_THREADS) {
+            unsigned long long sel = band_select_thread(c, raymask, rayoff, ssdf, thd, r, base);
+            int pos = poff[c.ray_off + r];
+            while (sel) {
+                const int idx = base + __ffsll((long long)sel) - 1;
+                sel &= sel - 1;
+                plist[c.samp_off + pos] = idx;
+                if (jpts) {   // speculative band rows: the sample goes straight into the jacobian launch (forward + backward), row jren_off + pos
+                    float4 p = spts[idx];
+                    p.w = __int_as_float(idx);
+                    jpts[c.jren_off + pos] = p;
+                    srow[idx] = c.jren_off + pos;
+                }
+                ++pos;
+            }
+        }
+    }
+}
+
+// k_render_scan + k_scan_rays(1) + k_sum_m + k_render_write
+constexpr int RENDER_FUSED_THREADS = 512;   // render_scan_ray keeps a ray's 64-entry occupancy and transmittance rows in registers
+__global__ __launch_bounds__(RENDER_FUSED_THREADS) void k_render_fused(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* raycnt,
+                                                                const int* rayoff, const float* ssdf, const float* depth_fg, const float4* spts,
+                                                                float* sdeds, float* ray_res, int* kcnt, int* koff, int* mcnt, float4* jpts,
+                                                                float2* jaux, const int* srow, int* jrow, int n_depth, float th) {
+    __shared__ int part[RENDER_FUSED_THREADS];
+    const int b = blockIdx.x;
+    const ObjConst c = oc[b];
+    for (int r = threadIdx.x; r < c.n_rays; r += RENDER_FUSED_THREADS) {
+        if (st[b].status != DSP_STATUS_GOOD) { kcnt[c.ray_off + r] = 0; mcnt[c.ray_off + r] = 0; }
+        else render_scan_ray(c, st, b, raymask, rayoff, ssdf, depth_fg, sdeds, ray_res, kcnt, mcnt, n_depth, th, r);
+    }
+    __syncthreads();
+    scan_rays_block<RENDER_FUSED_THREADS>(c, st, b, kcnt, koff, 1, part);
+    __syncthreads();
+    {   // k_sum_m
+        int sum = 0;
+        for (int r = threadIdx.x; r < c.n_rays; r += RENDER_FUSED_THREADS) sum += mcnt[c.ray_off + r];
+        part[threadIdx.x] = sum;
+        __syncthreads();
+        for (int d = RENDER_FUSED_THREADS / 2; d > 0; d >>= 1) {
+            if (threadIdx.x < d) part[threadIdx.x] += part[threadIdx.x + d];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) st[b].m = part[0];
+    }
+    for (int r = threadIdx.x; r < c.n_rays; r += RENDER_FUSED_THREADS) render_write_ray(c, st[b], raycnt, rayoff, koff, spts, sdeds, ray_res, jpts, jaux, r, srow, jrow);
 }
 
 __global__ __launch_bounds__(256) void k_sum_m(const ObjConst* oc, ObjState* st, const int* mcnt) {
@@ -587,7 +810,7 @@ constexpr int GRAM_PTS = 32;    // points staged per step
 constexpr int JLD = 73;         // LDS row stride (odd: conflict-free column access)
 
 __global__ __launch_bounds__(256) void k_gram(const ObjConst* oc, const ObjState* st, const float4* jpts, const float2* jaux,
-                                              const float* jgrad, const unsigned char* alive, float* partials, int n_slices,
+                                              const float* jgrad, const int* jrow, const unsigned char* alive, float* partials, int n_slices,
                                               float b_sdf, float b_render, int robust) {
     __shared__ float J[GRAM_PTS * JLD];
     const int slice = blockIdx.x, b = blockIdx.y, term = blockIdx.z;
@@ -614,7 +837,8 @@ __global__ __launch_bounds__(256) void k_gram(const ObjConst* oc, const ObjState
             float* row = J + tid * JLD;
             if (tid < np && (alive == nullptr || term != 0 || alive[off + p0 + tid])) {
                 const int idx = off + p0 + tid;
-                build_row(jgrad + (size_t)idx * GRAD_STRIDE, jpts[idx], jaux[idx], term, hb, robust, row);
+                const int gi = (term == 1 && jrow) ? jrow[idx] : idx;     // speculative band rows: the gradient stays where the launch wrote it
+                build_row(jgrad + (size_t)gi * GRAD_STRIDE, jpts[idx], jaux[idx], term, hb, robust, row);
             } else {
                 for (int i = 0; i < 72; ++i) row[i] = 0.f;
             }
@@ -646,14 +870,15 @@ __global__ __launch_bounds__(256) void k_gram(const ObjConst* oc, const ObjState
 
 // J rows to memory, for the stand-alone compute_sdf_loss / compute_render_loss entry points
 __global__ void k_jrows(const ObjConst* oc, const ObjState* st, const float4* jpts, const float2* jaux, const float* jgrad,
-                        int term, float* rows /*[n][72]*/) {
+                        const int* jrow, int term, float* rows /*[n][72]*/) {
     const ObjConst c = oc[0];
     const int n = (term == 0) ? c.n_pts : st[0].K;
     const int off = (term == 0) ? c.jsdf_off : c.jren_off;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float row[72];
-    build_row(jgrad + (size_t)(off + i) * GRAD_STRIDE, jpts[off + i], jaux[off + i], term, 0.f, 0, row);
+    const int gi = (term == 1 && jrow) ? jrow[off + i] : off + i;
+    build_row(jgrad + (size_t)gi * GRAD_STRIDE, jpts[off + i], jaux[off + i], term, 0.f, 0, row);
     for (int k = 0; k < 72; ++k) rows[(size_t)i * 72 + k] = row[k];
 }
 
@@ -768,6 +993,7 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const ObjState* st, const f
 constexpr int SOLVE_THREADS = 1024;   // 16 waves: the elimination is instruction-issue bound, so it is spread over 12 row groups x 72 columns
 
 __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, ObjState* st, const double* gsum, GnParamsDev prm, int iter,
+                                                         const float* codew, const float* cb0, const float* cblat, float* cbias,
                                                float* trace /*nullable*/, int n_obj) {
     __shared__ double A[NSOLVE][NSOLVE + 1];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -966,6 +1192,20 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
         if (!prm.pose_only) derive_iter_state(s, prm.n_depth);
         if (stamp) g_solve_clk[4] = wall_clock64();
     }
+    // 4. the next iteration's per-object code bias (k_code_bias: same k-ordered fmaf chains), while this workgroup holds the new code
+    if (!prm.pose_only && cbias) {
+        __shared__ float zc[CODE_LEN];
+        __syncthreads();
+        if (tid < CODE_LEN) zc[tid] = s.code[tid];
+        __syncthreads();
+        for (int e = tid; e < 2 * WIDTH; e += SOLVE_THREADS) {
+            const int which = e / WIDTH, o = e % WIDTH;
+            float acc = which == 0 ? cb0[o] : cblat[o];
+            const float* w = codew + (size_t)e * CODE_LEN;
+            for (int cidx = 0; cidx < CODE_LEN; ++cidx) acc = fmaf(w[cidx], zc[cidx], acc);
+            cbias[(size_t)b * 2 * WIDTH + e] = acc;
+        }
+    }
 }
 
 // pose-only inlier filter at e == 4 (optimizer.py:76-78): keep |r| <= 0.05 for the following iterations
@@ -1072,6 +1312,20 @@ void launch_prepass_audit(const ObjConst* oc, const ObjState* st, const float* s
                           int B, hipStream_t s) {
     hipLaunchKernelGGL(k_prepass_audit, dim3(64, B), dim3(256), 0, s, oc, st, ssdf, saudit, th, thd, out);
 }
+void launch_front_fused(const ObjConst* oc, ObjState* st, const float* rays, const float* pts, unsigned long long* raymask, int* raycnt, int* rayoff,
+                        float4* spts, float* ssdf, unsigned char* alive, float4* jpts, float2* jaux, int D, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_front_fused, dim3(B), dim3(FUSED_THREADS), 0, s, oc, st, rays, pts, raymask, raycnt, rayoff, spts, ssdf, alive, jpts, jaux, D);
+}
+void launch_band_fused(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff, const float* ssdf, float thd, int* pcnt,
+                       int* poff, int* plist, const float4* spts, float4* jpts, int* srow, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_band_fused, dim3(B), dim3(FUSED_THREADS), 0, s, oc, st, raymask, rayoff, ssdf, thd, pcnt, poff, plist, spts, jpts, srow);
+}
+void launch_render_fused(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* raycnt, const int* rayoff, const float* ssdf,
+                         const float* depth, const float4* spts, float* sdeds, float* ray_res, int* kcnt, int* koff, int* mcnt, float4* jpts,
+                         float2* jaux, const int* srow, int* jrow, int D, float th, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_render_fused, dim3(B), dim3(RENDER_FUSED_THREADS), 0, s, oc, st, raymask, raycnt, rayoff, ssdf, depth, spts, sdeds, ray_res, kcnt, koff,
+                       mcnt, jpts, jaux, srow, jrow, D, th);
+}
 void launch_surface(const ObjConst* oc, const ObjState* st, const float* pts, float4* jpts, float2* jaux, int maxM, int B, hipStream_t s) {
     hipLaunchKernelGGL(k_surface, GRID2(maxM, B), dim3(256), 0, s, oc, st, pts, jpts, jaux);
 }
@@ -1090,17 +1344,18 @@ void launch_render_write(const ObjConst* oc, const ObjState* st, const int* rayc
 void launch_sum_m(const ObjConst* oc, ObjState* st, const int* mcnt, int B, hipStream_t s) {
     hipLaunchKernelGGL(k_sum_m, dim3(B), dim3(256), 0, s, oc, st, mcnt);
 }
-void launch_gram(const ObjConst* oc, const ObjState* st, const float4* jpts, const float2* jaux, const float* jgrad, const unsigned char* alive,
-                 float* partials, int n_slices, float b_sdf, float b_render, int robust, int n_terms, int B, hipStream_t s) {
-    hipLaunchKernelGGL(k_gram, dim3(n_slices, B, n_terms), dim3(256), 0, s, oc, st, jpts, jaux, jgrad, alive, partials, n_slices, b_sdf, b_render, robust);
+void launch_gram(const ObjConst* oc, const ObjState* st, const float4* jpts, const float2* jaux, const float* jgrad, const int* jrow,
+                 const unsigned char* alive, float* partials, int n_slices, float b_sdf, float b_render, int robust, int n_terms, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_gram, dim3(n_slices, B, n_terms), dim3(256), 0, s, oc, st, jpts, jaux, jgrad, jrow, alive, partials, n_slices, b_sdf, b_render, robust);
 }
-void launch_jrows(const ObjConst* oc, const ObjState* st, const float4* jpts, const float2* jaux, const float* jgrad, int term, float* rows, int cap, hipStream_t s) {
-    hipLaunchKernelGGL(k_jrows, dim3((cap + 255) / 256), dim3(256), 0, s, oc, st, jpts, jaux, jgrad, term, rows);
+void launch_jrows(const ObjConst* oc, const ObjState* st, const float4* jpts, const float2* jaux, const float* jgrad, const int* jrow, int term, float* rows,
+                  int cap, hipStream_t s) {
+    hipLaunchKernelGGL(k_jrows, dim3((cap + 255) / 256), dim3(256), 0, s, oc, st, jpts, jaux, jgrad, jrow, term, rows);
 }
 void launch_solve(const ObjConst* oc, ObjState* st, const float* partials, double* gsum, int n_slices, const GnParamsDev& prm, int iter,
-                  float* trace, int B, hipStream_t s) {
+                  float* trace, const float* codew, const float* b0, const float* blat, float* cbias, int B, hipStream_t s) {
     hipLaunchKernelGGL(k_gram_reduce, dim3((72 * 72 + 255) / 256, B, prm.pose_only ? 1 : 2), dim3(256), 0, s, st, partials, n_slices, gsum);
-    hipLaunchKernelGGL(k_solve, dim3(B), dim3(SOLVE_THREADS), 0, s, oc, st, gsum, prm, iter, trace, B);
+    hipLaunchKernelGGL(k_solve, dim3(B), dim3(SOLVE_THREADS), 0, s, oc, st, gsum, prm, iter, codew, b0, blat, cbias, trace, B);
 }
 void launch_inlier_filter(const ObjConst* oc, ObjState* st, const float* jgrad, unsigned char* alive, int maxM, int B, hipStream_t s) {
     hipLaunchKernelGGL(k_inlier_filter, GRID2(maxM, B), dim3(256), 0, s, oc, st, jgrad, alive);

@@ -373,6 +373,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
             const float s2 = __shfl(skipx[2], pl + 48);
             const float sk = (g == 0) ? s0 : (g == 1) ? s1 : s2;
             if (valid) orow[64 + g] = (g < 3) ? (gfirst + sk) : y;
+            if (MODE == 2 && a.sdf_scatter && valid && g == 3 && tile >= *a.scatter_tile_begin) a.sdf_scatter[__float_as_int(pt.w)] = y;
         }
         // stores and LDS-DMA share vmcnt and may retire out of order: drain before counting again
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

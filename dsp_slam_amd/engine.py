@@ -83,6 +83,14 @@ class Batch(object):
     def set_prepass_audit(self, on=True):
         L.check(L.load().dsp_batch_set_prepass_audit(self._h, int(bool(on))), self.engine._h, "dsp_batch_set_prepass_audit")
 
+    def set_speculative_band(self, mode):
+        """-1 = automatic, 0 = band samples get a forward launch of their own, 1 = they go straight into the jacobian launch (latency path)."""
+        L.check(L.load().dsp_batch_set_speculative_band(self._h, int(mode)), self.engine._h, "dsp_batch_set_speculative_band")
+
+    def set_fused_bookkeeping(self, mode):
+        """-1 = automatic, 0 = per-ray bookkeeping as separate launches (throughput form), 1 = fused per object (latency form)."""
+        L.check(L.load().dsp_batch_set_fused_bookkeeping(self._h, int(mode)), self.engine._h, "dsp_batch_set_fused_bookkeeping")
+
     def set_split_rows(self, mode):
         """-1 = automatic, 0 = 64-point throughput tiles, 1 = 16-point latency tiles for the jacobian launch (when mask reuse is off)."""
         L.check(L.load().dsp_batch_set_split_rows(self._h, int(mode)), self.engine._h, "dsp_batch_set_split_rows")

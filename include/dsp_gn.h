@@ -207,6 +207,15 @@ int dsp_batch_set_mask_reuse(dsp_batch* b, int mode);
  * results.  -1 = automatic (on while the 16-point tiles fit a round or two over the CUs and mask reuse is off), 0 = off, 1 = on
  * (ignored while mask reuse is on). */
 int dsp_batch_set_split_rows(dsp_batch* b, int mode);
+/* Per-ray bookkeeping (sampling + compaction, band selection, occupancy scan + row compaction) either as one thread block per 256 rays
+ * with separate scan launches (throughput form) or fused per object (latency form: 3 launches instead of 11 per iteration).  -1 = automatic
+ * (fused for batches of <= 16 objects), 0 = off, 1 = on.  Results are identical for every setting. */
+int dsp_batch_set_fused_bookkeeping(dsp_batch* b, int mode);
+/* Latency path with the prepass on: the samples the prepass could not classify go straight into the jacobian launch (forward + backward,
+ * their sdf scattered back for the occupancy scan) instead of a forward launch of their own -- one decoder launch less per iteration.
+ * -1 = automatic (fused bookkeeping on, mask reuse off, surface points + band samples fit one round of 16-point tiles), 0 = off,
+ * 1 = on where applicable.  Results are identical for every setting. */
+int dsp_batch_set_speculative_band(dsp_batch* b, int mode);
 /* Record per-iteration traces during the following runs (testing; costs ~21 KB per object-iteration). */
 int dsp_batch_enable_trace(dsp_batch* b, int on);
 /* Per-iteration trace of the last run (testing): for iteration e < num_iterations and object i,

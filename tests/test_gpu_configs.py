@@ -301,3 +301,70 @@ def test_split_kernel_is_exact(eng, oracle_decoder):
     gp = golden("golden_pose_only.npz")
     t = eng.estimate_pose_batch(E.gn_params(), [gp["t_co_se3"]], [float(gp["scale"])], [gp["pts"]], [gp["code"]])
     assert np.abs(t[0] - gp["out"]).max() / np.abs(gp["out"]).max() < 1e-4
+
+
+def test_fused_bookkeeping_is_exact(eng):
+    """The per-object fused bookkeeping kernels (latency form) and the per-ray launches (throughput form) call the same device
+    functions: every bit of every iteration must agree, with and without the prepass, including an object that fails."""
+    prm = E.gn_params(num_iterations=4)
+    objs = synth.make_batch(5, first_seed=980, n_surface=300, n_background=90)
+    bad = synth.make_object(985, 60, 20)
+    bad["t_cam_obj_init"] = bad["t_cam_obj_init"].copy()
+    bad["t_cam_obj_init"][:3, 3] += 500.0
+    objs.insert(2, bad)
+    args = ([o["t_cam_obj_init"] for o in objs], [o["pts"] for o in objs], [o["rays"] for o in objs], [o["depth"] for o in objs])
+    for prepass in (0, 1):
+        out = {}
+        for fused in (0, 1):
+            b = eng.batch(prm, *args, trace=True)
+            b.set_prepass(prepass)
+            b.set_fused_bookkeeping(fused)
+            b.run()
+            out[fused] = (b.results(), [b.trace(e) for e in range(4)], b.stats())
+            b.close()
+        assert list(out[0][0][3]) == [0, 0, 1, 0, 0, 0]
+        for a, c in zip(out[0][0], out[1][0]):
+            assert np.array_equal(a, c)
+        good = np.array([0, 1, 3, 4, 5])        # the failed object's trace rows are never written
+        for ta, tc in zip(out[0][1], out[1][1]):
+            for k in ("H", "b", "dx", "V", "m", "K", "set_sums"):
+                assert np.array_equal(ta[k][good], tc[k][good]), (prepass, k)
+        assert out[0][2]["n_fwd_points"] == out[1][2]["n_fwd_points"] and out[0][2]["n_jac_points"] == out[1][2]["n_jac_points"]
+
+
+def test_speculative_band_rows_are_exact(eng, oracle_decoder):
+    """Latency path: the samples the prepass could not classify go straight into the jacobian launch (forward + backward, sdf
+    scattered back) and the Gram kernel picks the kept rows' gradients up where that launch left them -- every bit of every
+    iteration equals the path with a separate forward launch, the stand-alone render term included."""
+    prm = E.gn_params(num_iterations=5)
+    objs = synth.make_batch(3, first_seed=990, n_surface=250, n_background=200)
+    args = ([o["t_cam_obj_init"] for o in objs], [o["pts"] for o in objs], [o["rays"] for o in objs], [o["depth"] for o in objs])
+    out = {}
+    for spec in (0, 1):
+        b = eng.batch(prm, *args, trace=True)
+        b.set_prepass(1)
+        b.set_speculative_band(spec)
+        b.set_prepass_audit(True)
+        b.run()
+        out[spec] = (b.results(), [b.trace(e) for e in range(5)], b.stats())
+        b.close()
+    assert (out[0][0][3] == 0).all()
+    for a, c in zip(out[0][0], out[1][0]):
+        assert np.array_equal(a, c)
+    for ta, tc in zip(out[0][1], out[1][1]):
+        for k in ("H", "b", "dx", "V", "m", "K", "set_sums"):
+            assert np.array_equal(ta[k], tc[k]), k
+    assert out[0][2]["n_fwd_points"] > 0 and out[1][2]["n_fwd_points"] == 0          # no forward launch of their own
+    assert out[1][2]["n_mlp_fwd_launches"] == 0 and out[1][2]["n_mlp_jac_launches"] == 5
+    assert out[1][2]["n_jac_points"] == out[0][2]["n_jac_points"] - sum(int(t["K"].sum()) for t in out[0][1]) + out[0][2]["n_fwd_points"]
+    assert out[1][2]["prepass_misclassified"] == 0
+    # automatic mode picks it for a detection of this size
+    b = eng.batch(prm, *[a[:1] for a in args])
+    b.run()
+    assert b.stats()["n_mlp_fwd_launches"] == 0
+    b.close()
+    # stand-alone render term (one-object batch inside the library takes the same path) against the oracle's rows
+    g = golden("golden_terms.npz")
+    res, st = eng.compute_render_loss(g["rays"], g["depth_obs"], g["t_obj_cam"], g["sampled"], g["code"], th=0.01)
+    assert res[0].shape == g["ren_j7"].shape
+    assert np.abs(res[2] - g["ren_r"]).max() < 2e-5

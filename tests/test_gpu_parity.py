@@ -180,8 +180,12 @@ def compare_linearisation(tr, i, its, k4):
         j_rot = np.sqrt(np.abs(np.diag(it["H"])[3:6]) / max(k4, 1.0))
         tol_rot = k4 * (j_rot + 1e-3) * 2.4e-7 + 1e-4 * bs + 4 * amp_b
         assert np.all(np.abs(tr["b"][i][3:6] - it["b"][3:6]) <= tol_rot)
-        if np.all(np.abs(tr["b"][i][3:6] - it["b"][3:6]) <= 1e-4 * bs):
-            assert np.abs(tr["dx"][i] - it["dx"]).max() < 2e-4 * np.abs(it["dx"]).max() + 4 * np.abs(itj["dx"] - it["dx"]).max()
+        # dx = H^-1 b: whatever difference is accepted on b (above) maps to |H^-1| tol_b on dx -- near convergence b, hence dx, is
+        # a difference of large terms and a bound relative to |dx| alone would be ill-posed
+        tol_b = np.full(it["b"].shape[0], 1e-4 * bs + 4 * amp_b)
+        tol_b[3:6] = np.maximum(tol_b[3:6], tol_rot)
+        tol_dx = np.abs(np.linalg.inv(it["H"].astype(np.float64))) @ tol_b
+        assert np.all(np.abs(tr["dx"][i] - it["dx"]) <= 2e-4 * np.abs(it["dx"]).max() + 4 * np.abs(itj["dx"] - it["dx"]).max() + tol_dx)
         LAST_LINEARISATION.update(same_sets=True, flips=0, rel_H=float(np.abs(tr["H"][i] - it["H"]).max() / hs),
                                   rel_b=float(np.abs(tr["b"][i][mask] - it["b"][mask]).max() / bs), oracle_jitter_rel_H=float(amp_h / hs),
                                   V=int(it["V"]), K=int(it["K"]))
@@ -250,12 +254,14 @@ def test_reconstruct_redwood_each_iteration(eng, oracle_decoder):
 def test_reconstruct_end_to_end(eng, name):
     """All iterations chained, against the reference's final pose / code (north_star: 1e-4 relative).
 
-    Tolerance per quantity: 1e-4 relative, or 1x the REFERENCE'S OWN movement when its input points move by one float32 ulp
-    (golden ulp_*), whichever is larger: the 10-iteration map is discontinuous in its ragged sets, so one ulp of input is
-    amplified beyond 1e-4 inside the reference itself (cfg2: 1e-3 relative on the pose) -- DESIGN.md "Parity".  Rotation
-    (R / scale, entries of magnitude <= 1: absolute), scale (relative), translation (relative to |t|) and code (absolute,
-    |code| ~ 0.03) are checked separately so that the 18 m translation does not set the scale for the rotation entries.
-    The measured differences go to the parity report (profiles/parity_rNN.md)."""
+    Tolerance per quantity: 1e-4, or 1x the REFERENCE'S OWN spread when every element of its inputs moves to an adjacent
+    float32 (golden ulps_*: 8 seeded draws + the original one-direction draw; tools/make_golden_sensitivity.py), whichever is
+    larger.  The 10-iteration map is discontinuous in its ragged sets, so round-off of that size -- which any re-ordering of
+    one float32 sum produces -- is amplified far beyond 1e-4 inside the reference itself (cfg2: 2e-2 on the translation;
+    `small`: one draw in eight flips a set and moves the pose by 3e-2) -- DESIGN.md "Parity".  Rotation (R / scale, entries
+    of magnitude <= 1: absolute), scale (relative), translation (relative to |t|) and code (absolute) are checked separately so
+    that the 18 m translation does not set the scale for the rotation entries.  The measured differences go to the parity
+    report (profiles/parity_rNN.md)."""
     g = golden(name)
     cfg = json.loads(str(g["cfg_json"]))
     prm, oprm = prm_from(cfg)
@@ -268,21 +274,24 @@ def test_reconstruct_end_to_end(eng, name):
         sc = np.cbrt(np.linalg.det(t44[:3, :3]))
         return t44[:3, :3] / sc, sc, t44[:3, 3]
 
-    r_d, s_d, p_d = split(t[0])
+    def diffs(t44, cd):
+        r_a, s_a, p_a = split(t44)
+        return dict(rot=float(np.abs(r_a - r_g).max()), scale=float(abs(s_a - s_g) / s_g),
+                    trans=float(np.linalg.norm(p_a - p_g) / np.linalg.norm(p_g)), code=float(np.abs(cd - g["code"]).max()),
+                    t_abs=float(np.abs(np.asarray(t44, np.float64) - g["t_cam_obj"]).max()))
+
     r_g, s_g, p_g = split(g["t_cam_obj"])
-    r_u, s_u, p_u = split(g["ulp_t_cam_obj"])
-    m = dict(
-        rot=float(np.abs(r_d - r_g).max()), rot_sens=float(np.abs(r_u - r_g).max()),
-        scale=float(abs(s_d - s_g) / s_g), scale_sens=float(abs(s_u - s_g) / s_g),
-        trans=float(np.linalg.norm(p_d - p_g) / np.linalg.norm(p_g)), trans_sens=float(np.linalg.norm(p_u - p_g) / np.linalg.norm(p_g)),
-        code=float(np.abs(code[0] - g["code"]).max()), code_sens=float(np.abs(g["ulp_code"] - g["code"]).max()),
-        loss=float(abs(loss[0] - float(g["loss"])) / max(abs(float(g["loss"])), 1e-12)),
-        t_abs=float(np.abs(t[0] - g["t_cam_obj"]).max()), t_abs_sens=float(np.abs(g["ulp_t_cam_obj"] - g["t_cam_obj"]).max()))
-    parity_log(kind="end_to_end", case=name, **m)
-    print("%s: rot %.2e (ref 1-ulp sensitivity %.2e) scale %.2e (%.2e) trans %.2e (%.2e) code %.2e (%.2e)" % (
-        name, m["rot"], m["rot_sens"], m["scale"], m["scale_sens"], m["trans"], m["trans_sens"], m["code"], m["code_sens"]))
+    m = diffs(t[0], code[0])
+    draws = [diffs(g["ulp_t_cam_obj"], g["ulp_code"])] + [diffs(a, c) for a, c in zip(g["ulps_t_cam_obj"], g["ulps_code"])]
+    sens = {k: max(d[k] for d in draws) for k in m}
+    rec = {k: m[k] for k in m}
+    rec.update({k + "_sens": sens[k] for k in sens})
+    rec["loss"] = float(abs(loss[0] - float(g["loss"])) / max(abs(float(g["loss"])), 1e-12))
+    parity_log(kind="end_to_end", case=name, n_draws=len(draws), **rec)
+    print("%s: rot %.2e (reference spread under 1-ulp inputs %.2e) scale %.2e (%.2e) trans %.2e (%.2e) code %.2e (%.2e)" % (
+        name, m["rot"], sens["rot"], m["scale"], sens["scale"], m["trans"], sens["trans"], m["code"], sens["code"]))
     for q in ("rot", "scale", "trans", "code"):
-        assert m[q] <= max(1e-4, 1.0 * m[q + "_sens"]), (q, m[q], m[q + "_sens"])
+        assert m[q] <= max(1e-4, sens[q]), (q, m[q], sens[q])
 
 
 def test_failure_path_is_good_false(eng_random):

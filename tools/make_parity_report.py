@@ -20,8 +20,8 @@ def main():
     e2e = [r for (k, _), r in last.items() if k == "end_to_end"]
     if e2e:
         print("## Chained GN run vs the reference's final result (golden files recorded from the unmodified reference)\n")
-        print("Bound per quantity: max(1e-4, 1 x the reference's own movement under a ONE-ulp change of its input points).\n")
-        print("| golden | rot abs (ref 1-ulp sens.) | scale rel (sens.) | trans rel (sens.) | code abs (sens.) | loss rel | max abs dT (sens.) |")
+        print("Bound per quantity: max(1e-4, the reference's own spread when every input element moves to an adjacent float32: 9 draws, golden ulp*_ fields).\n")
+        print("| golden | rot abs (reference spread) | scale rel (spread) | trans rel (spread) | code abs (spread) | loss rel | max abs dT (spread) |")
         print("|---|---|---|---|---|---|---|")
         for r in sorted(e2e, key=lambda r: r["case"]):
             print("| %s | %.2e (%.2e) | %.2e (%.2e) | %.2e (%.2e) | %.2e (%.2e) | %.2e | %.2e (%.2e) |" % (
