@@ -932,13 +932,12 @@ void iteration_front(dsp_batch* b, size_t& cursor, bool do_render, bool code_bia
                 launch_decoder(b, 0, cursor);
             }
         }
+        launch_render_scan(b->oc.p, b->st.p, b->raymask.p, b->rayoff.p, b->ssdf.p, b->depth.p, b->sdeds.p, b->ray_res.p,
+                           b->kcnt.p, b->mcnt.p, b->D, b->prm.cut_off, b->maxR, B, s);
         if (fused) {
-            launch_render_fused(b->oc.p, b->st.p, b->raymask.p, b->raycnt.p, b->rayoff.p, b->ssdf.p, b->depth.p, b->spts.p, b->sdeds.p, b->ray_res.p,
-                                b->kcnt.p, b->koff.p, b->mcnt.p, b->jpts.p, b->jaux.p, spec ? b->srow.p : nullptr, spec ? b->jrow.p : nullptr, b->D,
-                                b->prm.cut_off, B, s);
+            launch_render_tail_fused(b->oc.p, b->st.p, b->raycnt.p, b->rayoff.p, b->spts.p, b->sdeds.p, b->ray_res.p, b->kcnt.p, b->koff.p, b->mcnt.p,
+                                     b->jpts.p, b->jaux.p, spec ? b->srow.p : nullptr, spec ? b->jrow.p : nullptr, B, s);
         } else {
-            launch_render_scan(b->oc.p, b->st.p, b->raymask.p, b->rayoff.p, b->ssdf.p, b->depth.p, b->sdeds.p, b->ray_res.p,
-                               b->kcnt.p, b->mcnt.p, b->D, b->prm.cut_off, b->maxR, B, s);
             launch_scan_rays(b->oc.p, b->st.p, b->kcnt.p, b->koff.p, 1, B, s);
             launch_sum_m(b->oc.p, b->st.p, b->mcnt.p, B, s);
             launch_render_write(b->oc.p, b->st.p, b->raycnt.p, b->rayoff.p, b->koff.p, b->spts.p, b->sdeds.p, b->ray_res.p,

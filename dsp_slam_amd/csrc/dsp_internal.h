@@ -171,14 +171,14 @@ void launch_build_tiles(const ObjConst* oc, const ObjState* st, int B, int mode,
 void launch_band_select(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff, const float* ssdf, float thd,
                         int* pcnt, int* poff, int* plist, int maxR, int B, hipStream_t s);
 // fused per-object forms (latency path): front = sample_count + scan + sample_write + surface; band = count + scan + write;
-// render = render_scan + scan + sum_m + render_write
+// render tail = scan + sum_m + render_write (behind k_render_scan, one wave per ray over the whole chip)
 void launch_front_fused(const ObjConst* oc, ObjState* st, const float* rays, const float* pts, unsigned long long* raymask, int* raycnt, int* rayoff,
                         float4* spts, float* ssdf, unsigned char* alive, float4* jpts, float2* jaux, int D, int B, hipStream_t s);
 void launch_band_fused(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff, const float* ssdf, float thd, int* pcnt,
                        int* poff, int* plist, const float4* spts, float4* jpts, int* srow, int B, hipStream_t s);   // jpts / srow: speculative band rows (or null)
-void launch_render_fused(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* raycnt, const int* rayoff, const float* ssdf,
-                         const float* depth, const float4* spts, float* sdeds, float* ray_res, int* kcnt, int* koff, int* mcnt, float4* jpts,
-                         float2* jaux, const int* srow, int* jrow, int D, float th, int B, hipStream_t s);
+void launch_render_tail_fused(const ObjConst* oc, ObjState* st, const int* raycnt, const int* rayoff, const float4* spts, const float* sdeds,
+                              const float* ray_res, const int* kcnt, int* koff, const int* mcnt, float4* jpts, float2* jaux, const int* srow, int* jrow,
+                              int B, hipStream_t s);
 void launch_prepass_audit(const ObjConst* oc, const ObjState* st, const float* ssdf, const float* saudit, float th, float thd, unsigned* out,
                           int B, hipStream_t s);
 void launch_render_scan(const ObjConst* oc, ObjState* st, const unsigned long long* m, const int* off, const float* ssdf, const float* depth,

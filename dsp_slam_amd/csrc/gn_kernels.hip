@@ -482,92 +482,79 @@ __global__ __launch_bounds__(256) void k_build_tiles(const ObjConst* oc, const O
 // One thread per ray, the 50-sample row kept in registers.  Pass 1 (count): occupancy o_j, T_l =
 // prod_{i<=l}(1-o_i), rendered depth d_u, suffix sums for de_do, keeps samples with |sdf| < th and
 // de_do > 1e-2; stores de_ds per compact sample (0 = dropped), d_u per ray and the kept count.
-__device__ __forceinline__ void render_scan_ray(const ObjConst& c, ObjState* st, int b, const unsigned long long* raymask, const int* rayoff,
-                                                const float* ssdf, const float* depth_fg, float* sdeds, float* ray_res, int* kcnt, int* mcnt,
-                                                int n_depth, float th, int r) {
-    const ObjState& s = st[b];
-    const int gr = c.ray_off + r;
-    if (s.status != DSP_STATUS_GOOD) { kcnt[gr] = 0; mcnt[gr] = 0; return; }
-    const unsigned long long mask = raymask[gr];
-    const int base = c.samp_off + rayoff[gr];
-    float o[64], T[64];
-    unsigned long long wg = 0ull;   // with_grad: -th < sdf < th  (loss.py:88)
-    // the ray's samples first, as 64 INDEPENDENT loads (sample of depth index j sits at compact position popc(mask below j)): loaded
-    // inside the sequential transmittance chain below they cost one memory latency each, 50 in a row
-#pragma unroll
-    for (int j = 0; j < 64; ++j) {
-        const bool in = j < n_depth && ((mask >> j) & 1ull);
-        o[j] = ssdf[in ? base + __popcll(mask & ((1ull << j) - 1ull)) : c.samp_off];
-    }
-    {
-        float acc = 1.f;
-#pragma unroll
-        for (int j = 0; j < 64; ++j) {
-            float oj = 0.f;
-            if (j < n_depth && ((mask >> j) & 1ull)) {
-                const float sd = o[j];
-                const float cl = fminf(fmaxf(sd, -th), th);
-                oj = __fsub_rn(0.5f, __fdiv_rn(cl, __fmul_rn(2.f, th)));   // sdf_to_occupancy (loss_utils.py:40-48)
-                if (sd > -th && sd < th) wg |= 1ull << j;
-            }
-            acc = __fmul_rn(acc, __fsub_rn(1.f, oj));
-            o[j] = oj;
-            T[j] = acc;
-        }
-    }
-    const float d_bg = __fmul_rn(1.1f, s.depths[n_depth - 1]);
-    // d_u = sum_l d_l * o_l * T_{l-1} + d_bg * T_{D-1}   (loss.py:100-114)
-    float du = 0.f;
-#pragma unroll
-    for (int j = 0; j < 64; ++j) {
-        if (j < n_depth) {
-            const float tp = __fmul_rn(o[j], (j == 0) ? 1.f : T[j - 1]);
-            du = __fadd_rn(du, __fmul_rn(s.depths[j], tp));
-        }
-    }
-    du = __fadd_rn(du, __fmul_rn(d_bg, T[63]));   // T[63] == T[n_depth-1] exactly: o_j = 0 behind the last sample (static index keeps T in registers)
-    const float obs = (r < c.n_fg) ? depth_fg[c.depth_off + r] : d_bg;   // optimizer.py:126
-    float res = __fsub_rn(obs, du);
-    res = fminf(fmaxf(res, -0.30f), 0.30f);                               // loss.py:139-140
-    ray_res[gr] = res;
-    // de_do_k = sum_{l>=k} T_l / (1 - o_k); keep > 1e-2; de_ds = de_do * delta_d * (-1/(2 th))  (loss.py:118-130)
-    const float delta_d = __fdiv_rn(__fsub_rn(s.depths[n_depth - 1], s.depths[0]), (float)(n_depth - 1));
-    const float do_ds = __fdiv_rn(-1.f, __fmul_rn(2.f, th));
-    {   // suffix sums of T, in place (T itself is not needed any more)
-        float sacc = 0.f;
-#pragma unroll
-        for (int j = 63; j >= 0; --j) {
-            if (j < n_depth) sacc = __fadd_rn(sacc, T[j]);
-            T[j] = sacc;
-        }
-    }
-    int kept = 0, k = 0;
-    unsigned khash = 0;
-#pragma unroll
-    for (int j = 0; j < 64; ++j) {
-        if (j < n_depth && ((mask >> j) & 1ull)) {
-            float deds = 0.f;
-            if ((wg >> j) & 1ull) {
-                const float dedo = __fdiv_rn(T[j], __fsub_rn(1.f, o[j]));
-                if (dedo > 1e-2f) { deds = __fmul_rn(__fmul_rn(dedo, delta_d), do_ds); ++kept; khash += id_hash(((unsigned)r << 6) | (unsigned)j); }
-            }
-            sdeds[base + k] = deds;   // never exactly 0 for a kept sample (dedo > 0.01, delta_d > 0)
-            ++k;
-        }
-    }
-    kcnt[gr] = kept;
-    mcnt[gr] = __popcll(wg);
-    if (khash) atomicAdd(&st[b].ksum, khash);
-}
+// One WAVE per ray, lane = depth index: everything per-sample (occupancy, the two divisions, the keep tests, the compaction) runs in
+// parallel across the lanes; only the three chains whose rounding order the reference fixes -- cumprod of (1 - o), the rendered-depth
+// sum and the suffix sums of T, all front to back resp. back to front in depth order -- are walked with v_readlane, one lane at a
+// time.  ~600 wave instructions per ray instead of ~7000 thread instructions, and every ray on its own SIMD.
+__device__ __forceinline__ float lane_value(float x, int j) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), j)); }
 
 __global__ __launch_bounds__(256) void k_render_scan(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff,
                               const float* ssdf, const float* depth_fg, float* sdeds, float* ray_res, int* kcnt, int* mcnt,
                               int n_depth, float th) {
     const int b = blockIdx.y;
     const ObjConst c = oc[b];
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);     // wave-uniform
     if (r >= c.n_rays) return;
-    render_scan_ray(c, st, b, raymask, rayoff, ssdf, depth_fg, sdeds, ray_res, kcnt, mcnt, n_depth, th, r);
+    const ObjState& s = st[b];
+    const int gr = c.ray_off + r;
+    if (s.status != DSP_STATUS_GOOD) { if (lane == 0) { kcnt[gr] = 0; mcnt[gr] = 0; } return; }
+    const unsigned long long mask = raymask[gr];
+    const int base = c.samp_off + rayoff[gr];
+    const bool in = lane < n_depth && ((mask >> lane) & 1ull);
+    const int k = __popcll(mask & ((1ull << lane) - 1ull));
+    const float sd = in ? ssdf[base + k] : 0.f;
+    const float dj = s.depths[lane < n_depth ? lane : 0];
+    float oj = 0.f;
+    bool wg = false;                     // with_grad: -th < sdf < th  (loss.py:88)
+    if (in) {
+        const float cl = fminf(fmaxf(sd, -th), th);
+        oj = __fsub_rn(0.5f, __fdiv_rn(cl, __fmul_rn(2.f, th)));   // sdf_to_occupancy (loss_utils.py:40-48)
+        wg = sd > -th && sd < th;
+    }
+    const float f = __fsub_rn(1.f, oj);  // 1 exactly where there is no sample
+    // T_l = prod_{i<=l} (1 - o_i), sequential in l (torch.cumprod)
+    float Tj = 0.f, acc = 1.f;
+    for (int j = 0; j < n_depth; ++j) {
+        acc = __fmul_rn(acc, lane_value(f, j));
+        if (lane == j) Tj = acc;
+    }
+    const float d_bg = __fmul_rn(1.1f, s.depths[n_depth - 1]);
+    // d_u = sum_l d_l * o_l * T_{l-1} + d_bg * T_{D-1}, summed front to back   (loss.py:100-114)
+    const float tprev = __shfl_up(Tj, 1);
+    const float term = __fmul_rn(dj, __fmul_rn(oj, lane == 0 ? 1.f : tprev));
+    float du = 0.f;
+    for (int j = 0; j < n_depth; ++j) du = __fadd_rn(du, lane_value(term, j));
+    du = __fadd_rn(du, __fmul_rn(d_bg, lane_value(Tj, n_depth - 1)));
+    const float obs = (r < c.n_fg) ? depth_fg[c.depth_off + r] : d_bg;   // optimizer.py:126
+    float res = __fsub_rn(obs, du);
+    res = fminf(fmaxf(res, -0.30f), 0.30f);                               // loss.py:139-140
+    // de_do_k = sum_{l>=k} T_l / (1 - o_k), the suffix sums accumulated back to front; keep > 1e-2;
+    // de_ds = de_do * delta_d * (-1/(2 th))  (loss.py:118-130)
+    float Sj = 0.f, sacc = 0.f;
+    for (int j = n_depth - 1; j >= 0; --j) {
+        sacc = __fadd_rn(sacc, lane_value(Tj, j));
+        if (lane == j) Sj = sacc;
+    }
+    const float delta_d = __fdiv_rn(__fsub_rn(s.depths[n_depth - 1], s.depths[0]), (float)(n_depth - 1));
+    const float do_ds = __fdiv_rn(-1.f, __fmul_rn(2.f, th));
+    float deds = 0.f;
+    bool keep = false;
+    if (wg) {
+        const float dedo = __fdiv_rn(Sj, __fsub_rn(1.f, oj));
+        if (dedo > 1e-2f) { deds = __fmul_rn(__fmul_rn(dedo, delta_d), do_ds); keep = true; }
+    }
+    if (in) sdeds[base + k] = deds;      // never exactly 0 for a kept sample (dedo > 0.01, delta_d > 0)
+    const unsigned long long keptm = __ballot(keep), wgm = __ballot(wg);
+    unsigned khash = keep ? id_hash(((unsigned)r << 6) | (unsigned)lane) : 0u;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) khash += __shfl_xor(khash, d);
+    if (lane == 0) {
+        ray_res[gr] = res;
+        kcnt[gr] = __popcll(keptm);
+        mcnt[gr] = __popcll(wgm);
+        if (khash) atomicAdd(&st[b].ksum, khash);
+    }
 }
 
 __device__ __forceinline__ void render_write_ray(const ObjConst& c, const ObjState& s, const int* raycnt, const int* rayoff, const int* koff,
@@ -735,33 +722,30 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_band_fused(const ObjConst* oc
 }
 
 // k_render_scan + k_scan_rays(1) + k_sum_m + k_render_write
-constexpr int RENDER_FUSED_THREADS = 512;   // render_scan_ray keeps a ray's 64-entry occupancy and transmittance rows in registers
-__global__ __launch_bounds__(RENDER_FUSED_THREADS) void k_render_fused(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* raycnt,
-                                                                const int* rayoff, const float* ssdf, const float* depth_fg, const float4* spts,
-                                                                float* sdeds, float* ray_res, int* kcnt, int* koff, int* mcnt, float4* jpts,
-                                                                float2* jaux, const int* srow, int* jrow, int n_depth, float th) {
-    __shared__ int part[RENDER_FUSED_THREADS];
+// k_scan_rays(1) + k_sum_m + k_render_write, behind k_render_scan (which spreads the rays over the whole chip, one wave each)
+__global__ __launch_bounds__(FUSED_THREADS) void k_render_tail_fused(const ObjConst* oc, ObjState* st, const int* raycnt, const int* rayoff,
+                                                                     const float4* spts, const float* sdeds, const float* ray_res,
+                                                                     const int* kcnt, int* koff, const int* mcnt, float4* jpts, float2* jaux,
+                                                                     const int* srow, int* jrow) {
+    __shared__ int part[FUSED_THREADS];
     const int b = blockIdx.x;
     const ObjConst c = oc[b];
-    for (int r = threadIdx.x; r < c.n_rays; r += RENDER_FUSED_THREADS) {
-        if (st[b].status != DSP_STATUS_GOOD) { kcnt[c.ray_off + r] = 0; mcnt[c.ray_off + r] = 0; }
-        else render_scan_ray(c, st, b, raymask, rayoff, ssdf, depth_fg, sdeds, ray_res, kcnt, mcnt, n_depth, th, r);
-    }
-    __syncthreads();
-    scan_rays_block<RENDER_FUSED_THREADS>(c, st, b, kcnt, koff, 1, part);
+    scan_rays_block<FUSED_THREADS>(c, st, b, kcnt, koff, 1, part);
     __syncthreads();
     {   // k_sum_m
         int sum = 0;
-        for (int r = threadIdx.x; r < c.n_rays; r += RENDER_FUSED_THREADS) sum += mcnt[c.ray_off + r];
-        part[threadIdx.x] = sum;
+        for (int r = threadIdx.x; r < c.n_rays; r += FUSED_THREADS) sum += mcnt[c.ray_off + r];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
         __syncthreads();
-        for (int d = RENDER_FUSED_THREADS / 2; d > 0; d >>= 1) {
-            if (threadIdx.x < d) part[threadIdx.x] += part[threadIdx.x + d];
-            __syncthreads();
+        if (threadIdx.x == 0) {
+            int tot = 0;
+            for (int w = 0; w < FUSED_THREADS / 64; ++w) tot += part[w];
+            st[b].m = tot;
         }
-        if (threadIdx.x == 0) st[b].m = part[0];
     }
-    for (int r = threadIdx.x; r < c.n_rays; r += RENDER_FUSED_THREADS) render_write_ray(c, st[b], raycnt, rayoff, koff, spts, sdeds, ray_res, jpts, jaux, r, srow, jrow);
+    for (int r = threadIdx.x; r < c.n_rays; r += FUSED_THREADS) render_write_ray(c, st[b], raycnt, rayoff, koff, spts, sdeds, ray_res, jpts, jaux, r, srow, jrow);
 }
 
 __global__ __launch_bounds__(256) void k_sum_m(const ObjConst* oc, ObjState* st, const int* mcnt) {
@@ -1320,11 +1304,11 @@ void launch_band_fused(const ObjConst* oc, ObjState* st, const unsigned long lon
                        int* poff, int* plist, const float4* spts, float4* jpts, int* srow, int B, hipStream_t s) {
     hipLaunchKernelGGL(k_band_fused, dim3(B), dim3(FUSED_THREADS), 0, s, oc, st, raymask, rayoff, ssdf, thd, pcnt, poff, plist, spts, jpts, srow);
 }
-void launch_render_fused(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* raycnt, const int* rayoff, const float* ssdf,
-                         const float* depth, const float4* spts, float* sdeds, float* ray_res, int* kcnt, int* koff, int* mcnt, float4* jpts,
-                         float2* jaux, const int* srow, int* jrow, int D, float th, int B, hipStream_t s) {
-    hipLaunchKernelGGL(k_render_fused, dim3(B), dim3(RENDER_FUSED_THREADS), 0, s, oc, st, raymask, raycnt, rayoff, ssdf, depth, spts, sdeds, ray_res, kcnt, koff,
-                       mcnt, jpts, jaux, srow, jrow, D, th);
+void launch_render_tail_fused(const ObjConst* oc, ObjState* st, const int* raycnt, const int* rayoff, const float4* spts, const float* sdeds,
+                              const float* ray_res, const int* kcnt, int* koff, const int* mcnt, float4* jpts, float2* jaux, const int* srow, int* jrow,
+                              int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_render_tail_fused, dim3(B), dim3(FUSED_THREADS), 0, s, oc, st, raycnt, rayoff, spts, sdeds, ray_res, kcnt, koff, mcnt, jpts, jaux,
+                       srow, jrow);
 }
 void launch_surface(const ObjConst* oc, const ObjState* st, const float* pts, float4* jpts, float2* jaux, int maxM, int B, hipStream_t s) {
     hipLaunchKernelGGL(k_surface, GRID2(maxM, B), dim3(256), 0, s, oc, st, pts, jpts, jaux);
@@ -1335,7 +1319,8 @@ void launch_build_tiles(const ObjConst* oc, const ObjState* st, int B, int mode,
 }
 void launch_render_scan(const ObjConst* oc, ObjState* st, const unsigned long long* m, const int* off, const float* ssdf, const float* depth,
                         float* sdeds, float* ray_res, int* kcnt, int* mcnt, int D, float th, int maxR, int B, hipStream_t s) {
-    hipLaunchKernelGGL(k_render_scan, GRID2(maxR, B), dim3(256), 0, s, oc, st, m, off, ssdf, depth, sdeds, ray_res, kcnt, mcnt, D, th);
+    hipLaunchKernelGGL(k_render_scan, dim3((unsigned)std::max(1, (maxR + 3) / 4), (unsigned)B), dim3(256), 0, s, oc, st, m, off, ssdf, depth, sdeds, ray_res,
+                       kcnt, mcnt, D, th);     // one wave per ray
 }
 void launch_render_write(const ObjConst* oc, const ObjState* st, const int* raycnt, const int* rayoff, const int* koff, const float4* spts,
                          const float* sdeds, const float* ray_res, float4* jpts, float2* jaux, int maxR, int B, hipStream_t s) {

@@ -114,13 +114,17 @@ def _check_trace(oracle_decoder, name, tol_final):
     rst = O.reconstruct_object(oracle_decoder, prm, g["in_t_cam_obj_init"], g["in_pts"], g["in_rays"],
                                g["in_depth"], code, trace=tr)
     assert rst["is_good"] == bool(g["is_good"])
-    # End-to-end tolerance: 1e-4 relative, or 10x the REFERENCE'S OWN movement under a one-ulp change of its input
-    # points (golden ulp_*), whichever is larger -- ten chained linearisations with data-dependent set membership
-    # amplify round-off far beyond 1e-4 in the reference itself (see DESIGN.md "Parity").
-    sens_t = np.abs(g["ulp_t_cam_obj"] - g["t_cam_obj"]).max()
-    sens_c = np.abs(g["ulp_code"] - g["code"]).max()
-    assert np.abs(rst["t_cam_obj"] - g["t_cam_obj"]).max() <= max(tol_final * np.abs(g["t_cam_obj"]).max(), 10 * sens_t)
-    assert np.abs(rst["code"] - g["code"]).max() <= max(tol_final, 10 * sens_c)
+    # End-to-end tolerance: 1e-4, or 3x the REFERENCE'S OWN spread under adjacent-float32 input perturbations (golden ulp_* /
+    # ulps_*: 9 draws, tools/make_golden_sensitivity.py), whichever is larger -- ten chained linearisations with
+    # data-dependent set membership amplify round-off far beyond 1e-4 in the reference itself (see DESIGN.md "Parity").
+    draws_t = [g["ulp_t_cam_obj"]] + list(g["ulps_t_cam_obj"])
+    draws_c = [g["ulp_code"]] + list(g["ulps_code"])
+    sens_t = max(np.abs(a - g["t_cam_obj"]).max() for a in draws_t)
+    sens_c = max(np.abs(a - g["code"]).max() for a in draws_c)
+    d_t, d_c = np.abs(rst["t_cam_obj"] - g["t_cam_obj"]).max(), np.abs(rst["code"] - g["code"]).max()
+    print("%s: oracle vs reference |dT| %.2e (reference spread %.2e)  |dcode| %.2e (%.2e)" % (name, d_t, sens_t, d_c, sens_c))
+    assert d_t <= max(tol_final * np.abs(g["t_cam_obj"]).max(), 3 * sens_t)
+    assert d_c <= max(tol_final, 3 * sens_c)
     assert abs(rst["loss"] - float(g["loss"])) <= max(1e-3 * abs(float(g["loss"])), 0.5 * abs(float(g["loss"])) * min(1.0, 50 * max(sens_t, sens_c)))
     assert tr[0]["V"] == g["it_V"][0] and tr[0]["K"] == g["it_K"][0]
 
@@ -141,6 +145,22 @@ def test_reconstruct_freiburg_hyper_parameters(oracle_decoder):
 
 def test_reconstruct_cfg1(oracle_decoder):
     _check_trace(oracle_decoder, "golden_recon_cfg1.npz", 1e-4)
+
+
+def test_reconstruct_cfg2_end_to_end_is_round_off_chaotic_in_the_reference_too(oracle_decoder):
+    """cfg2 (the bench workload's object): the chained 10-iteration result of an independent fp32 CPU restatement sits as far
+    from the reference as the reference sits from itself under adjacent-float32 input changes (|dcode| ~ 5e-3 with |code| <= 0.02)
+    -- the yardstick the GPU end-to-end test uses."""
+    g = golden("golden_recon_cfg2.npz")
+    prm = O.GNParams.from_configs(json.loads(str(g["cfg_json"])))
+    rst = O.reconstruct_object(oracle_decoder, prm, g["in_t_cam_obj_init"], g["in_pts"], g["in_rays"], g["in_depth"])
+    assert rst["is_good"]
+    sens_t = max(np.abs(a - g["t_cam_obj"]).max() for a in [g["ulp_t_cam_obj"]] + list(g["ulps_t_cam_obj"]))
+    sens_c = max(np.abs(a - g["code"]).max() for a in [g["ulp_code"]] + list(g["ulps_code"]))
+    d_t, d_c = np.abs(rst["t_cam_obj"] - g["t_cam_obj"]).max(), np.abs(rst["code"] - g["code"]).max()
+    print("cfg2: oracle vs reference |dT| %.2e (reference spread %.2e)  |dcode| %.2e (%.2e)" % (d_t, sens_t, d_c, sens_c))
+    assert sens_t > 1e-3 and sens_c > 1e-3                 # the reference moves by this much under one-ulp inputs
+    assert d_t <= 3 * sens_t and d_c <= 3 * sens_c
 
 
 def test_failure_path_random_decoder():
