@@ -83,6 +83,8 @@ SYMBOLS = [
     ("dsp_batch_enable_trace", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_trace", C.c_int, [_VP, C.c_int32, c_f32p, c_f32p, c_f32p, c_i64p, c_i64p, c_i64p, c_f32p, c_f32p, C.POINTER(C.c_uint32), c_f32p]),
     ("dsp_batch_destroy", None, [_VP]),
+    ("dsp_pack_results", None, [C.c_int32, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p]),
+    ("dsp_gather_results", C.c_int, [C.POINTER(_VP), C.c_int32, C.POINTER(c_f32p), c_i32p, c_f32p]),
     ("dsp_extract_mesh", C.c_int, [_VP, c_f32p, C.c_int32, C.c_int32, c_i64p, c_i64p]),
     ("dsp_marching_cubes", C.c_int, [_VP, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, c_i64p, c_i64p]),
     ("dsp_mesh_fetch", C.c_int, [_VP, c_f32p, C.c_int64, c_i32p, C.c_int64]),

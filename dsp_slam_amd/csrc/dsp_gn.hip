@@ -3,6 +3,9 @@
 #include "dsp_gn.h"
 #include "dsp_internal.h"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: librccl is dlopen()ed by dsp_gather_results, never linked
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -1495,3 +1498,113 @@ int dsp_estimate_pose_batch(dsp_handle* h, const dsp_gn_params* prm, int32_t n_o
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// multi-GPU gather of results over RCCL (single process, one handle per GPU) -- SURVEY 8(e)
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct Rccl {
+    void* lib = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGather) Gather = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::vector<int> devs;               // communicators are cached for the last device list
+    std::vector<ncclComm_t> comms;
+    std::mutex mu;
+};
+Rccl g_rccl;
+
+void rccl_load() {
+    if (g_rccl.lib) return;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        g_rccl.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (g_rccl.lib) break;
+    }
+    if (!g_rccl.lib) throw std::runtime_error(std::string("cannot load librccl: ") + dlerror());
+#define RCCL_SYM(field, sym)                                                                  \
+    g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(g_rccl.lib, #sym));      \
+    if (!g_rccl.field) throw std::runtime_error("librccl lacks " #sym)
+    RCCL_SYM(CommInitAll, ncclCommInitAll);
+    RCCL_SYM(CommDestroy, ncclCommDestroy);
+    RCCL_SYM(GroupStart, ncclGroupStart);
+    RCCL_SYM(GroupEnd, ncclGroupEnd);
+    RCCL_SYM(Gather, ncclGather);
+    RCCL_SYM(GetErrorString, ncclGetErrorString);
+#undef RCCL_SYM
+}
+
+#define RCCL_TRY(expr)                                                                                           \
+    do {                                                                                                         \
+        ncclResult_t r_ = (expr);                                                                                \
+        if (r_ != ncclSuccess) throw std::runtime_error(std::string(#expr " failed: ") + g_rccl.GetErrorString(r_)); \
+    } while (0)
+
+}  // namespace
+
+extern "C" int dsp_gather_results(dsp_handle* const* handles, int32_t n_handles, const float* const* results, const int32_t* n_objects,
+                                  float* out) {
+    if (!handles || n_handles < 1 || !results || !n_objects || !out) return DSP_E_ARG;
+    for (int i = 0; i < n_handles; ++i)
+        if (!handles[i] || n_objects[i] < 0 || (n_objects[i] > 0 && !results[i])) return DSP_E_ARG;
+    dsp_handle* root = handles[0];
+    return guarded(root, [&] {
+        std::lock_guard<std::mutex> lock(g_rccl.mu);
+        rccl_load();
+        std::vector<int> devs(n_handles);
+        int n_max = 0;
+        for (int i = 0; i < n_handles; ++i) {
+            devs[i] = handles[i]->device;
+            n_max = std::max(n_max, (int)n_objects[i]);
+            for (int j = 0; j < i; ++j)
+                if (devs[j] == devs[i]) throw std::invalid_argument("dsp_gather_results: one handle per GPU (two handles share a device)");
+        }
+        if (devs != g_rccl.devs) {
+            for (ncclComm_t c : g_rccl.comms) (void)g_rccl.CommDestroy(c);
+            g_rccl.comms.assign(n_handles, nullptr);
+            g_rccl.devs.clear();
+            RCCL_TRY(g_rccl.CommInitAll(g_rccl.comms.data(), n_handles, devs.data()));
+            g_rccl.devs = devs;
+        }
+        const size_t block = (size_t)std::max(n_max, 1) * DSP_RESULT_WIDTH;     // uneven shards are padded to the largest
+        std::vector<DevBuf<float>> send(n_handles);
+        DevBuf<float> recv;
+        for (int i = 0; i < n_handles; ++i) {
+            HIP_TRY(hipSetDevice(devs[i]));
+            send[i].alloc(block);
+            HIP_TRY(hipMemsetAsync(send[i].p, 0, block * 4, handles[i]->stream));
+            if (n_objects[i])
+                HIP_TRY(hipMemcpyAsync(send[i].p, results[i], (size_t)n_objects[i] * DSP_RESULT_WIDTH * 4, hipMemcpyHostToDevice, handles[i]->stream));
+            if (i == 0) recv.alloc(block * n_handles);
+        }
+        RCCL_TRY(g_rccl.GroupStart());       // the ONE collective of the path: every GPU's block to the first handle's GPU, over xGMI
+        for (int i = 0; i < n_handles; ++i)
+            RCCL_TRY(g_rccl.Gather(send[i].p, i == 0 ? recv.p : nullptr, block, ncclFloat, 0, g_rccl.comms[i], handles[i]->stream));
+        RCCL_TRY(g_rccl.GroupEnd());
+        for (int i = 0; i < n_handles; ++i) {
+            HIP_TRY(hipSetDevice(devs[i]));
+            HIP_TRY(hipStreamSynchronize(handles[i]->stream));
+        }
+        HIP_TRY(hipSetDevice(devs[0]));
+        std::vector<float> host(block * n_handles);
+        HIP_TRY(hipMemcpy(host.data(), recv.p, host.size() * 4, hipMemcpyDeviceToHost));
+        size_t o = 0;
+        for (int i = 0; i < n_handles; ++i) {
+            memcpy(out + o, host.data() + (size_t)i * block, (size_t)n_objects[i] * DSP_RESULT_WIDTH * 4);
+            o += (size_t)n_objects[i] * DSP_RESULT_WIDTH;
+        }
+    });
+}
+
+extern "C" void dsp_pack_results(int32_t n, const float* t_cam_obj, const float* codes, const float* loss, const int32_t* status, float* packed) {
+    for (int32_t i = 0; i < n; ++i) {
+        float* row = packed + (size_t)i * DSP_RESULT_WIDTH;
+        memcpy(row, t_cam_obj + (size_t)i * 16, 64);
+        memcpy(row + 16, codes + (size_t)i * CODE_LEN, CODE_LEN * 4);
+        row[80] = loss[i];
+        row[81] = (float)status[i];
+    }
+}

@@ -137,6 +137,27 @@ class Batch(object):
             pass
 
 
+def gather_results_c(engines, packed):
+    """dsp_gather_results: one RCCL gather, inside ONE process, of the (n_i, 82) result blocks of several engines (one per GPU)
+    to the first engine's GPU; returns them concatenated in engine order.  (Across processes use dsp_slam_amd.distributed.)"""
+    n = len(engines)
+    blocks = [L.f32(np.asarray(p, np.float32).reshape(-1, 82)) for p in packed]
+    hs = (C.c_void_p * n)(*[e._h for e in engines])
+    ptrs = (L.c_f32p * n)(*[L.ptr(b) for b in blocks])
+    cnt = np.array([b.shape[0] for b in blocks], np.int32)
+    out = np.zeros((int(cnt.sum()), 82), np.float32)
+    L.check(L.load().dsp_gather_results(hs, n, ptrs, L.ptr(cnt, L.c_i32p), L.ptr(out)), engines[0]._h, "dsp_gather_results")
+    return out
+
+
+def pack_results_c(t_cam_obj, codes, loss, status):
+    n = len(loss)
+    out = np.zeros((n, 82), np.float32)
+    L.load().dsp_pack_results(n, L.ptr(L.f32(t_cam_obj)), L.ptr(L.f32(codes)), L.ptr(L.f32(loss)), L.ptr(np.ascontiguousarray(status, np.int32), L.c_i32p),
+                              L.ptr(out))
+    return out
+
+
 _last_engine = None
 
 

@@ -9,9 +9,9 @@
  *
  * Conventions: plain C types; all pointers are HOST pointers unless a name ends in _dev; row-major
  * float32; every function returns 0 on success or a negative DSP_E_* code (dsp_last_error() gives
- * text).  A handle owns one device, one HIP stream and its device memory; calls on one handle must be
- * serialised by the caller (the reference serialises them through the GIL), different handles are
- * independent.  Nothing here depends on Python or PyTorch.
+ * text).  A handle owns one device, one HIP stream and its device memory; calls on one handle (and on
+ * batches created from it) are serialised INSIDE the library (a per-handle mutex), so they may come from
+ * any thread; different handles are independent.  Nothing here depends on Python or PyTorch.
  */
 #ifndef DSP_GN_H
 #define DSP_GN_H
@@ -225,6 +225,17 @@ int dsp_batch_enable_trace(dsp_batch* b, int on);
 int dsp_batch_trace(dsp_batch* b, int32_t iteration, float* H, float* bvec, float* dx, int64_t* V, int64_t* m,
                     int64_t* K, float* t_obj_cam, float* code, uint32_t* set_sums, float* depths /* 64 per object */);
 void dsp_batch_destroy(dsp_batch* b);
+
+/* ---- multi-GPU: objects are independent, so GPUs take disjoint blocks of the object list (one handle per GPU, one host
+ *      thread per handle) and the ONLY exchange is one gather of the per-object results.  The Python mirror does this across processes with
+ *      torch.distributed (dsp_slam_amd/distributed.py); these two calls are the same for a single C / C++ process that owns several GPUs. */
+#define DSP_RESULT_WIDTH 82   /* t_cam_obj 16 | code 64 | loss | status (as float) */
+/* Pack the outputs of dsp_reconstruct_batch / dsp_batch_results into n x DSP_RESULT_WIDTH rows (host only). */
+void dsp_pack_results(int32_t n, const float* t_cam_obj, const float* codes, const float* loss, const int32_t* status, float* packed);
+/* results[i]: n_objects[i] x DSP_RESULT_WIDTH host floats produced on handles[i] (distinct GPUs).  The blocks are uploaded, gathered
+ * device-to-device to handles[0]'s GPU by ONE RCCL ncclGather (xGMI; uneven blocks padded to the largest), and returned in `out`
+ * concatenated in handle order (sum(n_objects) x DSP_RESULT_WIDTH).  librccl is loaded on first use (dlopen), not linked. */
+int dsp_gather_results(dsp_handle* const* handles, int32_t n_handles, const float* const* results, const int32_t* n_objects, float* out);
 
 #ifdef __cplusplus
 }

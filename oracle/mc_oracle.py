@@ -77,15 +77,23 @@ def cube_faces():
     return faces
 
 
-def _loops(cfg, flip):
+def _loops(cfg, flip, alt=False):
+    """alt=True resolves an AMBIGUOUS face (two diagonally opposite inside corners) the other way: each entering edge is joined
+    to the second leaving edge counter-clockwise, so the face separates its two OUTSIDE corners.  Also a rule of the face's
+    own four signs, hence also watertight -- a different, equally valid triangulation over the same vertices (test use only)."""
     nxt = {}
     for ring in cube_faces():
         ins = [(cfg >> c) & 1 for c in ring]
+        ambiguous = ins == [ins[0], 1 - ins[0], ins[0], 1 - ins[0]]
         for i in range(4):
             if not ins[i] and ins[(i + 1) % 4]:                      # entering edge
                 j = (i + 1) % 4
                 while not (ins[j] and not ins[(j + 1) % 4]):         # next leaving edge counter-clockwise
                     j = (j + 1) % 4
+                if alt and ambiguous:                                # ... or the one after it
+                    j = (j + 1) % 4
+                    while not (ins[j] and not ins[(j + 1) % 4]):
+                        j = (j + 1) % 4
                 e_in = edge_id(ring[i], ring[(i + 1) % 4])
                 e_out = edge_id(ring[j], ring[(j + 1) % 4])
                 if flip:
@@ -156,8 +164,8 @@ def _triangulate(loop):
     return best[1]
 
 
-def build_tables():
-    """(n_tri[256] uint8, tri[256, MAX_TRI*3] uint8 of cube edge ids, 255-padded)."""
+def build_tables(alt=False):
+    """(n_tri[256] uint8, tri[256, MAX_TRI*3] uint8 of cube edge ids, 255-padded).  alt: see _loops."""
     # winding: a lone inside corner 0 must give a triangle whose normal points away from it
     flip = False
     l = _loops(1, False)[0]
@@ -167,7 +175,7 @@ def build_tables():
     tris = []
     for cfg in range(256):
         t = []
-        for loop in _loops(cfg, flip):
+        for loop in _loops(cfg, flip, alt):
             assert len(loop) >= 3
             for tri in _triangulate(loop):
                 t += list(tri)
@@ -190,8 +198,9 @@ def tables():
     return _TABLES
 
 
-def marching_cubes(volume, level=0.0):
+def marching_cubes(volume, level=0.0, table=None):
     """volume (n0, n1, n2) float32 -> (vertices (V,3) float32 in INDEX coordinates, faces (F,3) int32).
+    table: (n_tri, tri) to use instead of the library's construction (tests: build_tables(alt=True)).
 
     vertex on the edge from grid point g along axis a:  g + t * e_a,  t = (level - s0) / (s1 - s0)  (float32)."""
     vol = np.ascontiguousarray(volume, np.float32)
@@ -219,7 +228,7 @@ def marching_cubes(volume, level=0.0):
     verts = ijk.copy()
     verts[np.arange(len(axis)), axis] = ijk[np.arange(len(axis)), axis] + tpar.reshape(-1, 3)[gidx, axis]
     # --- faces: per cell (ordered by the index of its lowest corner), table order
-    n_tri, tab = tables()
+    n_tri, tab = tables() if table is None else table
     cfg = np.zeros((n0 - 1, n1 - 1, n2 - 1), np.int32)
     for c in range(8):
         o = corner_offset(c)

@@ -5,7 +5,8 @@
 //               src/LocalMapping.cc:38-40 (Optimizer / MeshExtractor construction),
 //               src/LocalMapping_util.cc:109-110 (estimate_pose_cam_obj -> Matrix4f),
 //               src/LocalMapping_util.cc:179-191 (reconstruct_object -> is_good / t_cam_obj / code),
-//               src/LocalMapping_util.cc:391-413 (5-argument form with a warm-start code, loss, code_len).
+//               src/LocalMapping_util.cc:391-413 (5-argument form with a warm-start code, loss, code_len),
+//               src/LocalMapping_util.cc:194-196,426-428 (extract_mesh_from_code -> vertices MatrixXf / faces MatrixXi).
 // Eigen is column-major and pybind11's Eigen caster hands numpy Fortran-ordered float32 COPIES; the harness builds the
 // same kind of arrays (py::array::f_style).  Inputs are read from an .npz the Python test wrote; results are printed as
 // "key v0 v1 ..." lines for the test to compare.
@@ -74,7 +75,17 @@ int main(int argc, char** argv) {
                 std::printf("loss2 %.9g\n", obj2.attr("loss").cast<float>());
                 std::printf("code_len %d\n", pyOptimizer.attr("code_len").cast<int>());
                 print_arr("t_cam_obj2", obj2.attr("t_cam_obj"));
-                // mesh extractor: the decoder half (grid decode) -- marching cubes needs scikit-image
+                // mesh extractor, as CreateNewMapObjects / ProcessDetectedObjects call it: code in, .vertices cast to MatrixXf,
+                // .faces cast to MatrixXi                                             (LocalMapping_util.cc:194-196,426-428)
+                py::object pyMesh = pyMeshExtractor.attr("extract_mesh_from_code")(obj.attr("code"));
+                py::array_t<float, py::array::c_style | py::array::forcecast> verts(pyMesh.attr("vertices"));
+                py::array_t<int, py::array::c_style | py::array::forcecast> faces(pyMesh.attr("faces"));
+                std::printf("mesh_shape %lld %lld %lld %lld\n", (long long)verts.shape(0), (long long)verts.shape(1), (long long)faces.shape(0),
+                            (long long)faces.shape(1));
+                print_arr("mesh_vertices", pyMesh.attr("vertices"));
+                std::printf("mesh_faces");
+                for (py::ssize_t i = 0; i < faces.size(); ++i) std::printf(" %d", faces.data()[i]);
+                std::printf("\n");
                 py::object grid = pyMeshExtractor.attr("decode_grid")(obj.attr("code"));
                 std::printf("grid_size %lld\n", (long long)py::array(grid).size());
             }

@@ -45,7 +45,9 @@ def test_cpp_embed_call_surface(tmp_path):
     res = {}
     for line in out.stdout.splitlines():
         k, *v = line.split()
-        res[k] = np.array([float(x) for x in v], np.float32)
+        if not k.startswith(("mesh_", "is_good", "keyerror", "code_len", "grid_size", "pose_only", "t_cam_obj", "code", "loss2")):
+            continue        # a print of the Python side (timing lines)
+        res[k] = np.array([int(x) for x in v], np.int64) if k in ("mesh_faces", "mesh_shape") else np.array([float(x) for x in v], np.float32)
     assert res["is_good"][0] == 1 and res["keyerror"][0] == 1 and res["code_len"][0] == 64 and res["grid_size"][0] == 16 ** 3
     # same numbers as the direct Python / C-ABI path
     from oracle import dsp_oracle as O
@@ -60,4 +62,9 @@ def test_cpp_embed_call_surface(tmp_path):
     pose = eng.estimate_pose_batch(prm, [gp["t_co_se3"]], [float(gp["scale"])], [gp["pts"]], [gp["code"]])
     assert np.array_equal(res["pose_only"].reshape(4, 4), pose[0])
     assert np.abs(pose[0] - gp["out"]).max() < 1e-4 * np.abs(gp["out"]).max()      # and the reference's golden pose
+    # the mesh C++ reads back (vertices as float32 (V,3), faces as int32 (F,3)) is the mesh the C ABI extracts for that code
+    nv, c3, nf, f3 = [int(x) for x in res["mesh_shape"]]
+    assert c3 == 3 and f3 == 3 and nv > 0 and nf > 0
+    v, f = eng.extract_mesh(code[0], 16)
+    assert np.array_equal(res["mesh_vertices"].reshape(nv, 3), v) and np.array_equal(res["mesh_faces"].reshape(nf, 3), f)
     eng.close()

@@ -368,3 +368,21 @@ def test_speculative_band_rows_are_exact(eng, oracle_decoder):
     res, st = eng.compute_render_loss(g["rays"], g["depth_obs"], g["t_obj_cam"], g["sampled"], g["code"], th=0.01)
     assert res[0].shape == g["ren_j7"].shape
     assert np.abs(res[2] - g["ren_r"]).max() < 2e-5
+
+
+def test_c_abi_gather_over_rccl(eng, oracle_decoder):
+    """dsp_pack_results / dsp_gather_results: the multi-GPU gather of the C ABI (one process, one handle per GPU, ONE ncclGather).
+    This box has one GPU, so the communicator has one rank: the block goes up to the device, through RCCL and back unchanged;
+    two handles on the same GPU are refused."""
+    prm = E.gn_params(num_iterations=2)
+    objs = synth.make_batch(3, first_seed=40, n_surface=120, n_background=30)
+    res = _run(eng, prm, objs)
+    packed = E.pack_results_c(*res)
+    assert np.array_equal(packed, D.pack_results(*res))                       # same layout as the Python mirror's
+    got = E.gather_results_c([eng], [packed])
+    assert np.array_equal(got, packed)
+    assert np.array_equal(E.gather_results_c([eng], [packed[:0]]), packed[:0])   # an empty shard still joins the collective
+    eng2 = E.Engine(oracle_decoder.layers, oracle_decoder.latent_in, oracle_decoder.code_len, device=0)
+    with pytest.raises(Exception):
+        E.gather_results_c([eng, eng2], [packed, packed])
+    eng2.close()

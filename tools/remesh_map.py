@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Batch re-decode every object of a saved DSP-SLAM map (MapObjects.txt) on the MI355X: one kernel launch decodes the
-D^3 SDF grid of ALL objects (saved as <id>_sdf.npy); per object, grid decode + marching cubes run on the device and the mesh is
+D^3 SDF grid of ALL objects (saved as <id>_sdf.npy); marching cubes then runs on the device on each decoded grid and the mesh is
 written as <id>.ply next to the pose <id>.npy -- the files the reference's extract_map_objects.py:46-63 produces.
 
     python tools/remesh_map.py --config configs/config_kitti.json --map_dir map/kitti/07 [--voxels_dim 64]
@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--map_dir", required=True)
     ap.add_argument("--voxels_dim", type=int, default=64)
     args = ap.parse_args()
-    from reconstruct.utils import get_configs, get_decoder, write_mesh_to_ply
+    from reconstruct.utils import get_configs, get_decoder, write_mesh_to_ply, convert_sdf_voxels_to_mesh
     from reconstruct.optimizer import MeshExtractor
     from dsp_slam_amd.map_objects import read_map_objects
     cfg = get_configs(args.config)
@@ -39,13 +39,13 @@ def main():
         np.save(os.path.join(save_dir, "%d_sdf.npy" % o["id"]), g)
     t0 = time.time()
     n_ok = 0
-    for o in objs:
+    for o, g in zip(objs, grids):
         try:
-            mesh = ext.extract_mesh_from_code(o["code"])
+            vertices, faces = convert_sdf_voxels_to_mesh(g)      # marching cubes on the grid decoded above: no second decode
         except ValueError as e:          # no zero crossing inside the grid
             print("object %d: %s" % (o["id"], e))
             continue
-        write_mesh_to_ply(mesh.vertices, mesh.faces, os.path.join(save_dir, "%d.ply" % o["id"]))
+        write_mesh_to_ply(vertices, faces, os.path.join(save_dir, "%d.ply" % o["id"]))
         n_ok += 1
     print("meshed %d objects in %.3f s" % (n_ok, time.time() - t0))
 
