@@ -14,8 +14,8 @@ Workloads (BASELINE.json configs):
   cfg2x64 (default; the configuration the metric is quoted on): 64 cfg2 objects per GPU -- 2000 surface points + 500
           background rays x 50 depth samples, 64-D code, 10 iterations, KITTI hyper-parameters;
   cfg4    1024 cfg2 objects over 8 GPUs = 128 x N objects block-sharded by estimated cost (distributed.shard_objects);
-  cfg5    4000-point objects, Redwood hyper-parameters (5 iterations), a mixed batch on two resident decoders (cars + a second
-          decoder), 32 + 32 objects per GPU.
+  cfg5    4000-point objects, Redwood hyper-parameters (5 iterations), a mixed batch on two resident decoders (cars, 64-D codes +
+          chairs32, 32-D codes and its own weights), 32 + 32 objects per GPU.
 
 The JSON line also carries
   roofline      fp32-MFMA roofline of the dominant fp32 kernel (forward decoder with relu-mask export, mlp_kernel<1>):
@@ -45,18 +45,6 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: 256 CU x 256 FLOP/clk x 2
 PEAK_16BIT_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / f16 MFMA (no sparsity)
 REDWOOD = dict(k1=10.0, k2=100.0, k3=2.5, k4=0.0, b1=0.2, b2=0.02, lr=1.0, s_damp=100.0, num_iterations=5)   # config_redwood_01053.json
 PREPASS = {"auto": -1, "off": 0, "f16": 1, "bf16": 2}
-
-
-def second_decoder_layers(layers):
-    """A second resident weight set for cfg5 (no chairs weights exist offline): the cars decoder composed with a 90-degree roll
-    about z, f'(x, y, z) = f(-y, x, z), applied to the xyz columns of the two layers that see xyz."""
-    out = [(np.array(w, np.float32, copy=True), np.array(b, np.float32, copy=True)) for w, b in layers]
-    for k in (0, 4):
-        w = out[k][0]
-        wx, wy = w[:, -3].copy(), w[:, -2].copy()
-        w[:, -3] = wy
-        w[:, -2] = -wx
-    return out
 
 
 def reference_cpu_baseline(obj, threads):
@@ -159,19 +147,18 @@ def main():
         B = 2 * half
         prm = E.gn_params(**REDWOOD)
         shards = [(r * B, (r + 1) * B) for r in range(world)]
-        eng2 = E.Engine(second_decoder_layers(layers), lat_in, code_len, device=local_rank)
+        # second resident decoder: the chairs32 fixture -- 32-D codes (the Redwood chairs option of LocalMapping_util.cc:415-423), its own
+        # weights, fitted to a different (taller) shape family
+        sd2 = fixtures.load_decoder_npz(fixtures.fixture_path("chairs32"))
+        sp2 = fixtures.fixture_specs("chairs32")
+        eng2 = E.Engine(fold_weight_norm(sd2, len(sp2["NetworkSpecs"]["dims"]) + 1), sp2["NetworkSpecs"]["latent_in"], sp2["CodeLength"], device=local_rank)
         engines.append(eng2)
         cars = synth.make_batch(half, first_seed=1 + rank * B, n_surface=4000, n_background=500)
-        p = np.array([[0, -1, 0, 0], [1, 0, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float32)
-        others = []
-        for o in synth.make_batch(half, first_seed=1 + rank * B + half, n_surface=4000, n_background=500):
-            o = dict(o)
-            o["t_cam_obj_init"] = (o["t_cam_obj_init"] @ p).astype(np.float32)     # the same world points seen by the rolled decoder
-            others.append(o)
+        others = [synth.make_object(1 + rank * B + half + i, n_surface=4000, n_background=500, code_len=32, half=synth.CHAIR_HALF) for i in range(half)]
         groups = [(eng, cars), (eng2, others)]
         objs = cars
         workload = ("cfg5: 4000 surface pts + 500 free-space rays x 50 samples, Redwood hyper-parameters (5 iterations), mixed batch on two "
-                    "resident decoders, %d + %d objects per GPU" % (half, half))
+                    "resident decoders (cars: 64-D codes; chairs32: 32-D codes, own weights), %d + %d objects per GPU" % (half, half))
     batches = []
     for e, ol in groups:
         bt = e.batch(prm, [o["t_cam_obj_init"] for o in ol], [o["pts"] for o in ol], [o["rays"] for o in ol], [o["depth"] for o in ol])

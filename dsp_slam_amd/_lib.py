@@ -124,6 +124,16 @@ def f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
+def code64(code):
+    """A shape code as the C ABI carries it: DSP_CODE_LEN (64) floats; a 32-D code occupies the first 32 entries, the rest is zero
+    (the decoder has no weights for them and the optimiser leaves them alone)."""
+    c = np.asarray(code, np.float32).reshape(-1)
+    out = np.zeros(CODE_LEN, np.float32)
+    n = min(c.shape[0], CODE_LEN)
+    out[:n] = c[:n]
+    return out
+
+
 def ptr(a, typ=c_f32p):
     return None if a is None else a.ctypes.data_as(typ)
 

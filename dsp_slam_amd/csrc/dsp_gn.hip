@@ -65,6 +65,7 @@ struct dsp_handle {
     float b_last = 0.f;
     int wlast_row = 0, w0_row = 0;
     int n_bias_rows = 0, n_fwd = 0, n_pass_all = 0, chunks_fwd = 0, chunks_all = 0;
+    int lat_tile = 27, code_len = CODE_LEN;
     PassDesc pass[MAX_PASSES];
     // low-precision prepass (mlp_lp_kernel.hip): packed 16-bit weight streams [0] = f16, [1] = bf16 and their pass table
     DevBuf<uint16_t> wlp[2];
@@ -93,20 +94,24 @@ namespace {
 
 struct NetView {
     int n_layers, hidden, lat;
+    int code_len = CODE_LEN, in_dim = IN_DIM;   // of the decoder (code_len 32 or 64)
+    int width = WIDTH;                           // hidden width of the decoder (<= 512: narrower nets are embedded with zero rows / columns)
     std::vector<int> out_dims, in_dims;
     std::vector<const float*> w, b;
     // layer k: input-slab row -> original weight column (or -1).  The code columns of the latent_in layer are not part
     // of the forward stream (they are a per-object bias, k_code_bias) but their gradient rows 448..511 are produced by the
     // backward pass; layer 0 never goes through the forward stream at all and only its 64 code rows through the backward one.
+    int lat_row0() const { return WIDTH - in_dim; }
     std::vector<int> colmap(int k, bool backward) const {
         std::vector<int> m(WIDTH, -1);
         if (k == 0) {
-            if (backward) for (int r = 0; r < CODE_LEN; ++r) m[r] = r;
+            if (backward) for (int r = 0; r < code_len; ++r) m[r] = r;
         } else if (k == lat) {
-            const int p = WIDTH - IN_DIM;                                  // 445
-            for (int r = 0; r < p; ++r) m[r] = r;
-            for (int r = 0; r < 3; ++r) m[p + r] = p + CODE_LEN + r;         // xyz re-injected at rows 445..447
-            if (backward) for (int r = 0; r < CODE_LEN; ++r) m[p + 3 + r] = p + r;   // code gradient rows 448..511
+            const int p = lat_row0();                                        // slab row of x: 445 (code_len 64) or 477 (32)
+            const int hr = width - in_dim;                                   // rows of the previous layer's output
+            for (int r = 0; r < hr; ++r) m[r] = r;
+            for (int r = 0; r < 3; ++r) m[p + r] = hr + code_len + r;        // xyz re-injected at slab rows p .. p+2
+            if (backward) for (int r = 0; r < code_len; ++r) m[p + 3 + r] = hr + r;   // code gradient rows p+3 ..
         } else {
             for (int r = 0; r < in_dims[k]; ++r) m[r] = r;
         }
@@ -140,6 +145,7 @@ struct PackedNet {
     float b_last = 0.f;
     int wlast_row = 0, w0_row = 0;
     int n_bias_rows = 0, n_fwd = 0, n_pass_all = 0, chunks_fwd = 0, chunks_all = 0;
+    int lat_tile = 27, code_len = CODE_LEN;   // 16-row slab tile holding the re-injected xyz (27: rows 445..447, 29: 477..479)
     PassDesc pass[MAX_PASSES];
 };
 
@@ -148,19 +154,29 @@ void pack_decoder_host(PackedNet* h, const dsp_decoder_desc* d) {
     nv.n_layers = d->n_layers;
     nv.hidden = d->n_layers - 1;
     nv.lat = d->latent_in;
-    if (d->code_len != CODE_LEN) throw std::invalid_argument("code_len must be 64");
+    if (d->code_len != 64 && d->code_len != 32) throw std::invalid_argument("code_len must be 64 or 32");
     if (nv.hidden < 2 || nv.hidden > 8) throw std::invalid_argument("need 2..8 hidden layers");
     if (nv.lat < 2 || nv.lat >= nv.hidden) throw std::invalid_argument("latent_in must name one hidden layer >= 2");
+    nv.code_len = d->code_len;
+    nv.in_dim = d->code_len + 3;
+    nv.width = d->out_dims[0];
+    // Narrower decoders run embedded in the 512-row slabs (zero rows / columns: an fmaf with a zero weight leaves the accumulator
+    // unchanged, so the results are those of a kernel built for the narrow width).  The re-injected input of the latent_in layer
+    // sits at fixed slab rows (445.. or 477..), so the previous layer's output must end below them.
+    if (nv.width < 16 || nv.width > WIDTH || nv.width % 16) throw std::invalid_argument("hidden width must be a multiple of 16, at most 512");
+    if (nv.width - nv.in_dim > nv.lat_row0()) throw std::invalid_argument("hidden width too large for this code length");
     for (int k = 0; k < d->n_layers; ++k) {
         nv.out_dims.push_back(d->out_dims[k]);
         nv.in_dims.push_back(d->in_dims[k]);
         nv.w.push_back(d->weights[k]);
         nv.b.push_back(d->biases[k]);
-        const int want_in = (k == 0) ? IN_DIM : WIDTH;
-        const int want_out = (k == nv.hidden) ? 1 : (k + 1 == nv.lat ? WIDTH - IN_DIM : WIDTH);
+        const int want_in = (k == 0) ? nv.in_dim : nv.width;
+        const int want_out = (k == nv.hidden) ? 1 : (k + 1 == nv.lat ? nv.width - nv.in_dim : nv.width);
         if (d->in_dims[k] != want_in || d->out_dims[k] != want_out)
-            throw std::invalid_argument("unsupported decoder geometry (hidden width must be 512, input 67, output 1)");
+            throw std::invalid_argument("unsupported decoder geometry (one hidden width, input code_len + 3, output 1, one latent_in layer)");
     }
+    h->lat_tile = nv.lat_row0() / 16;
+    h->code_len = nv.code_len;
     std::vector<float>& stream = h->stream;
     std::vector<float>& bias = h->bias;
     stream.clear();
@@ -173,8 +189,8 @@ void pack_decoder_host(PackedNet* h, const dsp_decoder_desc* d) {
         const int od = nv.out_dims[k], id = nv.in_dims[k];
         const float* W = nv.w[k];
         PassDesc& p = h->pass[np++];
-        p.nog = (int16_t)((od + 63) / 64);
-        p.nchunks = (int16_t)(k == nv.lat ? 7 : 8);          // latent_in: K = 445 + 3 rows
+        p.nog = (int16_t)((std::max(od, 1) + 63) / 64);
+        p.nchunks = (int16_t)(k == nv.lat ? (nv.lat_row0() + 3 + 63) / 64 : 8);          // latent_in: K = 445 + 3 rows (7 chunks) or 477 + 3 (8)
         p.bias_row = (int16_t)(k == nv.lat ? -2 : k - 1);    // -2: per-object bias (code contribution + b_lat)
         p.relu = 1;
         p.mask_slot = (int16_t)k;
@@ -191,19 +207,21 @@ void pack_decoder_host(PackedNet* h, const dsp_decoder_desc* d) {
     h->chunks_fwd = chunk;
     h->wlast_row = nv.hidden - 1;
     h->w0_row = nv.hidden;
-    for (int o = 0; o < WIDTH; ++o) bias[(size_t)h->wlast_row * WIDTH + o] = nv.w[nv.hidden][o];
+    for (int o = 0; o < nv.width; ++o) bias[(size_t)h->wlast_row * WIDTH + o] = nv.w[nv.hidden][o];
     for (int c3 = 0; c3 < 3; ++c3)
-        for (int o = 0; o < WIDTH; ++o) bias[(size_t)(h->w0_row + c3) * WIDTH + o] = nv.w[0][(size_t)o * IN_DIM + CODE_LEN + c3];
+        for (int o = 0; o < nv.width; ++o) bias[(size_t)(h->w0_row + c3) * WIDTH + o] = nv.w[0][(size_t)o * nv.in_dim + nv.code_len + c3];
     h->b_last = nv.b[nv.hidden][0];
     h->n_bias_rows = nv.hidden + 3;
     // code columns of layer 0 and of the latent_in layer, for the per-object bias
     h->codew.assign((size_t)2 * WIDTH * CODE_LEN, 0.f);
-    h->b0.assign(nv.b[0], nv.b[0] + WIDTH);
-    h->blat.assign(nv.b[nv.lat], nv.b[nv.lat] + WIDTH);
-    for (int o = 0; o < WIDTH; ++o)
-        for (int c = 0; c < CODE_LEN; ++c) {
-            h->codew[(size_t)o * CODE_LEN + c] = nv.w[0][(size_t)o * IN_DIM + c];
-            h->codew[(size_t)(WIDTH + o) * CODE_LEN + c] = nv.w[nv.lat][(size_t)o * WIDTH + (WIDTH - IN_DIM) + c];
+    h->b0.assign(WIDTH, 0.f);
+    h->blat.assign(WIDTH, 0.f);
+    std::copy(nv.b[0], nv.b[0] + nv.width, h->b0.begin());
+    std::copy(nv.b[nv.lat], nv.b[nv.lat] + nv.width, h->blat.begin());
+    for (int o = 0; o < nv.width; ++o)
+        for (int c = 0; c < nv.code_len; ++c) {       // code columns beyond code_len stay zero: the optimiser carries 64-entry codes
+            h->codew[(size_t)o * CODE_LEN + c] = nv.w[0][(size_t)o * nv.in_dim + c];
+            h->codew[(size_t)(WIDTH + o) * CODE_LEN + c] = nv.w[nv.lat][(size_t)o * nv.width + (nv.width - nv.in_dim) + c];
         }
     // backward passes (transposed weights): output rows = the forward layer's INPUT slab rows
     for (int k = nv.hidden - 1; k >= 0; --k) {
@@ -269,16 +287,17 @@ bool pack_decoder_lp_host(PackedLp* out, const dsp_decoder_desc* d, bool bf) {
     const int hidden = d->n_layers - 1, lat = d->latent_in;
     constexpr int NCH = 4, NOG = 2 * NCH;
     if (hidden < 2 || hidden > LP_MAX_PASSES || lat < 2 || lat >= hidden) return false;
-    const int in_dim = d->code_len + 3;
+    const int in_dim = d->code_len + 3, width = d->out_dims[0];            // narrower nets are embedded with zero rows / columns
+    if (width < 16 || width > WIDTH) return false;
     for (int k = 0; k < d->n_layers; ++k) {
-        const int want_in = k == 0 ? in_dim : WIDTH;
-        const int want_out = k == hidden ? 1 : (k + 1 == lat ? WIDTH - in_dim : WIDTH);
+        const int want_in = k == 0 ? in_dim : width;
+        const int want_out = k == hidden ? 1 : (k + 1 == lat ? width - in_dim : width);
         if (d->in_dims[k] != want_in || d->out_dims[k] != want_out) return false;
     }
-    const int lat_rows = WIDTH - in_dim;                                  // slab rows of the latent_in layer (445)
+    const int lat_rows = width - in_dim;                                  // slab rows of the latent_in layer (445 / 477 for width 512)
     const int lat_ksteps = (lat_rows + 15) / 16;
     const int xyz0 = LP_KSTEPS_PER_CHUNK * NCH - LP_XYZ_KSTEPS;           // first xyz k-step of the latent_in layer
-    if (lat_ksteps > xyz0 || xyz0 - lat_ksteps > 3) return false;
+    if (lat_ksteps > xyz0) return false;
     const int tsel = bf ? 1 : 0;
     out->stream.clear();
     memset(out->pass, 0, sizeof out->pass);
@@ -288,11 +307,10 @@ bool pack_decoder_lp_host(PackedLp* out, const dsp_decoder_desc* d, bool bf) {
         const int od = d->out_dims[k], id = d->in_dims[k];
         const float* W = d->weights[k];
         p.kind = (int16_t)(k == 0 ? 0 : (k == lat ? 2 : 1));
-        if ((od + 63) / 64 != NOG && (od + 63) / 64 != NOG - 1) return false;
-        p.nog = NOG;               // the layer in front of the latent_in layer is padded with zero rows: every pass is the same straight-line code
+        p.nog = NOG;               // layers with fewer than 512 outputs are padded with zero rows: every pass is the same straight-line code
         p.nchunks = (int16_t)(k == 0 ? 1 : NCH);
         p.bias_row = (int16_t)(k == 0 ? -3 : (k == lat ? -2 : k - 1));
-        p.npad = (int16_t)(k == lat ? xyz0 - lat_ksteps : 0);
+        p.npad = (int16_t)(k == lat ? std::min(3, xyz0 - lat_ksteps) : 0);   // (a narrower net's unused slab rows are zero anyway: every layer writes them)
         p.last = (int16_t)(k == hidden - 1);
         p.chunk_base = chunk;
         const int slab_rows = k == 0 ? 0 : (k == lat ? lat_rows : id);
@@ -357,6 +375,7 @@ void pack_decoder(dsp_handle* h, const dsp_decoder_desc* d) {
     h->b_last = pn.b_last; h->n_bias_rows = pn.n_bias_rows; h->n_fwd = pn.n_fwd; h->n_pass_all = pn.n_pass_all;
     h->chunks_fwd = pn.chunks_fwd; h->chunks_all = pn.chunks_all;
     h->wlast_row = pn.wlast_row; h->w0_row = pn.w0_row;
+    h->lat_tile = pn.lat_tile; h->code_len = pn.code_len;
     h->h_codew = pn.codew; h->h_b0 = pn.b0; h->h_blat = pn.blat;
     h->codew.alloc(pn.codew.size());
     HIP_TRY(hipMemcpy(h->codew.p, pn.codew.data(), pn.codew.size() * 4, hipMemcpyHostToDevice));
@@ -425,6 +444,7 @@ MlpArgs make_mlp_args(const dsp_handle* h, int mode) {   // mode: 0/1 forward, 2
     a.wlast_row = h->wlast_row;
     a.w0_row = h->w0_row;
     a.seed_slot = h->n_fwd;        // mask slot of the last hidden layer (slot = layer index, layer 0 has slot 0)
+    a.lat_tile = h->lat_tile;
     a.wsplit = h->wsplit.p;
     memcpy(a.split_off, h->split_off, sizeof a.split_off);
     memcpy(a.split_len, h->split_len, sizeof a.split_len);
@@ -697,6 +717,7 @@ GnParamsDev dev_params(const dsp_batch* b) {
     p.k1 = b->prm.k1; p.k2 = b->prm.k2; p.k3 = b->prm.k3; p.k4 = b->prm.k4;
     p.b1 = b->prm.b1; p.b2 = b->prm.b2; p.lr = b->prm.lr; p.s_damp = b->prm.s_damp; p.cut_off = b->prm.cut_off;
     p.n_depth = b->D; p.pose_only = b->pose_only ? 1 : 0;
+    p.code_len = b->h->code_len;
     return p;
 }
 
@@ -1161,7 +1182,7 @@ int dsp_debug_code_bias(const dsp_decoder_desc* decoder, const float* code, floa
 
 /* Host-only: pack a decoder exactly as dsp_create does and copy the result out (tests emulate the kernel's
  * data flow on it without a GPU).  pass_out receives n_pass x 8 int32 {nog,nchunks,bias_row,relu,mask_slot,kind,chunk_base,0};
- * meta_out = {n_fwd, n_pass, chunks_fwd, chunks_all, n_bias_rows, wlast_row, w0_row}.  Call with NULL buffers to query sizes. */
+ * meta_out = {n_fwd, n_pass, chunks_fwd, chunks_all, n_bias_rows, wlast_row, w0_row, lat_tile, code_len}.  Call with NULL buffers to query sizes. */
 int dsp_debug_pack(const dsp_decoder_desc* decoder, float* stream_out, int64_t* stream_len, float* bias_out,
                    int64_t* bias_len, int32_t* pass_out, int32_t* meta_out, float* b_last_out) {
     if (!decoder || !stream_len || !bias_len || !meta_out) return DSP_E_ARG;
@@ -1172,7 +1193,7 @@ int dsp_debug_pack(const dsp_decoder_desc* decoder, float* stream_out, int64_t* 
         *bias_len = (int64_t)pn.bias.size();
         meta_out[0] = pn.n_fwd; meta_out[1] = pn.n_pass_all; meta_out[2] = pn.chunks_fwd; meta_out[3] = pn.chunks_all; meta_out[4] = pn.n_bias_rows;
         if (b_last_out) *b_last_out = pn.b_last;
-        meta_out[5] = pn.wlast_row; meta_out[6] = pn.w0_row;
+        meta_out[5] = pn.wlast_row; meta_out[6] = pn.w0_row; meta_out[7] = pn.lat_tile; meta_out[8] = pn.code_len;
         if (stream_out) memcpy(stream_out, pn.stream.data(), pn.stream.size() * 4);
         if (bias_out) memcpy(bias_out, pn.bias.data(), pn.bias.size() * 4);
         if (pass_out)

@@ -57,6 +57,7 @@ struct MlpArgs {
     const float* sdf_in;        // MODE 3: sdf of the samples, as written by the forward launches
     float th;                   // MODE 1: export masks of samples with |sdf| < th
     int seed_slot;              // MODE 3: mask slot of the last hidden layer
+    int lat_tile;               // 16-row slab tile of the latent_in layer's re-injected xyz: 27 (rows 445..447, 64-D codes) or 29 (477..479, 32-D)
     float* out_sdf;             // FWD: [n_points]
     float* out_grad;            // BWD: [n_points][GRAD_STRIDE]
     float* sdf_scatter;         // BWD, optional: tiles from *scatter_tile_begin on also store their sdf at sdf_scatter[int(pt.w)] (speculative band rows)
@@ -149,6 +150,7 @@ struct ObjState {           // per-object optimiser state, lives on the device f
 struct GnParamsDev {
     float k1, k2, k3, k4, b1, b2, lr, s_damp, cut_off;
     int n_depth, pose_only;
+    int code_len;       // of the decoder (32 or 64); the state always carries CODE_LEN entries
 };
 
 // kernels_mlp / kernels_gn launchers

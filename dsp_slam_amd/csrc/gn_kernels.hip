@@ -1024,12 +1024,16 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
             if (j < n) {
                 v = w_s * g0[q] + w_r * g1[q];                                                 // :161-168
                 if (i >= pd && i == j) v += (double)prm.k3;                                    // :170
+                // code entries beyond the decoder's code length (32-D codes in the 64-wide state) have a zero jacobian: their rows are
+                // k3 on the diagonal and 0 on the right -- pinned to the identity so that they stay decoupled (dx = 0) even with k3 = 0
+                if (i >= pd + prm.code_len && i == j) v = 1.0;
                 if (i < pd && j < pd) v += (double)prm.k4 * (double)jr(i) * (double)jr(j);       // :176,178
                 if (i < pd && i == j) v += 1.0;                                                // :183
                 if (i == pd - 1 && j == pd - 1) v += (double)prm.s_damp;                       // :184
             } else {
                 v = -(w_s * g0[q] + w_r * g1[q]);                                              // b = -J^T r~
                 if (i >= pd) v -= (double)prm.k3 * (double)s.code[i - pd];                     // :172
+                if (i >= pd + prm.code_len) v = 0.0;
                 if (i < pd) v += (double)prm.k4 * (double)jr(i) * (double)res_rot;             // :177,179 (sign as written)
             }
             A[i][j] = v;

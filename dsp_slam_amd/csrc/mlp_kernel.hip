@@ -185,7 +185,11 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
             // ---- pass prologue ------------------------------------------------------------------------------------
             if (pd.kind == 2) {
                 // latent_in layer: xyz re-enters at rows 445..447 (lane group 3); the code part is in the bias (cb_l + 512)
-                if (g == 3) { sin_[109] = pt.x; sin_[110] = pt.y; sin_[111] = pt.z; }
+                // (row 445 = tile 27, row 477 = tile 29 with 32-D codes; both are row 13 of their tile: lane group 3, registers 1..3)
+                if (g == 3) {
+                    if (a.lat_tile == 29) { sin_[117] = pt.x; sin_[118] = pt.y; sin_[119] = pt.z; }
+                    else { sin_[109] = pt.x; sin_[110] = pt.y; sin_[111] = pt.z; }
+                }
             } else if (BWD && pd.kind == 5) {
                 // first layer, backward: d y / d xyz = W0[:, xyz]^T ga0 on the VALU (ga0 = the input slab of this pass,
                 // which the pass epilogue overwrites); the MFMA pass itself only produces the 64 code rows
@@ -296,10 +300,16 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
                         if (pd.kind == 4) {
                             // latent_in layer: rows 445..447 / 448..511 of its input are the re-injected xyz / code, not
                             // relu outputs -- keep their gradients (unmasked) for the final d/d[code,xyz] sum
-                            if (og == 6) { skipx[0] = v[13]; skipx[1] = v[14]; skipx[2] = v[15]; }
-                            if (og == 7) {
+                            if (a.lat_tile != 29) {          // 64-D codes: xyz at rows 445..447, code at 448..511
+                                if (og == 6) { skipx[0] = v[13]; skipx[1] = v[14]; skipx[2] = v[15]; }
+                                if (og == 7) {
 #pragma unroll
-                                for (int k = 0; k < 16; ++k) skipc[k] = v[k];
+                                    for (int k = 0; k < 16; ++k) skipc[k] = v[k];
+                                }
+                            } else if (og == 7) {            // 32-D codes: xyz at rows 477..479, code at 480..511 (code index 16 (j - 2) + 4 g + r)
+                                skipx[0] = v[5]; skipx[1] = v[6]; skipx[2] = v[7];
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) skipc[k] = v[8 + k];
                             }
                         }
                         const unsigned bits = mask_l[(pd.mask_slot * 8 + og) * 256 + tid];

@@ -149,7 +149,11 @@ __global__ __launch_bounds__(256, 1) void mlp_split_kernel(const MlpArgs a) {
         for (int ps = 0; ps < a.n_pass; ++ps) {
             const PassDesc pd = a.pass[ps];
             if (pd.kind == 2) {
-                if (g == 3) { sin_[109] = pt.x; sin_[110] = pt.y; sin_[111] = pt.z; }
+                // (row 445 = tile 27, row 477 = tile 29 with 32-D codes; both are row 13 of their tile: lane group 3, registers 1..3)
+                if (g == 3) {
+                    if (a.lat_tile == 29) { sin_[117] = pt.x; sin_[118] = pt.y; sin_[119] = pt.z; }
+                    else { sin_[109] = pt.x; sin_[110] = pt.y; sin_[111] = pt.z; }
+                }
             } else if (BWD && pd.kind == 5) {
                 const float* w0 = bias_l + a.w0_row * WIDTH + 4 * g;
                 float gx = 0.f, gy = 0.f, gz = 0.f;
@@ -242,10 +246,16 @@ __global__ __launch_bounds__(256, 1) void mlp_split_kernel(const MlpArgs a) {
                         if (BWD) mask_l[(pd.mask_slot * 2 + ol) * 256 + tid] = (unsigned short)bits;
                     } else if (BWD && pd.mask_slot >= 0) {
                         if (pd.kind == 4) {      // latent_in layer: gradients of the re-injected xyz / code rows, unmasked (wave 3)
-                            if (og == 6) { skipx[0] = own[ol][13]; skipx[1] = own[ol][14]; skipx[2] = own[ol][15]; }
-                            if (og == 7) {
+                            if (a.lat_tile != 29) {          // 64-D codes: xyz at rows 445..447, code at 448..511
+                                if (og == 6) { skipx[0] = own[ol][13]; skipx[1] = own[ol][14]; skipx[2] = own[ol][15]; }
+                                if (og == 7) {
 #pragma unroll
-                                for (int k = 0; k < 16; ++k) skipc[k] = own[ol][k];
+                                    for (int k = 0; k < 16; ++k) skipc[k] = own[ol][k];
+                                }
+                            } else if (og == 7) {            // 32-D codes: xyz at rows 477..479, code at 480..511 (code index 16 (j - 2) + 4 g + r)
+                                skipx[0] = own[ol][5]; skipx[1] = own[ol][6]; skipx[2] = own[ol][7];
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) skipc[k] = own[ol][8 + k];
                             }
                         }
                         const unsigned bits = mask_l[(pd.mask_slot * 2 + ol) * 256 + tid];

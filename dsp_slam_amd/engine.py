@@ -50,7 +50,7 @@ class Batch(object):
         self._keep = (
             _ragged(pts, 3), _ragged(rays, 3), _ragged(depth, 0),
             L.f32(np.stack([np.asarray(t, np.float32).reshape(4, 4) for t in t_cam_obj])),
-            None if codes is None else L.f32(np.stack([np.asarray(c, np.float32)[:L.CODE_LEN] for c in codes])),
+            None if codes is None else L.f32(np.stack([L.code64(c) for c in codes])),
         )
         (po, p), (ro, r), (do, d), t, c = self._keep
         self._h = C.c_void_p()
@@ -106,7 +106,7 @@ class Batch(object):
         status = np.zeros(n, np.int32)
         L.check(L.load().dsp_batch_results(self._h, L.ptr(t), L.ptr(code), L.ptr(loss), L.ptr(status, L.c_i32p)),
                 self.engine._h, "dsp_batch_results")
-        return t, code, loss, status
+        return t, np.ascontiguousarray(code[:, :self.engine.code_len]), loss, status
 
     def stats(self):
         s = L.Stats()
@@ -153,6 +153,7 @@ def gather_results_c(engines, packed):
 def pack_results_c(t_cam_obj, codes, loss, status):
     n = len(loss)
     out = np.zeros((n, 82), np.float32)
+    codes = np.stack([L.code64(c) for c in codes]) if n else np.zeros((0, L.CODE_LEN), np.float32)
     L.load().dsp_pack_results(n, L.ptr(L.f32(t_cam_obj)), L.ptr(L.f32(codes)), L.ptr(L.f32(loss)), L.ptr(np.ascontiguousarray(status, np.int32), L.c_i32p),
                               L.ptr(out))
     return out
@@ -190,7 +191,7 @@ class Engine(object):
     # -- decoder ------------------------------------------------------------------------------------
     def decode_sdf(self, code, pts):
         pts = L.f32(pts).reshape(-1, 3)
-        code = L.f32(code).reshape(-1)[:L.CODE_LEN]
+        code = L.code64(code)
         out = np.zeros(pts.shape[0], np.float32)
         L.check(L.load().dsp_decode_sdf(self._h, L.ptr(code), L.ptr(pts), pts.shape[0], L.ptr(out)), self._h, "dsp_decode_sdf")
         return out
@@ -199,7 +200,7 @@ class Engine(object):
         """The decoder through the low-precision prepass kernel (f16 / bf16 MFMA).  Calibration and tests only: the optimiser
         uses these values to classify samples, never as results."""
         pts = L.f32(pts).reshape(-1, 3)
-        code = L.f32(code).reshape(-1)[:L.CODE_LEN]
+        code = L.code64(code)
         out = np.zeros(pts.shape[0], np.float32)
         L.check(L.load().dsp_decode_sdf_prepass(self._h, int(dtype), L.ptr(code), L.ptr(pts), pts.shape[0], L.ptr(out)), self._h,
                 "dsp_decode_sdf_prepass")
@@ -208,7 +209,8 @@ class Engine(object):
     def decode_sdf_multi(self, codes, pts):
         """(n_codes, 64) codes x one shared (n, 3) point set -> (n_codes, n) sdf, one kernel launch."""
         pts = L.f32(pts).reshape(-1, 3)
-        codes = L.f32(np.asarray(codes, np.float32).reshape(-1, L.CODE_LEN))
+        codes = np.asarray(codes, np.float32)
+        codes = L.f32(np.stack([L.code64(c) for c in codes.reshape(-1, codes.shape[-1])]))
         out = np.zeros((codes.shape[0], pts.shape[0]), np.float32)
         L.check(L.load().dsp_decode_sdf_multi(self._h, L.ptr(codes), codes.shape[0], L.ptr(pts), pts.shape[0], L.ptr(out)),
                 self._h, "dsp_decode_sdf_multi")
@@ -225,7 +227,7 @@ class Engine(object):
         """Grid decode + marching cubes on the device (the SDF volume never leaves HBM): vertices (V,3) float32 in the
         decoder's [-1,1]^3 frame, faces (F,3) int32.  Empty when the surface does not cross the grid.  regular_grid=False
         samples the reference's (sheared) grid, see reconstruct.utils.create_voxel_grid."""
-        code = L.f32(code).reshape(-1)[:L.CODE_LEN]
+        code = L.code64(code)
         nv, nf = C.c_int64(0), C.c_int64(0)
         L.check(L.load().dsp_extract_mesh(self._h, L.ptr(code), int(vol_dim), 1 if regular_grid else 0, C.byref(nv), C.byref(nf)), self._h, "dsp_extract_mesh")
         return self._fetch_mesh(nv, nf)
@@ -242,11 +244,13 @@ class Engine(object):
 
     def sdf_jacobian(self, code, pts):
         pts = L.f32(pts).reshape(-1, 3)
-        code = L.f32(code).reshape(-1)[:L.CODE_LEN]
+        code = L.code64(code)
         n = pts.shape[0]
         sdf = np.zeros(n, np.float32)
         grad = np.zeros((n, L.GRAD_DIM), np.float32)
         L.check(L.load().dsp_sdf_jacobian(self._h, L.ptr(code), L.ptr(pts), n, L.ptr(sdf), L.ptr(grad)), self._h, "dsp_sdf_jacobian")
+        if self.code_len != L.CODE_LEN:     # d/d[code(code_len), xyz]: drop the unused code columns
+            grad = np.ascontiguousarray(np.concatenate([grad[:, :self.code_len], grad[:, L.CODE_LEN:]], 1))
         return sdf, grad
 
     # -- residual terms -----------------------------------------------------------------------------
@@ -254,20 +258,20 @@ class Engine(object):
         pts = L.f32(pts_cam).reshape(-1, 3)
         n = pts.shape[0]
         t = L.f32(t_obj_cam).reshape(4, 4)
-        code = L.f32(code).reshape(-1)[:L.CODE_LEN]
+        code = L.code64(code)
         j7 = np.zeros((n, 7), np.float32)
         jc = np.zeros((n, L.CODE_LEN), np.float32)
         r = np.zeros(n, np.float32)
         L.check(L.load().dsp_compute_sdf_loss(self._h, L.ptr(pts), n, L.ptr(t), L.ptr(code), L.ptr(j7), L.ptr(jc), L.ptr(r)),
                 self._h, "dsp_compute_sdf_loss")
-        return j7, jc, r
+        return j7, jc[:, :self.code_len], r
 
     def compute_render_loss(self, rays, depth_obs, t_obj_cam, sampled_depth, code, th=0.01):
         rays = L.f32(rays).reshape(-1, 3)
         depth_obs = L.f32(depth_obs).reshape(-1)
         sampled = L.f32(sampled_depth).reshape(-1)
         t = L.f32(t_obj_cam).reshape(4, 4)
-        code = L.f32(code).reshape(-1)[:L.CODE_LEN]
+        code = L.code64(code)
         cap = rays.shape[0] * sampled.shape[0]
         j7 = np.zeros((cap, 7), np.float32)
         jc = np.zeros((cap, L.CODE_LEN), np.float32)
@@ -281,7 +285,7 @@ class Engine(object):
         stats = dict(V=v.value, m=m.value, K=k.value)
         if k.value < 0:
             return None, stats
-        return (j7[:k.value].copy(), jc[:k.value].copy(), r[:k.value].copy()), stats
+        return (j7[:k.value].copy(), jc[:k.value, :self.code_len].copy(), r[:k.value].copy()), stats
 
     # -- optimiser ----------------------------------------------------------------------------------
     def batch(self, prm, t_cam_obj, pts, rays, depth, codes=None, trace=False):
@@ -289,7 +293,7 @@ class Engine(object):
 
     def reconstruct_batch(self, prm, t_cam_obj, pts, rays, depth, codes=None):
         if len(pts) == 0:      # an empty shard (more ranks than objects): nothing to run, but the caller still joins the gather
-            return (np.zeros((0, 4, 4), np.float32), np.zeros((0, L.CODE_LEN), np.float32), np.zeros(0, np.float32), np.zeros(0, np.int32))
+            return (np.zeros((0, 4, 4), np.float32), np.zeros((0, self.code_len), np.float32), np.zeros(0, np.float32), np.zeros(0, np.int32))
         b = Batch(self, prm, t_cam_obj, pts, rays, depth, codes)
         try:
             b.run()
@@ -304,7 +308,7 @@ class Engine(object):
         po, p = _ragged(pts, 3)
         t = L.f32(np.stack([np.asarray(x, np.float32).reshape(4, 4) for x in t_co_se3]))
         sc = L.f32(np.asarray(scale, np.float32).reshape(n))
-        cd = L.f32(np.stack([np.asarray(c, np.float32)[:L.CODE_LEN] for c in codes]))
+        cd = L.f32(np.stack([L.code64(c) for c in codes]))
         out = np.zeros((n, 4, 4), np.float32)
         L.check(L.load().dsp_estimate_pose_batch(self._h, C.byref(prm), n, L.ptr(po, L.c_i64p), L.ptr(p), L.ptr(t), L.ptr(sc),
                                                  L.ptr(cd), L.ptr(out)), self._h, "dsp_estimate_pose_batch")

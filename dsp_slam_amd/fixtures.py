@@ -42,9 +42,11 @@ def _round_to_bf16(a):
     return bits, val
 
 
-def save_decoder_npz(state_dict, path):
+def save_decoder_npz(state_dict, path, code_len=None):
     """state_dict: torch or numpy tensors keyed as Decoder.state_dict() (no `module.` prefix)."""
     out = {}
+    if code_len is not None and code_len != SPECS["CodeLength"]:
+        out["meta:code_len"] = np.array(code_len, np.int32)
     for k, v in state_dict.items():
         a = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
         if k.endswith("weight_v") or k == "lin8.weight":
@@ -60,11 +62,23 @@ def load_decoder_npz(path):
     z = np.load(path)
     sd = {}
     for k in z.files:
+        if k.startswith("meta:"):
+            continue
         if k.endswith(":bf16"):
             sd[k[:-5]] = (z[k].astype(np.uint32) << 16).view(np.float32)
         else:
             sd[k] = z[k].astype(np.float32)
     return sd
+
+
+def fixture_specs(name_or_npz):
+    """specs.json content of a fixture: the upstream example spec with the fixture's CodeLength."""
+    path = name_or_npz if os.path.isfile(name_or_npz) else fixture_path(name_or_npz)
+    z = np.load(path)
+    specs = json.loads(json.dumps(SPECS))
+    if "meta:code_len" in z.files:
+        specs["CodeLength"] = int(z["meta:code_len"])
+    return specs
 
 
 def fixture_path(name):
@@ -79,7 +93,7 @@ def materialize_decoder_dir(name_or_npz, out_dir, specs=None):
     sd = load_decoder_npz(path)
     os.makedirs(os.path.join(out_dir, "ModelParameters"), exist_ok=True)
     with open(os.path.join(out_dir, "specs.json"), "w") as f:
-        json.dump(specs or SPECS, f, indent=2)
+        json.dump(specs or fixture_specs(path), f, indent=2)
     tsd = {"module." + k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
     torch.save({"epoch": 0, "model_state_dict": tsd},
                os.path.join(out_dir, "ModelParameters", "latest.pth"))
@@ -95,7 +109,7 @@ def random_state_dict(seed, specs=None):
     rng = np.random.default_rng(seed)
     ns = specs["NetworkSpecs"]
     d0 = specs["CodeLength"] + 3
-    dims = [d0] + list(ns["dims"]) + [1]
+    dims = [d0] + list(ns["dims"]) + [1]      # any CodeLength / hidden widths the spec names
     sd = {}
     for layer in range(len(dims) - 1):
         out_dim = dims[layer + 1] - d0 if (layer + 1) in ns["latent_in"] else dims[layer + 1]

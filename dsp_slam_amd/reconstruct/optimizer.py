@@ -41,8 +41,10 @@ class Optimizer(object):
         self.num_iterations_pose_only = 5
         if configs.data_type == "KITTI":
             self.num_iterations_pose_only = optim_cfg.pose_only_optim.num_iterations
-        if self.code_len != _L.CODE_LEN:
-            raise NotImplementedError("the MI355X decoder kernel is built for 64-D codes (got %d)" % self.code_len)
+        if self.code_len not in (32, _L.CODE_LEN):      # the two code lengths the reference's C++ casts (LocalMapping_util.cc:413-423)
+            raise NotImplementedError("the MI355X decoder kernels are built for 64-D and 32-D codes (got %d)" % self.code_len)
+        if decoder is not None and self.code_len != getattr(decoder, "latent_size", self.code_len):
+            raise ValueError("optimizer.code_len (%d) does not match the decoder's CodeLength (%d)" % (self.code_len, decoder.latent_size))
         self.verbose = True
 
     def _params(self):

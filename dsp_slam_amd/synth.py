@@ -12,33 +12,36 @@ BOX_HALF = np.array([0.38, 0.28, 0.80], dtype=np.float64)
 BOX_ROUND = 0.08
 
 
-def shape_half_extents(code3):
-    """Half extents of the rounded box for shape parameters code3 (first 3 code dims)."""
+CHAIR_HALF = np.array([0.36, 0.55, 0.36], dtype=np.float64)   # second shape family ("chairs" fixture: taller than wide)
+
+
+def shape_half_extents(code3, half=None):
+    """Half extents of the rounded box for shape parameters code3 (first 3 code dims); half: base extents (default BOX_HALF)."""
     code3 = np.asarray(code3, dtype=np.float64)
-    return BOX_HALF * (1.0 + 0.2 * np.tanh(code3))
+    return (BOX_HALF if half is None else np.asarray(half, np.float64)) * (1.0 + 0.2 * np.tanh(code3))
 
 
-def rounded_box_sdf(p, code3):
+def rounded_box_sdf(p, code3, half=None):
     """Signed distance of points p (...,3) to the rounded box with parameters code3 (...,3)|(3,)."""
     p = np.asarray(p, dtype=np.float64)
-    b = shape_half_extents(code3)
+    b = shape_half_extents(code3, half)
     q = np.abs(p) - b
     outside = np.linalg.norm(np.maximum(q, 0.0), axis=-1)
     inside = np.minimum(np.max(q, axis=-1), 0.0)
     return outside + inside - BOX_ROUND
 
 
-def _sdf_normal(p, code3, h=1e-4):
+def _sdf_normal(p, code3, h=1e-4, half=None):
     g = np.zeros_like(p)
     for a in range(3):
         e = np.zeros(3)
         e[a] = h
-        g[:, a] = (rounded_box_sdf(p + e, code3) - rounded_box_sdf(p - e, code3)) / (2 * h)
+        g[:, a] = (rounded_box_sdf(p + e, code3, half) - rounded_box_sdf(p - e, code3, half)) / (2 * h)
     n = np.linalg.norm(g, axis=-1, keepdims=True)
     return g / np.maximum(n, 1e-12)
 
 
-def surface_points(code3, n, rng):
+def surface_points(code3, n, rng, half=None):
     """n points on the zero level set, found by bisection along random rays from the centre."""
     u = rng.normal(size=(n, 3))
     u /= np.linalg.norm(u, axis=-1, keepdims=True)
@@ -46,7 +49,7 @@ def surface_points(code3, n, rng):
     hi = np.full(n, 1.6)
     for _ in range(40):
         mid = 0.5 * (lo + hi)
-        s = rounded_box_sdf(u * mid[:, None], code3)
+        s = rounded_box_sdf(u * mid[:, None], code3, half)
         inside = s < 0
         lo = np.where(inside, mid, lo)
         hi = np.where(inside, hi, mid)
@@ -58,14 +61,14 @@ def rot_y(theta):
     return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]], dtype=np.float64)
 
 
-def _ray_hits_shape(o, d, code3, n_steps=96):
+def _ray_hits_shape(o, d, code3, n_steps=96, half=None):
     """Sphere-trace rays (origin o (n,3), unit dir d (n,3), object frame); True where they hit."""
     t = np.zeros(o.shape[0])
     hit = np.zeros(o.shape[0], dtype=bool)
     alive = np.ones(o.shape[0], dtype=bool)
     for _ in range(n_steps):
         p = o + d * t[:, None]
-        s = rounded_box_sdf(p, code3)
+        s = rounded_box_sdf(p, code3, half)
         hit |= alive & (s < 1e-4)
         alive &= ~hit
         alive &= t < 60.0
@@ -74,7 +77,7 @@ def _ray_hits_shape(o, d, code3, n_steps=96):
 
 
 def make_object(seed, n_surface=2000, n_background=500, code_len=64,
-                t_noise=0.25, yaw_noise_deg=5.0):
+                t_noise=0.25, yaw_noise_deg=5.0, half=None):
     """One synthetic detection.
 
     Returns a dict with float32 arrays, laid out as the reference's callers build them
@@ -98,8 +101,8 @@ def make_object(seed, n_surface=2000, n_background=500, code_len=64,
     pts_o = np.zeros((0, 3))
     cam_o = r_co.T @ (-t) / scale  # camera centre in the object frame
     while pts_o.shape[0] < n_surface:
-        cand = surface_points(code_gt[:3], 4 * n_surface, rng)
-        nrm = _sdf_normal(cand, code_gt[:3])
+        cand = surface_points(code_gt[:3], 4 * n_surface, rng, half)
+        nrm = _sdf_normal(cand, code_gt[:3], half=half)
         vis = np.einsum("ij,ij->i", nrm, cam_o[None, :] - cand) > 0.05
         pts_o = np.concatenate([pts_o, cand[vis]], axis=0)
     pts_o = pts_o[:n_surface]
@@ -116,7 +119,7 @@ def make_object(seed, n_surface=2000, n_background=500, code_len=64,
         d_c = np.concatenate([uv, np.ones((uv.shape[0], 1))], axis=-1)
         d_o = d_c @ r_co  # R^T d  (row-vector form)
         d_o /= np.linalg.norm(d_o, axis=-1, keepdims=True)
-        hit = _ray_hits_shape(np.repeat(cam_o[None, :], uv.shape[0], 0), d_o, code_gt[:3])
+        hit = _ray_hits_shape(np.repeat(cam_o[None, :], uv.shape[0], 0), d_o, code_gt[:3], half=half)
         bg = np.concatenate([bg, d_c[~hit]], axis=0)
         if n_background == 0:
             break

@@ -62,3 +62,12 @@ def parity_log(**record):
     record["_t"] = time.time()
     with open(os.path.join(out, "parity.jsonl"), "a") as f:
         f.write(json.dumps({k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in record.items()}) + "\n")
+
+
+@pytest.fixture(scope="session")
+def chairs32_decoder():
+    """The second fixture decoder: 32-D codes, fitted to a different (taller) shape family (tools/make_decoder_fixture.py
+    --name chairs32 --code-len 32 --half 0.36 0.55 0.36); oracle form."""
+    from dsp_slam_amd import fixtures
+    from oracle import dsp_oracle
+    return dsp_oracle.fold_decoder(fixtures.load_decoder_npz(fixtures.fixture_path("chairs32")), fixtures.fixture_specs("chairs32"))

@@ -23,7 +23,7 @@ def debug_pack(layers, latent_in, code_len=64):
     lib = L.load()
     holder = L.DecoderDescHolder(layers, latent_in, code_len)
     slen, blen = C.c_int64(0), C.c_int64(0)
-    meta = np.zeros(7, np.int32)
+    meta = np.zeros(9, np.int32)
     L.check(lib.dsp_debug_pack(C.byref(holder.desc), None, C.byref(slen), None, C.byref(blen), None,
                                L.ptr(meta, L.c_i32p), None), None, "dsp_debug_pack(size)")
     stream = np.zeros(slen.value, np.float32)
@@ -34,12 +34,13 @@ def debug_pack(layers, latent_in, code_len=64):
                                L.ptr(passes, L.c_i32p), L.ptr(meta, L.c_i32p), C.byref(b_last)), None, "dsp_debug_pack")
     def code_bias(code):
         out = np.zeros(1024, np.float32)
-        L.check(lib.dsp_debug_code_bias(C.byref(holder.desc), L.ptr(L.f32(code)), L.ptr(out)), None, "dsp_debug_code_bias")
+        L.check(lib.dsp_debug_code_bias(C.byref(holder.desc), L.ptr(L.code64(code)), L.ptr(out)), None, "dsp_debug_code_bias")
         return out
 
     return dict(stream=stream.reshape(-1, 16, 64, 4), bias=bias.reshape(-1, 512), passes=passes,
                 n_fwd=int(meta[0]), n_pass=int(meta[1]), chunks_fwd=int(meta[2]), chunks_all=int(meta[3]),
-                n_bias_rows=int(meta[4]), wlast_row=int(meta[5]), w0_row=int(meta[6]), b_last=float(b_last.value),
+                n_bias_rows=int(meta[4]), wlast_row=int(meta[5]), w0_row=int(meta[6]), lat_tile=int(meta[7]), code_len=int(meta[8]),
+                b_last=float(b_last.value),
                 code_bias=code_bias, _holder=holder)
 
 
@@ -84,7 +85,8 @@ def run_wave(pk, code, pts16, bwd):
         assert chunk == chunk_base
         if kind == 2:
             g3 = G == 3
-            sin[109][g3], sin[110][g3], sin[111][g3] = px[g3], py[g3], pz[g3]
+            r0 = 4 * pk["lat_tile"] + 1          # row 445 (tile 27) or 477 (tile 29, 32-D codes): row 13 of the tile
+            sin[r0][g3], sin[r0 + 1][g3], sin[r0 + 2][g3] = px[g3], py[g3], pz[g3]
         elif bwd and kind == 5:
             part = np.zeros((3, 64))
             for t in range(32):
@@ -120,10 +122,15 @@ def run_wave(pk, code, pts16, bwd):
                 masks[(mask_slot, og)] = bits
             elif bwd and mask_slot >= 0:
                 if kind == 4:
-                    if og == 6:
-                        skipx = v[13:16].copy()
-                    if og == 7:
-                        skipc = v.copy()
+                    if pk["lat_tile"] != 29:
+                        if og == 6:
+                            skipx = v[13:16].copy()
+                        if og == 7:
+                            skipc = v.copy()
+                    elif og == 7:
+                        skipx = v[5:8].copy()
+                        skipc = np.zeros((16, 64))
+                        skipc[:8] = v[8:16]
                 bits = masks.get((mask_slot, og))
                 if bits is None:      # never written by the forward sweep (stale LDS in the kernel): must not matter
                     bits = np.ones((16, 64), bool)
@@ -143,7 +150,8 @@ def run_wave(pk, code, pts16, bwd):
             if bwd:
                 d = 1.0 - y * y
                 for o in range(8):
-                    sin[16 * o:16 * o + 16] = np.where(masks[(mask_slot, o)], d * wl[16 * o:16 * o + 16], 0.0)
+                    # (groups a narrower decoder never produced read stale mask bits in the kernel: their final-layer weights are 0)
+                    sin[16 * o:16 * o + 16] = np.where(masks.get((mask_slot, o), np.ones((16, 64), bool)), d * wl[16 * o:16 * o + 16], 0.0)
     sdf = y[:16]
     if not bwd:
         return sdf.astype(np.float32)
@@ -154,4 +162,8 @@ def run_wave(pk, code, pts16, bwd):
     for cidx in range(3):
         lanes = np.where(G == cidx)[0]
         grad[PL[lanes], 64 + cidx] = gfirst[lanes] + skipx[cidx][(lanes & 15) + 48]
+    cl = pk["code_len"]
+    if cl != 64:            # the kernel's row is always [64 code slots | xyz]: slots beyond the code length must be zero
+        assert np.all(grad[:, cl:64] == 0)
+        grad = np.concatenate([grad[:, :cl], grad[:, 64:]], 1)
     return sdf.astype(np.float32), grad.astype(np.float32)

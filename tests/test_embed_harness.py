@@ -43,10 +43,11 @@ def test_cpp_embed_call_surface(tmp_path):
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     res = {}
+    keys = ("mesh_shape", "mesh_vertices", "mesh_faces", "is_good", "keyerror", "code_len", "grid_size", "pose_only", "t_cam_obj", "t_cam_obj2", "code", "loss2")
     for line in out.stdout.splitlines():
-        k, *v = line.split()
-        if not k.startswith(("mesh_", "is_good", "keyerror", "code_len", "grid_size", "pose_only", "t_cam_obj", "code", "loss2")):
+        if not line.split() or line.split()[0] not in keys:
             continue        # a print of the Python side (timing lines)
+        k, *v = line.split()
         res[k] = np.array([int(x) for x in v], np.int64) if k in ("mesh_faces", "mesh_shape") else np.array([float(x) for x in v], np.float32)
     assert res["is_good"][0] == 1 and res["keyerror"][0] == 1 and res["code_len"][0] == 64 and res["grid_size"][0] == 16 ** 3
     # same numbers as the direct Python / C-ABI path

@@ -1,0 +1,137 @@
+"""GPU: decoders other than the 64-D / 512-wide cars fixture (VERDICT J1).
+
+* chairs32: 32-D codes (the Redwood chairs option the reference's C++ casts, LocalMapping_util.cc:415-423), a genuinely
+  different set of weights fitted to a different shape family -- against goldens recorded from the unmodified reference
+  and against the oracle, every GN iteration re-linearised, prepass on == off, mixed batches next to the cars decoder;
+* narrower hidden widths (Decoder.__init__ is generic over dims, deep_sdf_decoder.py:27-47): random decoders of width 256 / 384,
+  embedded in the 512-row kernels, against the oracle."""
+import copy
+import json
+
+import numpy as np
+import pytest
+
+from conftest import golden, parity_log
+from oracle import dsp_oracle as O
+from dsp_slam_amd import fixtures, synth, engine as E, _lib as L
+from test_gpu_parity import compare_linearisation, one_iteration_oracle, rel, LAST_LINEARISATION
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng32(chairs32_decoder):
+    e = E.Engine(chairs32_decoder.layers, chairs32_decoder.latent_in, chairs32_decoder.code_len, device=0)
+    yield e
+    e.close()
+
+
+def test_chairs32_decoder_vs_reference_golden_and_oracle(eng32, chairs32_decoder):
+    g = golden("golden_decoder_chairs32.npz")
+    assert np.abs(eng32.decode_sdf(g["code"], g["pts"]) - g["sdf"]).max() < 5e-6
+    sdf, grad = eng32.sdf_jacobian(g["code"], g["pts"])
+    assert grad.shape == (96, 35)
+    assert np.abs(sdf - g["y_jac"]).max() < 5e-6 and rel(grad, g["grad"]) < 2e-5
+    rng = np.random.default_rng(8)
+    for n in (1, 17, 64, 65, 5000):
+        code = (rng.normal(size=32) * 0.2).astype(np.float32)
+        pts = rng.uniform(-1, 1, size=(n, 3)).astype(np.float32)
+        assert np.abs(eng32.decode_sdf(code, pts) - O.decode_sdf(chairs32_decoder, code, pts)).max() < 5e-6
+        y, gr = O.get_batch_sdf_jacobian(chairs32_decoder, code, pts)
+        s2, g2 = eng32.sdf_jacobian(code, pts)
+        assert np.abs(s2 - y).max() < 5e-6 and np.abs(g2 - gr).max() < 1e-5 * max(1.0, np.abs(gr).max())
+        lp = eng32.decode_sdf_prepass(code, pts, L.PREPASS_F16)
+        assert np.abs(lp - y).max() < 4e-4
+
+
+def test_chairs32_reconstruction_vs_reference_golden(eng32, chairs32_decoder):
+    g = golden("golden_recon_chairs32.npz")
+    cfg = json.loads(str(g["cfg_json"]))
+    assert cfg["optimizer"]["code_len"] == 32
+    prm, oprm = E.params_from_configs(cfg), O.GNParams.from_configs(cfg)
+    obj = dict(pts=g["in_pts"], rays=g["in_rays"], depth=g["in_depth"])
+    out = {}
+    for mode in (0, 1):
+        b = eng32.batch(prm, [g["in_t_cam_obj_init"]], [g["in_pts"]], [g["in_rays"]], [g["in_depth"]], trace=True)
+        b.set_prepass(mode)
+        b.set_prepass_audit(bool(mode))
+        b.run()
+        out[mode] = (b.results(), [b.trace(e) for e in range(prm.num_iterations)], b.stats())
+        b.close()
+    (t, code, loss, status), traces, st = out[1]
+    assert status[0] == 0 and code.shape == (1, 32)
+    for a, c in zip(out[0][0], out[1][0]):
+        assert np.array_equal(a, c)                                         # prepass on == off, 32-D decoder
+    for ta, tc in zip(out[0][1], out[1][1]):
+        for k in ("H", "b", "dx", "V", "K", "set_sums"):
+            assert np.array_equal(ta[k], tc[k]), k
+    assert st["prepass_misclassified"] == 0 and 4.0 * st["prepass_max_err"] <= st["prepass_delta"]
+    # code entries beyond the decoder's 32 never move
+    assert all(np.all(tr["code"][0][32:] == 0) and np.all(tr["dx"][0][39:] == 0) for tr in traces)
+    # first iteration against the reference's own trace (39 x 39 system)
+    assert traces[0]["V"][0] == g["it_V"][0] and traces[0]["K"][0] == g["it_K"][0]
+    assert rel(traces[0]["H"][0][:39, :39], g["it_H"][0]) < 1e-4
+    # every iteration re-linearised by the oracle from the device state
+    strict, per = 0, []
+    for tr in traces:
+        tr39 = dict(tr, H=tr["H"][:, :39, :39], b=tr["b"][:, :39], dx=tr["dx"][:, :39], code=tr["code"][:, :32])
+        strict += bool(compare_linearisation(tr39, 0, one_iteration_oracle(chairs32_decoder, oprm, obj, tr39), oprm.k4))
+        per.append(dict(LAST_LINEARISATION))
+    parity_log(kind="iterations", case="chairs32 (32-D codes, Redwood hyper-parameters)", n=len(traces), strict=strict,
+               same_sets=sum(1 for p in per if p["same_sets"]), flips=[p["flips"] for p in per], rel_H=[p["rel_H"] for p in per],
+               rel_b=[p["rel_b"] for p in per], oracle_jitter_rel_H=[p["oracle_jitter_rel_H"] for p in per], K=[p["K"] for p in per])
+    assert strict >= 3
+    # chained result against the reference's, inside the reference's own round-off spread
+    sens_t = max(np.abs(a - g["t_cam_obj"]).max() for a in [g["ulp_t_cam_obj"]] + list(g["ulps_t_cam_obj"]))
+    sens_c = max(np.abs(a - g["code"]).max() for a in [g["ulp_code"]] + list(g["ulps_code"]))
+    d_t, d_c = np.abs(t[0] - g["t_cam_obj"]).max(), np.abs(code[0] - g["code"]).max()
+    parity_log(kind="end_to_end", case="golden_recon_chairs32.npz", n_draws=9, rot=float("nan"), rot_sens=float("nan"), scale=float("nan"),
+               scale_sens=float("nan"), trans=float("nan"), trans_sens=float("nan"), code=float(d_c), code_sens=float(sens_c),
+               loss=float(abs(loss[0] - float(g["loss"])) / abs(float(g["loss"]))), t_abs=float(d_t), t_abs_sens=float(sens_t))
+    assert d_t <= max(1e-4 * np.abs(g["t_cam_obj"]).max(), 3 * sens_t) and d_c <= max(1e-4, 3 * sens_c)
+
+
+def test_two_decoders_of_different_code_length_side_by_side(eng32, chairs32_decoder, oracle_decoder):
+    """cfg5's mixed batch with a genuinely different second decoder: car objects on the 64-D cars handle, chair objects on the
+    32-D chairs handle, interleaved; each handle's results are what it gives alone and match the oracle's linearisation."""
+    eng64 = E.Engine(oracle_decoder.layers, oracle_decoder.latent_in, oracle_decoder.code_len, device=0)
+    prm = E.gn_params(k1=10.0, k2=100.0, k3=2.5, k4=0.0, b1=0.2, b2=0.02, lr=1.0, s_damp=100.0, num_iterations=5)
+    oprm32 = O.GNParams(k1=10.0, k2=100.0, k3=2.5, k4=0.0, b1=0.2, b2=0.02, lr=1.0, s_damp=100.0, num_iterations=1, code_len=32)
+    cars = synth.make_batch(2, first_seed=700, n_surface=1000, n_background=200)
+    chairs = [synth.make_object(800 + i, n_surface=1000, n_background=200, code_len=32, half=synth.CHAIR_HALF) for i in range(2)]
+    bc = eng64.batch(prm, [o["t_cam_obj_init"] for o in cars], [o["pts"] for o in cars], [o["rays"] for o in cars], [o["depth"] for o in cars])
+    bh = eng32.batch(prm, [o["t_cam_obj_init"] for o in chairs], [o["pts"] for o in chairs], [o["rays"] for o in chairs],
+                     [o["depth"] for o in chairs], trace=True)
+    bc.run(); bh.run(); bc.run()
+    rc, rh = bc.results(), bh.results()
+    assert (rc[3] == 0).all() and (rh[3] == 0).all() and rc[1].shape == (2, 64) and rh[1].shape == (2, 32)
+    tr = bh.trace(0)
+    tr39 = dict(tr, H=tr["H"][:, :39, :39], b=tr["b"][:, :39], dx=tr["dx"][:, :39], code=tr["code"][:, :32])
+    compare_linearisation(tr39, 1, one_iteration_oracle(chairs32_decoder, oprm32, chairs[1], tr39, 1), 0.0)
+    alone = eng32.reconstruct_batch(prm, [o["t_cam_obj_init"] for o in chairs], [o["pts"] for o in chairs], [o["rays"] for o in chairs],
+                                    [o["depth"] for o in chairs])
+    assert np.array_equal(alone[0], rh[0]) and np.array_equal(alone[1], rh[1])
+    # the chairs converge towards their ground truth (the fitted decoder does describe that shape family)
+    e0 = np.mean([np.linalg.norm(o["t_cam_obj_init"][:3, 3] - o["t_cam_obj_gt"][:3, 3]) for o in chairs])
+    e1 = np.mean([np.linalg.norm(rh[0][i][:3, 3] - o["t_cam_obj_gt"][:3, 3]) for i, o in enumerate(chairs)])
+    assert e1 < e0
+    bc.close(); bh.close(); eng64.close()
+
+
+@pytest.mark.parametrize("code_len,width", [(64, 256), (32, 256), (64, 384)])
+def test_narrower_decoders_run_embedded(code_len, width):
+    sp = copy.deepcopy(fixtures.SPECS)
+    sp["CodeLength"] = code_len
+    sp["NetworkSpecs"]["dims"] = [width] * 8
+    dec = O.fold_decoder(fixtures.random_state_dict(40 + width + code_len, sp), sp)
+    e = E.Engine(dec.layers, dec.latent_in, dec.code_len, device=0)
+    rng = np.random.default_rng(width)
+    code = (rng.normal(size=code_len) * 0.3).astype(np.float32)
+    pts = rng.uniform(-1, 1, size=(3000, 3)).astype(np.float32)
+    y, g = O.get_batch_sdf_jacobian(dec, code, pts)
+    assert np.abs(e.decode_sdf(code, pts) - y).max() < 5e-6
+    s2, g2 = e.sdf_jacobian(code, pts)
+    assert g2.shape == (3000, code_len + 3)
+    assert np.abs(s2 - y).max() < 5e-6 and np.abs(g2 - g).max() < 1e-5 * max(1.0, np.abs(g).max())
+    assert np.abs(e.decode_sdf_prepass(code, pts, L.PREPASS_F16) - y).max() < 2e-3
+    e.close()

@@ -84,6 +84,7 @@ def test_huber():
 
 def _check_trace(oracle_decoder, name, tol_final):
     g = golden(name)
+    n_unk = 7 + oracle_decoder.code_len
     cfg = json.loads(str(g["cfg_json"]))
     prm = O.GNParams.from_configs(cfg)
     code = g["in_code"] if "in_code" in g.files else None
@@ -103,7 +104,7 @@ def _check_trace(oracle_decoder, name, tol_final):
             # b[3:6] carries k4 * J_rot * res_rot with res_rot = 1 + R_co[1,1]: for a near-upright object that is a
             # difference of two numbers ~1, quantised in fp32 ulps (6e-8) and then multiplied by k4 = 1e7 -- the
             # reference's own value is round-off noise there, so those three entries get an ulp-scaled tolerance
-            mask = np.ones(71, bool)
+            mask = np.ones(n_unk, bool)
             mask[3:6] = False
             assert np.abs(it["b"][mask] - g["it_b"][e][mask]).max() < 1e-4 * np.abs(g["it_b"][e]).max()
             j_rot = np.sqrt(np.abs(np.diag(g["it_H"][e])[3:6]) / max(prm.k4, 1.0))
@@ -126,7 +127,9 @@ def _check_trace(oracle_decoder, name, tol_final):
     assert d_t <= max(tol_final * np.abs(g["t_cam_obj"]).max(), 3 * sens_t)
     assert d_c <= max(tol_final, 3 * sens_c)
     assert abs(rst["loss"] - float(g["loss"])) <= max(1e-3 * abs(float(g["loss"])), 0.5 * abs(float(g["loss"])) * min(1.0, 50 * max(sens_t, sens_c)))
-    assert tr[0]["V"] == g["it_V"][0] and tr[0]["K"] == g["it_K"][0]
+    # own start state: T_oc comes from this BLAS's float32 inverse, which may differ from the reference's by an ulp -- one sample sitting on
+    # the unit sphere may then switch sides (chairs32: 9711 vs 9712)
+    assert abs(tr[0]["V"] - g["it_V"][0]) <= 1 and abs(tr[0]["K"] - g["it_K"][0]) <= 1
 
 
 def test_reconstruct_small_kitti(oracle_decoder):
@@ -179,3 +182,14 @@ def test_pose_only(oracle_decoder):
     prm = O.GNParams()
     out = O.estimate_pose_cam_obj(oracle_decoder, prm, g["t_co_se3"], float(g["scale"]), g["pts"], g["code"])
     assert rel(out, g["out"]) < 1e-5
+
+
+def test_chairs32_decoder_and_reconstruction(chairs32_decoder):
+    """The 32-D decoder (Redwood chairs option: LocalMapping_util.cc:415-423, Decoder.__init__ generic over latent_size,
+    deep_sdf_decoder.py:10-73) against goldens recorded from the unmodified reference."""
+    g = golden("golden_decoder_chairs32.npz")
+    assert chairs32_decoder.code_len == 32 and chairs32_decoder.layers[0][0].shape == (512, 35) and chairs32_decoder.layers[3][0].shape == (477, 512)
+    assert np.abs(O.decode_sdf(chairs32_decoder, g["code"], g["pts"]) - g["sdf"]).max() < 5e-7
+    y, grad = O.get_batch_sdf_jacobian(chairs32_decoder, g["code"], g["pts"])
+    assert np.abs(y - g["y_jac"]).max() < 5e-7 and rel(grad, g["grad"]) < 2e-6
+    _check_trace(chairs32_decoder, "golden_recon_chairs32.npz", 1e-4)

@@ -86,3 +86,41 @@ def test_split_stream_layout(packed):
         assert lf[w] == want_fwd and all(i < pk["chunks_fwd"] for i in want[:want_fwd])
     # waves 0..2 carry two groups of every pass; wave 3 one group fewer in the two 445/448-row passes; wave 0 the first-layer backward
     assert ln[0] > ln[1] == ln[2] > ln[3]
+
+
+def _specs(code_len=64, width=512):
+    import copy
+    sp = copy.deepcopy(fixtures.SPECS)
+    sp["CodeLength"] = code_len
+    sp["NetworkSpecs"]["dims"] = [width] * 8
+    return sp
+
+
+@pytest.mark.parametrize("code_len,width", [(32, 512), (64, 256), (32, 256), (64, 384)])
+def test_other_code_lengths_and_widths(code_len, width):
+    """32-D codes (the Redwood chairs option, LocalMapping_util.cc:415-423; Decoder.__init__ is generic over latent_size and
+    dims, deep_sdf_decoder.py:10-73): the re-injected input moves to slab rows 477.., and narrower decoders run embedded in
+    the 512-row slabs with zero rows / columns.  Forward, input gradient and the prepass stream against the oracle."""
+    sp = _specs(code_len, width)
+    dec = O.fold_decoder(fixtures.random_state_dict(11 + code_len + width, sp), sp)
+    assert dec.code_len == code_len and dec.layers[1][0].shape == (width, width) and dec.layers[3][0].shape[0] == width - code_len - 3
+    pk = KE.debug_pack(dec.layers, dec.latent_in, dec.code_len)
+    assert pk["code_len"] == code_len and pk["lat_tile"] == (29 if code_len == 32 else 27)
+    rng = np.random.default_rng(2)
+    code = (rng.normal(size=code_len) * 0.3).astype(np.float32)
+    pts = rng.uniform(-0.8, 0.8, size=(16, 3)).astype(np.float32)
+    sdf, grad = KE.run_wave(pk, code, pts, bwd=True)
+    y, g = O.get_batch_sdf_jacobian(dec, code, pts)
+    assert grad.shape == g.shape == (16, code_len + 3)
+    assert np.abs(sdf - y).max() < 2e-6
+    assert np.abs(grad - g).max() < 1e-5 * max(1.0, np.abs(g).max())
+    assert np.abs(g[:, :code_len]).max() > 1e-5 and np.abs(g[:, code_len:]).max() > 1e-5
+    assert np.abs(KE.run_wave(pk, code, pts, bwd=False) - y).max() < 2e-6
+    # prepass stream of the same decoder
+    import lp_emulator as LE
+    from dsp_slam_amd import _lib as L
+    lp = LE.debug_pack(pk["_holder"], L.PREPASS_F16)
+    pts32 = rng.uniform(-0.8, 0.8, size=(32, 3)).astype(np.float32)
+    got = LE.run_wave(pk, lp, code, pts32, L.PREPASS_F16)
+    assert np.abs(got - LE.reference_forward(dec, code, pts32, L.PREPASS_F16)).max() < 5e-5
+    assert np.abs(got - O.decode_sdf(dec, code, pts32)).max() < 2e-3

@@ -27,7 +27,7 @@ from dsp_slam_amd import synth  # noqa: E402
 from dsp_slam_amd.fixtures import SPECS, save_decoder_npz  # noqa: E402
 
 
-def sample_batch(rng, n, code_len):
+def sample_batch(rng, n, code_len, half=None):
     codes = np.zeros((n, code_len))
     codes[:, :3] = rng.normal(scale=0.45, size=(n, 3))
     codes[:, 3:] = rng.normal(scale=0.05, size=(n, code_len - 3))
@@ -45,7 +45,7 @@ def sample_batch(rng, n, code_len):
     c3 = codes[n_uni:, :3]
     for _ in range(30):
         mid = 0.5 * (lo + hi)
-        s = synth.rounded_box_sdf(d * mid[:, None], c3)
+        s = synth.rounded_box_sdf(d * mid[:, None], c3, half)
         inside = s < 0
         lo = np.where(inside, mid, lo)
         hi = np.where(inside, hi, mid)
@@ -53,7 +53,7 @@ def sample_batch(rng, n, code_len):
     sig = np.where(rng.uniform(size=(m, 1)) < 0.5, 0.01, 0.05)
     p_near = p_surf + rng.normal(size=(m, 3)) * sig
     p = np.concatenate([p_uni, p_near], 0)
-    sdf = synth.rounded_box_sdf(p, codes[:, :3])
+    sdf = synth.rounded_box_sdf(p, codes[:, :3], half)
     x = np.concatenate([codes, p], -1).astype(np.float32)
     return torch.from_numpy(x), torch.from_numpy(sdf.astype(np.float32))
 
@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--batch", type=int, default=16384)
+    ap.add_argument("--code-len", type=int, default=SPECS["CodeLength"])      # 32: the Redwood chairs option of LocalMapping_util.cc:415-423
+    ap.add_argument("--half", type=float, nargs=3, default=None)               # base half extents of the shape family (default: synth.BOX_HALF)
     args = ap.parse_args()
 
     ref_shim.install()
@@ -71,7 +73,7 @@ def main():
 
     torch.manual_seed(args.seed)
     rng = np.random.default_rng(args.seed)
-    code_len = SPECS["CodeLength"]
+    code_len = args.code_len
     dec = Decoder(code_len, **SPECS["NetworkSpecs"])
     dec.eval()  # dropout inert, as in deep_sdf/workspace.py:221
     opt = torch.optim.Adam(dec.parameters(), lr=1e-3)
@@ -79,7 +81,7 @@ def main():
     clamp = 0.1
     t0 = time.time()
     for step in range(args.steps):
-        x, y = sample_batch(rng, args.batch, code_len)
+        x, y = sample_batch(rng, args.batch, code_len, args.half)
         pred = dec(x).squeeze(-1)
         loss = (torch.clamp(pred, -clamp, clamp) - torch.clamp(y, -clamp, clamp)).abs().mean()
         opt.zero_grad()
@@ -91,7 +93,7 @@ def main():
 
     sd = {k: v.detach().clone() for k, v in dec.state_dict().items()}
     out = os.path.join(ROOT, "tests", "golden", "decoder_%s.npz" % args.name)
-    save_decoder_npz(sd, out)
+    save_decoder_npz(sd, out, code_len=code_len)
     print("wrote", out, os.path.getsize(out) / 1e6, "MB")
 
 

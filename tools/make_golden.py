@@ -34,10 +34,10 @@ FREIBURG = dict(k1=1.0, k2=100.0, k3=0.5, k4=0.0, b1=0.20, b2=0.025, num_iterati
                 learning_rate=1.0, scale_damping=100.0)
 
 
-def make_cfg(deepsdf_dir, joint, data_type="KITTI"):
+def make_cfg(deepsdf_dir, joint, data_type="KITTI", code_len=64):
     return {
         "data_type": data_type, "DeepSDF_DIR": deepsdf_dir, "voxels_dim": 32,
-        "optimizer": {"code_len": 64, "num_depth_samples": 50, "cut_off_threshold": 0.01,
+        "optimizer": {"code_len": code_len, "num_depth_samples": 50, "cut_off_threshold": 0.01,
                       "joint_optim": dict(joint),
                       "pose_only_optim": {"num_iterations": 5, "learning_rate": 1.0}},
     }
@@ -286,6 +286,26 @@ def main():
             json.dump(cfg_r, f)
         dec_r = get_decoder(get_configs(os.path.join(tmp, "cfg_r.json")))
         recon("golden_recon_fail.npz", synth.make_object(13, n_surface=100, n_background=30), cfg_r, dec=dec_r)
+
+    # ---- C2. a second decoder: 32-D codes (the Redwood chairs option, LocalMapping_util.cc:415-423), fitted to a different shape family
+    if want("chairs32"):
+        ch_dir = fixtures.materialize_decoder_dir("chairs32", os.path.join(tmp, "chairs_32"))
+        cfg_ch = make_cfg(ch_dir, REDWOOD, "Redwood", code_len=32)
+        with open(os.path.join(tmp, "cfg_ch.json"), "w") as f:
+            json.dump(cfg_ch, f)
+        dec_ch = get_decoder(get_configs(os.path.join(tmp, "cfg_ch.json")))
+        for p_ in dec_ch.parameters():
+            p_.requires_grad_(False)
+        n = 96
+        code = (rng.normal(size=32) * 0.1).astype(np.float32)
+        code[:3] = [0.2, -0.3, 0.1]
+        pts = rng.uniform(-0.9, 0.9, size=(n, 3)).astype(np.float32)
+        yj, gj = rlu.get_batch_sdf_jacobian(dec_ch, torch.from_numpy(code), torch.from_numpy(pts), 1)
+        sdf = rlu.decode_sdf(dec_ch, torch.from_numpy(code), torch.from_numpy(pts)).numpy()
+        np.savez_compressed(os.path.join(GOLD, "golden_decoder_chairs32.npz"), code=code, pts=pts, y_jac=yj.reshape(-1).numpy(),
+                            grad=gj.reshape(n, 35).numpy(), sdf=sdf)
+        obj = synth.make_object(21, n_surface=220, n_background=60, code_len=32, half=synth.CHAIR_HALF)
+        recon("golden_recon_chairs32.npz", obj, cfg_ch, dec=dec_ch)
 
     # ---- D. pose-only optimiser --------------------------------------------------------------
     if want("pose"):

@@ -39,7 +39,8 @@ def main():
     from reconstruct.utils import get_configs, get_decoder
     torch.manual_seed(0)
     tmp = tempfile.mkdtemp(prefix="dsp_sens_")
-    cars_dir = fixtures.materialize_decoder_dir("cars", os.path.join(tmp, "cars_64"))
+    dirs = {64: fixtures.materialize_decoder_dir("cars", os.path.join(tmp, "cars_64")),
+            32: fixtures.materialize_decoder_dir("chairs32", os.path.join(tmp, "chairs_32"))}
     names = sys.argv[1:] or sorted(f for f in os.listdir(GOLD) if f.startswith("golden_recon_") and f != "golden_recon_fail.npz")
     for name in names:
         path = os.path.join(GOLD, name)
@@ -47,7 +48,7 @@ def main():
         if not bool(g["is_good"]):
             continue
         cfg_d = json.loads(str(g["cfg_json"]))
-        cfg_d["DeepSDF_DIR"] = cars_dir
+        cfg_d["DeepSDF_DIR"] = dirs[cfg_d["optimizer"]["code_len"]]      # 64-D goldens use the cars fixture, 32-D ones chairs32
         with open(os.path.join(tmp, "cfg.json"), "w") as f:
             json.dump(cfg_d, f)
         cfg = get_configs(os.path.join(tmp, "cfg.json"))
