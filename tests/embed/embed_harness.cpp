@@ -38,6 +38,7 @@ struct PyThreadStateLock {   // reference include/System.h:56-70
 int main(int argc, char** argv) {
     if (argc < 4) { std::fprintf(stderr, "usage: embed_harness <mirror_dir> <cfg.json> <inputs.npz>\n"); return 2; }
     const std::string mirror = argv[1], cfg_file = argv[2], npz = argv[3];
+    std::setvbuf(stdout, nullptr, _IOLBF, 1 << 16);                            // whole lines, so that Python's own prints cannot land inside one
     py::initialize_interpreter();                                              // System.cc:90
     py::object pyCfg, pyDecoder;
     {

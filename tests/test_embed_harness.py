@@ -38,7 +38,7 @@ def test_cpp_embed_call_surface(tmp_path):
     gp = golden("golden_pose_only.npz")
     np.savez(tmp_path / "in.npz", t_cam_obj=g["in_t_cam_obj_init"], pts=g["in_pts"], rays=g["in_rays"], depth=g["in_depth"],
              pose_t_co_se3=gp["t_co_se3"], pose_scale=gp["scale"], pose_pts=gp["pts"], pose_code=gp["code"])
-    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), PYTHONUNBUFFERED="1")
     out = subprocess.run([HARNESS, os.path.join(ROOT, "dsp_slam_amd"), str(tmp_path / "cfg.json"), str(tmp_path / "in.npz")],
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
