@@ -14,10 +14,10 @@ def main():
     # keep the latest record per (kind, case)
     last = {}
     for r in recs:
-        last[(r["kind"], r.get("case", ""))] = r
+        last[(r["kind"], r.get("case", ""), r.get("dtype", ""))] = r
     print("# Parity report -- measured on MI355X by `pytest -m gpu` (tests/conftest.py:parity_log)\n")
     print("Every number is |device - reference| (or oracle) as the test measured it, next to the bound it was held to.\n")
-    e2e = [r for (k, _), r in last.items() if k == "end_to_end"]
+    e2e = [r for (k, _, _d), r in last.items() if k == "end_to_end"]
     if e2e:
         print("## Chained GN run vs the reference's final result (golden files recorded from the unmodified reference)\n")
         print("Bound per quantity: max(1e-4, the reference's own spread when every input element moves to an adjacent float32: 9 draws, golden ulp*_ fields).\n")
@@ -28,7 +28,7 @@ def main():
                 r["case"], r["rot"], r["rot_sens"], r["scale"], r["scale_sens"], r["trans"], r["trans_sens"], r["code"], r["code_sens"],
                 r["loss"], r["t_abs"], r["t_abs_sens"]))
         print()
-    its = [r for (k, _), r in last.items() if k == "iterations"]
+    its = [r for (k, _, _d), r in last.items() if k == "iterations"]
     if its:
         print("## Every GN iteration re-linearised by the oracle from the device's own state\n")
         print("strict = identical sample sets (membership checksums) AND the oracle's own jitter response < 1e-3: compared at 1e-4 + 4 x jitter response.\n")
@@ -38,7 +38,7 @@ def main():
             print("| %s | %d | %d | %d | %s | %.2e | %.2e | %.2e | %s |" % (
                 r["case"], r["n"], r["same_sets"], r["strict"], r["flips"], max(r["rel_H"]), max(r["rel_b"]), max(r["oracle_jitter_rel_H"]), r["K"]))
         print()
-    b64 = [r for (k, _), r in last.items() if k == "batch64"]
+    b64 = [r for (k, _, _d), r in last.items() if k == "batch64"]
     for r in b64:
         print("## %s\n" % r["case"])
         print("| object | iteration | identical sets | flips | rel dH | rel db | oracle jitter response | V | K |")
@@ -47,7 +47,7 @@ def main():
             print("| %d | %d | %s | %d | %.2e | %.2e | %.2e | %d | %d |" % (c["object"], c["iteration"], c["same_sets"], c["flips"], c["rel_H"], c["rel_b"],
                                                                            c["oracle_jitter_rel_H"], c["V"], c["K"]))
         print()
-    pp = [r for (k, _), r in last.items() if k == "prepass"]
+    pp = [r for (k, _, _d), r in last.items() if k == "prepass"]
     if pp:
         print("## Prepass (low-precision classification): audit against the fp32 decoder\n")
         print("| case | dtype | samples audited | max abs(sdf_lp - sdf_fp32) | margin delta | misclassified | fp32 forward points / in-sphere | bit-identical to prepass off |")

@@ -8,6 +8,9 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
 timeout 400 python bench.py --steps 5 --warmup 1 2> $OUT/bench.err | tail -1 > $OUT/bench.json
+timeout 400 python bench.py --steps 5 --warmup 1 --prepass off --no-cpu-baseline --latency-runs 3 2> $OUT/bench_prepass_off.err | tail -1 > $OUT/bench_prepass_off.json
+timeout 400 python bench.py --steps 3 --warmup 1 --config cfg4 --no-cpu-baseline 2> $OUT/bench_cfg4.err | tail -1 > $OUT/bench_cfg4.json
+timeout 400 python bench.py --steps 3 --warmup 1 --config cfg5 --no-cpu-baseline 2> $OUT/bench_cfg5.err | tail -1 > $OUT/bench_cfg5.json
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_stats -o stats -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --latency-runs 1 > $OUT/bench_under_rocprof.txt 2>&1
 DB=$(find /tmp/prof_stats -name "*.db" | head -1)
@@ -22,5 +25,8 @@ done
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_lat -o stats -- python $R/tools/gpu_small_loop.py 250 200 50 > $OUT/latency_run.txt 2>&1
 DB=$(find /tmp/prof_lat -name "*.db" | head -1)
 python $R/tools/rocpd_stats.py $DB > $OUT/latency_kernel_stats.md 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_lat2 -o stats -- python $R/tools/gpu_small_loop.py 2000 500 20 > $OUT/latency_cfg2_run.txt 2>&1
+DB=$(find /tmp/prof_lat2 -name "*.db" | head -1)
+python $R/tools/rocpd_stats.py $DB > $OUT/latency_cfg2_kernel_stats.md 2>&1
 cd $R
 cut -c1-600 $OUT/bench.json; head -12 $OUT/kernel_stats.md; tail -4 $OUT/latency_run.txt
