@@ -78,6 +78,7 @@ SYMBOLS = [
     ("dsp_batch_set_fused_bookkeeping", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_set_speculative_band", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_set_prepass", C.c_int, [_VP, C.c_int, C.c_float]),
+    ("dsp_prepass_calibration", C.c_int, [_VP, C.c_int, c_f32p, c_f32p]),
     ("dsp_batch_set_prepass_audit", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_set_split_rows", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_enable_trace", C.c_int, [_VP, C.c_int]),

@@ -23,6 +23,11 @@ namespace {
 
 thread_local std::string g_create_error;
 
+// Prepass margins are calibrated per decoder at dsp_create (calibrate_prepass): delta = 5 x the largest |sdf_lp - sdf_fp32| over
+// 64 k unit-ball points x 4 codes, not below these floors (what the cars fixture needs: measured 1.05e-4 f16, 6.8e-4 bf16 over the
+// 38 M audited samples of the bench workload, profiles/parity_r02.md).
+constexpr float PREPASS_DELTA_F16 = 5e-4f, PREPASS_DELTA_BF16 = 3e-3f;
+
 #define HIP_TRY(expr)                                                                                       \
     do {                                                                                                    \
         hipError_t e_ = (expr);                                                                             \
@@ -72,6 +77,8 @@ struct dsp_handle {
     LpPass lp_pass[LP_MAX_PASSES];
     int lp_n_pass = 0, lp_chunks = 0;
     bool lp_ok = false;        // decoder geometry supported by the prepass kernel (hidden width 512)
+    float lp_err[2] = {0.f, 0.f};      // calibration at dsp_create: largest |sdf_lp - sdf_fp32| over the calibration points, per dtype
+    float lp_delta[2] = {0.f, 0.f};    // the margin derived from it (prepass_delta default)
     // scratch of the single-shot decoder calls
     DevBuf<float4> s_pts;
     DevBuf<float> s_code, s_out, s_cbias;
@@ -545,6 +552,36 @@ void run_decoder_points(dsp_handle* h, const float* codes, int64_t n_codes, cons
     }
 }
 
+// Prepass margin of THIS decoder: decode seeded unit-ball points with a few codes through the fp32 kernel and through both
+// low-precision kernels and take 5 x the largest difference (never below the floors above).  A decoder whose 16-bit error were larger
+// than the fixture's -- bigger activations, say -- gets a wider band instead of misclassified samples; dsp_prepass_calibration reports it.
+void calibrate_prepass(dsp_handle* h) {
+    if (!h->lp_ok) return;
+    constexpr int N = 16384, NCODE = 4;
+    std::vector<float> pts((size_t)N * 3), codes((size_t)NCODE * CODE_LEN, 0.f), ref((size_t)N * NCODE), lp((size_t)N * NCODE);
+    uint64_t st = 0x9E3779B97F4A7C15ull;
+    auto rnd = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (float)((st >> 40) & 0xFFFFFF) / 16777216.f; };
+    for (int i = 0; i < N;) {                      // uniform in the unit ball (the optimiser only decodes in-sphere samples)
+        const float x = 2.f * rnd() - 1.f, y = 2.f * rnd() - 1.f, z = 2.f * rnd() - 1.f;
+        if (x * x + y * y + z * z >= 1.f) continue;
+        pts[3 * i] = x; pts[3 * i + 1] = y; pts[3 * i + 2] = z;
+        ++i;
+    }
+    for (int c = 1; c < NCODE; ++c)                // code 0 = the zero start; the others ~ +-0.15 uniform on the decoder's own entries
+        for (int k = 0; k < h->code_len; ++k) codes[(size_t)c * CODE_LEN + k] = 0.3f * (rnd() - 0.5f);
+    run_decoder_points(h, codes.data(), NCODE, pts.data(), N, false, ref.data(), nullptr, 0);
+    for (int bf = 0; bf < 2; ++bf) {
+        run_decoder_points(h, codes.data(), NCODE, pts.data(), N, false, lp.data(), nullptr, bf ? DSP_PREPASS_BF16 : DSP_PREPASS_F16);
+        float worst = 0.f;
+        for (size_t i = 0; i < ref.size(); ++i) {
+            const float d = std::fabs(lp[i] - ref[i]);
+            if (!(d <= worst)) worst = std::isfinite(d) ? d : 1.f;      // a non-finite prepass value: make the band cover everything
+        }
+        h->lp_err[bf] = worst;
+        h->lp_delta[bf] = std::min(0.5f, std::max(5.f * worst, bf ? PREPASS_DELTA_BF16 : PREPASS_DELTA_F16));
+    }
+}
+
 // marching cubes over a device-resident volume; the mesh stays in h->mc_verts / mc_faces until dsp_mesh_fetch
 void extract_mesh_device(dsp_handle* h, const float* vol, int n0, int n1, int n2, float level, float spacing, float origin) {
     if ((int64_t)n0 * n1 * n2 > ((int64_t)1 << 30)) throw std::invalid_argument("volume too large");
@@ -782,9 +819,6 @@ bool use_speculative_band(const dsp_batch* b) {
     return ((double)b->sum_pts + 0.16 * (double)b->cap_s) / SPLIT_TILE_PTS <= 1.0 * b->h->n_cu;
 }
 
-// Prepass default margins: 4x the largest |sdf_lp - sdf_fp32| measured on the device over the decoder fixtures
-// (tests/test_gpu_prepass.py prints it; profiles/parity_r02.md records it): f16 1.05e-4, bf16 6.8e-4.
-constexpr float PREPASS_DELTA_F16 = 5e-4f, PREPASS_DELTA_BF16 = 3e-3f;
 
 int prepass_mode(const dsp_batch* b) {      // 0 off, 1 f16, 2 bf16
     if (b->pose_only || !b->h->lp_ok) return 0;
@@ -793,7 +827,7 @@ int prepass_mode(const dsp_batch* b) {      // 0 off, 1 f16, 2 bf16
 }
 float prepass_delta(const dsp_batch* b) {
     if (b->prepass_delta >= 0.f) return b->prepass_delta;
-    return prepass_mode(b) == DSP_PREPASS_BF16 ? PREPASS_DELTA_BF16 : PREPASS_DELTA_F16;
+    return b->h->lp_delta[prepass_mode(b) == DSP_PREPASS_BF16 ? 1 : 0];     // calibrated for THIS decoder at dsp_create
 }
 
 // what: 0 = forward pass over the current sample list (with mask reuse: relu masks of band samples exported), 1 = jacobian
@@ -1228,6 +1262,7 @@ int dsp_create(const dsp_decoder_desc* decoder, int device, dsp_handle** out) {
         HIP_TRY(mlp_split_prepare_device());
         HIP_TRY(mlp_lp_prepare_device());
         pack_decoder(h, decoder);
+        calibrate_prepass(h);
     });
     if (rc != DSP_OK) { delete h; return rc; }
     *out = h;
@@ -1417,6 +1452,14 @@ int dsp_batch_set_ray_pass_bounds(dsp_batch* b, const int32_t* bounds, int n_pas
     for (int p = 0; p < n_passes; ++p) if (bounds[p + 1] < bounds[p]) return DSP_E_ARG;
     b->n_ray_passes = n_passes;
     b->pass_bounds.assign(bounds, bounds + n_passes + 1);
+    return DSP_OK;
+}
+
+int dsp_prepass_calibration(dsp_handle* h, int dtype, float* max_err, float* delta) {
+    if (!h || (dtype != DSP_PREPASS_F16 && dtype != DSP_PREPASS_BF16)) return DSP_E_ARG;
+    if (!h->lp_ok) return DSP_E_STATE;
+    if (max_err) *max_err = h->lp_err[dtype == DSP_PREPASS_BF16 ? 1 : 0];
+    if (delta) *delta = h->lp_delta[dtype == DSP_PREPASS_BF16 ? 1 : 0];
     return DSP_OK;
 }
 

@@ -206,6 +206,12 @@ class Engine(object):
                 "dsp_decode_sdf_prepass")
         return out
 
+    def prepass_calibration(self, dtype=L.PREPASS_F16):
+        """(largest |sdf_lp - sdf_fp32| measured at creation, margin derived from it) for this decoder."""
+        err, delta = C.c_float(0), C.c_float(0)
+        L.check(L.load().dsp_prepass_calibration(self._h, int(dtype), C.byref(err), C.byref(delta)), self._h, "dsp_prepass_calibration")
+        return err.value, delta.value
+
     def decode_sdf_multi(self, codes, pts):
         """(n_codes, 64) codes x one shared (n, 3) point set -> (n_codes, n) sdf, one kernel launch."""
         pts = L.f32(pts).reshape(-1, 3)

@@ -189,10 +189,14 @@ int dsp_batch_set_ray_pass_bounds(dsp_batch* b, const int32_t* bounds, int n_pas
  * prepass on, every candidate sample is first decoded by an f16 (or bf16) MFMA kernel at 16x the fp32 matrix rate; samples with
  * |sdf_lp| >= cut_off + delta are classified by that value alone, rays stop behind their first certainly-solid sample, and only the
  * samples inside the widened band are decoded by the fp32 kernel (one launch per iteration).  delta must exceed the largest
- * |sdf_lp - sdf_fp32| of the decoder (dsp_decode_sdf_prepass / the audit below measure it; default = 4x the measured maximum of
- * the dtype: 5e-4 f16, 3e-3 bf16); results are then identical, bit for bit, to prepass off.
+ * |sdf_lp - sdf_fp32| of the decoder.  The default is calibrated PER DECODER at dsp_create: 5x the largest difference over 16 384 seeded
+ * unit-ball points x 4 codes, not below 5e-4 (f16) / 3e-3 (bf16) -- dsp_prepass_calibration reports both numbers, the audit below
+ * measures the error on the actual workload; results are then identical, bit for bit, to prepass off.
  * mode: -1 automatic (f16 when the decoder geometry is supported), DSP_PREPASS_OFF / _F16 / _BF16; delta < 0 = default. */
 int dsp_batch_set_prepass(dsp_batch* b, int mode, float delta);
+/* The calibration dsp_create made for this decoder: largest |sdf_lp - sdf_fp32| it measured and the margin it derived (DSP_E_STATE when the
+ * decoder's geometry has no prepass kernel). */
+int dsp_prepass_calibration(dsp_handle* h, int dtype, float* max_err, float* delta);
 /* Audit: every run also decodes all in-sphere samples in fp32 and fills dsp_stats.prepass_max_err / _misclassified / _audited. */
 int dsp_batch_set_prepass_audit(dsp_batch* b, int on);
 /* Render rows (kept ray samples) need the decoder's input gradient at points the forward launches of the same iteration

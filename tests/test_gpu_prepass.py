@@ -160,3 +160,28 @@ def test_prepass_is_exact_on_64_cfg2_objects(eng):
     print("64 x cfg2: fp32 forward points %.3g -> %.3g (%.1f %% of in-sphere), prepass points %.3g, max |sdf_lp - sdf_fp32| %.3g, delta %.3g" % (
         ref[2]["n_fwd_points"], st["n_fwd_points"], 100 * st["n_fwd_points"] / st["n_insphere_points"], st["n_prepass_points"],
         st["prepass_max_err"], st["prepass_delta"]))
+
+
+def test_margin_is_calibrated_per_decoder(eng, oracle_decoder):
+    """dsp_create measures the prepass error of the decoder it was given and derives the margin from it: the fixture gets the
+    floor with f16 (its error is 5x below it) and 5x its measured error with bf16; a decoder whose hidden activations are 30x larger gets a proportionally wider band
+    instead of misclassified samples -- and still gives prepass-on == prepass-off."""
+    for dt, floor in ((L.PREPASS_F16, 5e-4), (L.PREPASS_BF16, 3e-3)):
+        err, delta = eng.prepass_calibration(dt)
+        assert 0 < err < floor / 4 and abs(delta - max(floor, 5 * err)) < 1e-7
+    # scale the last hidden layer's output by 30 and the final layer's weights by 1/30: same function, 30x the activations of layer 7
+    layers = [(w.copy(), b.copy()) for w, b in oracle_decoder.layers]
+    w7, b7 = layers[7]
+    layers[7] = (w7 * 30.0, b7 * 30.0)
+    layers[8] = (layers[8][0] / 30.0, layers[8][1])
+    big = E.Engine(layers, oracle_decoder.latent_in, oracle_decoder.code_len, device=0)
+    e1, d1 = big.prepass_calibration(L.PREPASS_F16)
+    assert d1 >= 5 * e1 * 0.999
+    prm = E.gn_params(num_iterations=3)
+    objs = synth.make_batch(2, first_seed=930, n_surface=300, n_background=80)
+    args = ([o["t_cam_obj_init"] for o in objs], [o["pts"] for o in objs], [o["rays"] for o in objs], [o["depth"] for o in objs])
+    ref = _run_traced(big, prm, args, L.PREPASS_OFF)
+    run = _run_traced(big, prm, args, L.PREPASS_F16)
+    _assert_identical(run, ref, "rescaled decoder")
+    assert run[2]["prepass_misclassified"] == 0 and abs(run[2]["prepass_delta"] - d1) < 1e-9
+    big.close()
