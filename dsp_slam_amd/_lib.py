@@ -13,6 +13,7 @@ from . import build as _build
 c_f32p = C.POINTER(C.c_float)
 c_i32p = C.POINTER(C.c_int32)
 c_i64p = C.POINTER(C.c_int64)
+c_f64p = C.POINTER(C.c_double)
 
 CODE_LEN = 64
 GRAD_DIM = 67
@@ -93,6 +94,15 @@ SYMBOLS = [
     ("dsp_debug_mc_table", C.c_int, [C.POINTER(C.c_uint8), C.POINTER(C.c_uint8)]),
     ("dsp_debug_code_bias", C.c_int, [C.POINTER(DecoderDesc), c_f32p, c_f32p]),
     ("dsp_debug_pack", C.c_int, [C.POINTER(DecoderDesc), c_f32p, c_i64p, c_f32p, c_i64p, c_i32p, c_i32p, c_f32p]),
+    # include/dsp_pose_graph.h (host fp64; no handle)
+    ("dsp_pg_from_matrix", C.c_int, [C.c_int64, c_f64p, c_f64p]),
+    ("dsp_pg_to_matrix", C.c_int, [C.c_int64, c_f64p, c_f64p]),
+    ("dsp_pg_log", C.c_int, [C.c_int64, c_f64p, c_f64p]),
+    ("dsp_pg_exp", C.c_int, [C.c_int64, c_f64p, c_f64p]),
+    ("dsp_pg_edge_error", C.c_int, [C.c_int64, c_f64p, c_f64p, c_f64p, c_f64p]),
+    ("dsp_pg_edge_linearize", C.c_int, [C.c_int64, c_f64p, c_f64p, c_f64p, c_f64p]),
+    ("dsp_pg_edge_chi2", C.c_int, [C.c_int64, c_f64p, C.c_double, C.c_double, c_f64p, c_f64p, c_f64p]),
+    ("dsp_pg_vertex_oplus", C.c_int, [C.c_int64, C.c_int, c_f64p, c_f64p, c_f64p]),
 ]
 
 

@@ -9,8 +9,9 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libdspgn.so")
-SOURCES = ["mlp_kernel.hip", "mlp_split_kernel.hip", "mlp_lp_kernel.hip", "gn_kernels.hip", "mesh_kernels.hip", "dsp_gn.hip"]
-HEADERS = [os.path.join(CSRC, "dsp_internal.h"), os.path.join(CSRC, "mlp_common.h"), os.path.join(ROOT, "include", "dsp_gn.h")]
+SOURCES = ["mlp_kernel.hip", "mlp_split_kernel.hip", "mlp_lp_kernel.hip", "gn_kernels.hip", "mesh_kernels.hip", "dsp_gn.hip", "pose_graph.cpp"]
+HEADERS = [os.path.join(CSRC, "dsp_internal.h"), os.path.join(CSRC, "mlp_common.h"), os.path.join(ROOT, "include", "dsp_gn.h"),
+           os.path.join(ROOT, "include", "dsp_pose_graph.h")]
 
 
 def _hipcc():
@@ -32,7 +33,8 @@ def is_stale():
 # edge interpolation): no fused multiply-add may be formed where the reference rounds twice.  The `__fmul_rn`/`__fadd_rn`
 # spellings do not prevent that on their own (they are plain `*`/`+` in clang's HIP headers), so these files are compiled with
 # contraction off; explicit fmaf() calls stay FMAs.  mlp_kernel.hip keeps the default (its MFMA / fmaf use is explicit anyway).
-EXTRA_FLAGS = {"gn_kernels.hip": ["-ffp-contract=off"], "mesh_kernels.hip": ["-ffp-contract=off"]}
+EXTRA_FLAGS = {"gn_kernels.hip": ["-ffp-contract=off"], "mesh_kernels.hip": ["-ffp-contract=off"],
+               "pose_graph.cpp": ["-ffp-contract=off"]}
 OBJ_DIR = os.path.join(LIB_DIR, "obj")
 
 

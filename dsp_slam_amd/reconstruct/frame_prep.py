@@ -130,3 +130,50 @@ def associate_masks(instances, masks_2d, bboxes_2d, k_cam, inv_k, img_w, img_h, 
             inst.occ_mask = occluded
             previous = masks_2d[best, ...]
     return instances
+
+
+def undistort_pixels(pixels, k_cam, k1, k2, iterations=5):
+    """`cv2.undistortPoints(px, K, [k1, k2, 0, 0, 0], P=K)` for a radial two-coefficient model (mono_sequence.py:102-103).
+
+    OpenCV is not a dependency here; this is its published fixed-point iteration (modules/calib3d undistortPoints: normalise
+    with K, five iterations of  x <- x0 / (1 + k1 r^2 + k2 r^4), re-project with P), in double precision with a float32
+    result like OpenCV gives for float32 input.  An iterate whose inverse distortion factor turns negative falls back to the
+    normalised input point, as OpenCV does."""
+    px = np.asarray(pixels, np.float32).reshape(-1, 2).astype(np.float64)
+    k_cam = np.asarray(k_cam, np.float64)
+    fx, fy, cx, cy = k_cam[0, 0], k_cam[1, 1], k_cam[0, 2], k_cam[1, 2]
+    x0 = (px[:, 0] - cx) / fx
+    y0 = (px[:, 1] - cy) / fy
+    x, y = x0.copy(), y0.copy()
+    live = np.ones(x.shape[0], bool)
+    for _ in range(iterations):
+        r2 = x * x + y * y
+        icdist = 1.0 / (1.0 + (k2 * r2 + k1) * r2)
+        bad = live & (icdist < 0)
+        x[bad], y[bad] = x0[bad], y0[bad]
+        live &= ~bad
+        x = np.where(live, x0 * icdist, x)
+        y = np.where(live, y0 * icdist, y)
+    return np.stack([x * fx + cx, y * fy + cy], axis=-1).astype(np.float32)
+
+
+def mono_instance(masks_2d, bboxes_2d, k_cam, inv_k, k1, k2, downsample_ratio, img_w, img_h, max_background=200):
+    """Monocular sequences (Freiburg cars / Redwood chairs): only the detection with the largest mask is used; its box gives the
+    off-mask background pixels (at most `max_background`, evenly spaced ranks), which are undistorted and turned into rays
+    (mono_sequence.py:75-112).  Returns None when there is no 2D detection; surface points come later from the SLAM map
+    (src/LocalMapping_util.cc:330-398), so the instance carries only `bbox`, `mask` and `background_rays`."""
+    if masks_2d.shape[0] == 0:
+        return None
+    biggest = int(np.argmax(masks_2d.sum(axis=-1).sum(axis=-1)))
+    mask = masks_2d[biggest, ...].astype(np.float32) * 255.
+    bbox = bboxes_2d[biggest, ...]
+    background = pixels_sampler(bbox, mask.astype(bool), downsample_ratio, img_w, img_h)
+    if background.shape[0] > max_background:
+        keep = np.linspace(0, background.shape[0] - 1, max_background).astype(np.int32)
+        background = background[keep, :]
+    undist = undistort_pixels(background, k_cam, k1, k2)
+    inst = ForceKeyErrorDict()
+    inst.bbox = bbox
+    inst.mask = mask
+    inst.background_rays = get_rays(undist, inv_k).astype(np.float32)
+    return inst

@@ -1,4 +1,4 @@
-"""CPU-only: the C-ABI library loads and exports every symbol include/dsp_gn.h declares; the product path fails
+"""CPU-only: the C-ABI library loads and exports every symbol include/*.h declares; the product path fails
 loudly (no fallback) when there is no GPU."""
 import os
 import re
@@ -11,7 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def header_symbols():
-    src = open(os.path.join(ROOT, "include", "dsp_gn.h")).read()
+    inc = os.path.join(ROOT, "include")
+    src = "".join(open(os.path.join(inc, f)).read() for f in sorted(os.listdir(inc)) if f.endswith(".h"))
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(dsp_[a-z0-9_]+)\s*\(", src)))
 
@@ -19,7 +20,7 @@ def header_symbols():
 def test_library_exports_every_declared_symbol():
     lib = L.load()
     names = header_symbols()
-    assert len(names) >= 16
+    assert len(names) >= 16 and "dsp_pg_edge_error" in names and "dsp_create" in names
     for n in names:
         assert hasattr(lib, n), "libdspgn.so does not export %s" % n
     bound = {n for n, _, _ in L.SYMBOLS}

@@ -7,7 +7,11 @@ Runs only where /root/reference exists (the build container).  The reference cla
 installed here and is not touched by the methods used, and `np.bool` (removed from numpy >= 1.24, used at
 kitti_sequence.py:181) is aliased to `bool` for the duration of the run.
 
-    python tools/make_golden_frame.py        ->  tests/golden/golden_frame_prep.npz
+    python tools/make_golden_frame.py        ->  tests/golden/golden_frame_prep.npz, golden_mono_prep.npz
+
+The monocular frame class (reconstruct/mono_sequence.py:51-112) is recorded the same way.  Its one OpenCV call,
+`cv2.undistortPoints`, cannot run here: the stub records the pixels it was handed and returns them unchanged, which is what
+OpenCV returns for the zero distortion the golden is recorded with (to float32 rounding of integer pixel coordinates: exactly).
 """
 import os
 import sys
@@ -61,6 +65,37 @@ def synthetic_frame(seed=0):
                 masks=np.stack(masks), bboxes=np.array(bboxes, dtype=np.float32))
 
 
+def record_mono(fr):
+    """reconstruct/mono_sequence.py Frame.get_detections on the same masks (Redwood-like: the largest mask wins)."""
+    import cv2
+    from reconstruct.mono_sequence import Frame
+    handed = {}
+
+    def undistort_stub(pts, k, dist, P=None):
+        handed["pts"], handed["dist"] = np.array(pts), np.array(dist)
+        return np.array(pts)
+
+    cv2.undistortPoints = undistort_stub
+    if not hasattr(np, "bool8"):
+        np.bool8 = np.bool_                              # mono_sequence.py:96 predates numpy 2
+    frame = Frame.__new__(Frame)
+    frame.configs = types.SimpleNamespace(downsample_ratio=4.0)
+    frame.K, frame.invK, frame.k1, frame.k2 = fr["k_cam"], fr["inv_k"], 0.0, 0.0
+    frame.online = True
+    frame.object_class = "chairs"
+    frame.img_rgb = np.zeros((fr["img_h"], fr["img_w"], 3), np.uint8)
+    frame.img_bgr = frame.img_rgb
+    frame.img_h, frame.img_w = fr["img_h"], fr["img_w"]
+    frame.instances = []
+    frame.detector_2d = types.SimpleNamespace(make_prediction=lambda img, object_class=None: {"pred_masks": fr["masks"], "pred_boxes": fr["bboxes"]})
+    frame.get_detections()
+    inst = frame.instances[0]
+    out = dict(masks=fr["masks"], bboxes=fr["bboxes"], k_cam=fr["k_cam"], inv_k=fr["inv_k"], img_wh=np.array([fr["img_w"], fr["img_h"]]),
+               bbox=inst.bbox, mask=inst.mask, background_rays=inst.background_rays, handed_pixels=handed["pts"], handed_dist=handed["dist"])
+    np.savez_compressed(os.path.join(GOLD, "golden_mono_prep.npz"), **out)
+    print("mono: background rays", inst.background_rays.shape, inst.background_rays.dtype, "pixels handed to cv2", handed["pts"].shape, handed["pts"].dtype)
+
+
 def main():
     from oracle import ref_shim
     sys.modules.setdefault("cv2", types.ModuleType("cv2"))
@@ -106,6 +141,7 @@ def main():
         os.makedirs(GOLD, exist_ok=True)
         np.savez_compressed(os.path.join(GOLD, "golden_frame_prep.npz"), **out)
         print("instances:", len(frame.instances), [(int(i.num_surface_points), None if i.rays is None else i.rays.shape) for i in frame.instances])
+        record_mono(fr)
     finally:
         if not had_bool:
             del np.bool
