@@ -254,6 +254,7 @@ def main():
             "avg_launch_ms": round(fwd_ms / max(n_fwd, 1), 4),
             "alg_flop_per_launch": round(fwd_pts * F_FWD / max(n_fwd, 1)),
             "fwd_points_evaluated_over_insphere": round(fwd_pts / max(insphere_pts, 1.0), 4),
+            "render_rows_kept_over_fwd_points": round(ren_rows / max(fwd_pts, 1.0), 4),
             "jac_kernel_tflops": round(jac_tflops, 2),
             "jac_kernel_frac": round(jac_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
             "jac_avg_launch_ms": round(jac_ms / max(n_jac, 1), 4),

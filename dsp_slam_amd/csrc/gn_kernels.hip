@@ -434,45 +434,80 @@ __global__ __launch_bounds__(256) void k_build_tiles(const ObjConst* oc, const O
                                                      int* n_tiles, double* counters, int add_v, int tile_pts, int cnt_slot) {
     // mode 0: forward tiles over the V in-sphere samples; mode 1: jacobian tiles over M surface + K render points;
     // mode 2: forward tiles over the P samples selected for the current front-to-back pass (indexed through plist)
-    __shared__ int base;
-    if (threadIdx.x == 0) base = 0;
-    __syncthreads();
-    double cnt = 0.0, vtot = 0.0, rows = 0.0;
-    int n_surface_tiles = 0;
+    // One thread per object (rounds of 256): tile counts, a block-wide exclusive scan for the list offsets, then the four waves
+    // fill the objects' tile entries side by side -- same lists, in the same order, as walking the objects one by one.
+    __shared__ int s_n[256], s_off[256], s_base[256], s_part[8];
+    __shared__ double s_red[3][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double cnt = 0.0, vtot = 0.0, rows = 0.0;       // per-thread partial sums of integers: exact in any order
+    int base = 0, n_surface_tiles = 0;
     // mode 1 lists every object's surface tiles first and the render tiles after them, so that the two jacobian launches
     // (forward+backward / backward-only) each take one contiguous range
     const bool jac = mode == 1 || mode == 3;   // mode 3: the band samples (P) stand in for the kept render rows (K): speculative band rows
     for (int phase = 0; phase < (jac ? 2 : 1); ++phase) {
-        for (int b = 0; b < n_obj; ++b) {
-            const ObjConst c = oc[b];
-            const ObjState& s = st[b];
-            const bool good = s.status == DSP_STATUS_GOOD;
-            const int b0 = base;
-            __syncthreads();
-            if (!jac) {
-                const int n = good ? (mode == 0 ? s.V : s.P) : 0;
-                const int nt = (n + tile_pts - 1) / tile_pts;
-                for (int i = threadIdx.x; i < nt; i += 256)
-                    tiles[b0 + i] = make_int4(c.samp_off + i * tile_pts, min(tile_pts, n - i * tile_pts), b, 0);
-                if (threadIdx.x == 0) { base = b0 + nt; cnt += n; if (good) vtot += s.V; }
-            } else {
-                const int n = good ? (phase == 0 ? c.n_pts : (mode == 3 ? s.P : s.K)) : 0;
-                const int off = phase == 0 ? c.jsdf_off : c.jren_off;
-                const int nt = (n + tile_pts - 1) / tile_pts;
-                for (int i = threadIdx.x; i < nt; i += 256)
-                    tiles[b0 + i] = make_int4(off + i * tile_pts, min(tile_pts, n - i * tile_pts), b, 0);
-                if (threadIdx.x == 0) { base = b0 + nt; if (phase == 0) cnt += n; else rows += n; }
+        for (int b0 = 0; b0 < n_obj; b0 += 256) {
+            const int b = b0 + tid;
+            int n = 0, off = 0;
+            if (b < n_obj) {
+                const ObjConst c = oc[b];
+                const ObjState& s = st[b];
+                const bool good = s.status == DSP_STATUS_GOOD;
+                if (!jac) {
+                    n = good ? (mode == 0 ? s.V : s.P) : 0;
+                    off = c.samp_off;
+                    cnt += n;
+                    if (good) vtot += s.V;
+                } else {
+                    n = good ? (phase == 0 ? c.n_pts : (mode == 3 ? s.P : s.K)) : 0;
+                    off = phase == 0 ? c.jsdf_off : c.jren_off;
+                    if (phase == 0) cnt += n; else rows += n;
+                }
             }
+            const int nt = (n + tile_pts - 1) / tile_pts;
+            int incl = nt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int v = __shfl_up(incl, d);
+                if (lane >= d) incl += v;
+            }
+            __syncthreads();                        // the previous round's fill has finished reading s_*
+            if (lane == 63) s_part[wave] = incl;
             __syncthreads();
+            int before = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int pw = s_part[w];
+                if (w < wave) before += pw;
+                total += pw;
+            }
+            s_n[tid] = n;
+            s_off[tid] = off;
+            s_base[tid] = base + before + incl - nt;
+            __syncthreads();
+            const int in_round = min(256, n_obj - b0);
+            for (int j = wave; j < in_round; j += 4) {
+                const int nj = s_n[j], oj = s_off[j], bj = s_base[j];
+                const int ntj = (nj + tile_pts - 1) / tile_pts;
+                for (int i = lane; i < ntj; i += 64) tiles[bj + i] = make_int4(oj + i * tile_pts, min(tile_pts, nj - i * tile_pts), b0 + j, 0);
+            }
+            base += total;
         }
         if (phase == 0) n_surface_tiles = base;
     }
-    if (threadIdx.x == 0) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        cnt += __shfl_xor(cnt, d);
+        vtot += __shfl_xor(vtot, d);
+        rows += __shfl_xor(rows, d);
+    }
+    if (lane == 0) { s_red[0][wave] = cnt; s_red[1][wave] = vtot; s_red[2][wave] = rows; }
+    __syncthreads();
+    if (tid == 0) {
         n_tiles[0] = base;
         if (jac) n_tiles[1] = n_surface_tiles;
-        counters[jac ? 1 : cnt_slot] += cnt;
-        if (add_v) counters[2] += vtot;
-        if (jac) counters[3] += rows;
+        counters[jac ? 1 : cnt_slot] += s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+        if (add_v) counters[2] += s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+        if (jac) counters[3] += s_red[2][0] + s_red[2][1] + s_red[2][2] + s_red[2][3];
     }
 }
 

@@ -124,6 +124,20 @@ def test_cfg4_sharded_equals_unsharded(eng):
     assert max(b - a for a, b in shards) - min(b - a for a, b in shards) <= 3     # balanced
 
 
+def test_more_than_256_objects_in_one_batch(eng):
+    """300 tiny ragged objects in ONE batch (the tile-list builder walks objects 256 at a time; per-object kernels use the grid's
+    y / x dimension) == the same objects in three batches of 100, bit for bit, including two objects that fail."""
+    prm = E.gn_params(num_iterations=3)
+    objs = [synth.make_object(3000 + i, n_surface=40 + 5 * (i % 7), n_background=12 + (i % 5)) for i in range(300)]
+    objs[17] = dict(objs[17], rays=np.zeros((0, 3), np.float32), depth=np.zeros((0,), np.float32))    # no samples: status 1
+    objs[290] = dict(objs[290], pts=np.zeros((0, 3), np.float32))                                      # no surface points: status 2
+    full = _run(eng, prm, objs)
+    parts = [_run(eng, prm, objs[a:a + 100]) for a in (0, 100, 200)]
+    for k in range(4):
+        assert np.array_equal(np.concatenate([p[k] for p in parts], 0), full[k])
+    assert full[3][17] == 1 and full[3][290] == 2 and (full[3] == 0).sum() >= 290
+
+
 def test_cfg5_redwood_4000_points_two_decoders_mixed_batch(eng, oracle_decoder):
     """Redwood hyper-parameters, 4000 surface points + render term, a second decoder resident on the same GPU, and a
     mixed batch: car objects on the car handle, 'chair' objects on the chair handle; each handle's results equal the
