@@ -19,11 +19,32 @@ constexpr int GLDS_PER_CHUNK = 4;             // per wave: 4 x 1 KiB pieces of a
 #define MFMA16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x4f32((A), (B), (C), 0, 0, 0)
 
 // LDS-DMA of one wave's quarter (4 KiB) of a weight chunk: four global_load_lds_dwordx4, each 64 lanes x 16 B from a
-// per-lane global address to LDS at M0 + lane*16.  The instruction's immediate offset moves BOTH the global source and
-// the LDS destination (measured: tools/probes/hw_probe.hip), so one address VGPR pair and one M0 value serve all four.
+// global address to LDS at M0 + lane*16.  The instruction's immediate offset moves BOTH the global source and
+// the LDS destination (measured: tools/probes/hw_probe.hip), so one address and one M0 value serve all four.
 // Invisible to hipcc's s_waitcnt bookkeeping by design: completion is counted by hand (vmcnt) below.
-__device__ __forceinline__ void glds_quarter(const void* gsrc, unsigned lds_dst) {
+// Addressing: the stream position is wave-uniform, so it travels as an SGPR pair (saddr) and the per-lane part is the constant
+// 32-bit offset lane*16 -- half the address registers the 64-bit per-lane form sends through the address unit per instruction
+// (GLDS_SADDR 0 rebuilds that form for comparison).
+#ifndef GLDS_SADDR
+#define GLDS_SADDR 1
+#endif
+__device__ __forceinline__ void glds_quarter(const char* gsrc_uniform, unsigned lane_off, unsigned lds_dst) {
     unsigned keep;
+#if GLDS_SADDR
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(lane_off), "s"(gsrc_uniform), "s"(lds_dst)
+        : "memory");
+#else
+    const char* gsrc = gsrc_uniform + lane_off;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
         "s_mov_b32 m0, %2\n\t"
@@ -36,12 +57,25 @@ __device__ __forceinline__ void glds_quarter(const void* gsrc, unsigned lds_dst)
         : "=&s"(keep)
         : "v"(gsrc), "s"(lds_dst)
         : "memory");
+#endif
 }
 
 // One 1 KiB piece of the quarter: PIECE selects the immediate offset (moves source and destination alike).
 template <int PIECE>
-__device__ __forceinline__ void glds_piece(const void* gsrc, unsigned lds_dst) {
+__device__ __forceinline__ void glds_piece(const char* gsrc_uniform, unsigned lane_off, unsigned lds_dst) {
     unsigned keep;
+#if GLDS_SADDR
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:%4\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(lane_off), "s"(gsrc_uniform), "s"(lds_dst), "n"(PIECE * 1024)
+        : "memory");
+#else
+    const char* gsrc = gsrc_uniform + lane_off;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
         "s_mov_b32 m0, %2\n\t"
@@ -51,6 +85,7 @@ __device__ __forceinline__ void glds_piece(const void* gsrc, unsigned lds_dst) {
         : "=&s"(keep)
         : "v"(gsrc), "s"(lds_dst), "n"(PIECE * 1024)
         : "memory");
+#endif
 }
 
 __device__ __forceinline__ unsigned lds_addr(const void* p) {

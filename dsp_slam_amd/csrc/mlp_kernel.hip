@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
 
     // ---- weight stream state (all wave-uniform) ---------------------------------------------------
     int issue_pos = 0, issue_slot = 0, rd_slot = 0;
-    const char* wbase = reinterpret_cast<const char*>(a.wstream) + wave * 4096 + lane * 16;
+    const char* wbase = reinterpret_cast<const char*>(a.wstream) + wave * 4096;   // wave-uniform; the lane part is lane_off
+    const unsigned lane_off = lane * 16;
     const int total_chunks = a.total_chunks;
     // A chunk refill is four LDS-DMA instructions per wave.  Each costs ~30-60 issue cycles (64 lane addresses through
     // the address unit), so in the main loop they are spread over four k-steps, one behind an MFMA each, instead of
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
         idst = ring0 + issue_slot * CHUNK_BYTES + wave * 4096;
     };
     auto issue = [&]() {
-        glds_quarter(isrc, idst);
+        glds_quarter(isrc, lane_off, idst);
         issue_next();
     };
 #pragma unroll
@@ -259,10 +260,10 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
                                 acc[4 * og + 0] = MFMA16(av.x, b, (c == 0 && s == 0) ? bias4[0] : acc[4 * og + 0]);
 #if !defined(ABL_NOISSUE)
                                 // refill of the slot freed by the barrier above: one DMA piece per k-step, behind an MFMA
-                                if (s == KSTEPS_PER_CHUNK / 2 + 0) glds_piece<0>(isrc, idst);
-                                if (s == KSTEPS_PER_CHUNK / 2 + 1) glds_piece<1>(isrc, idst);
-                                if (s == KSTEPS_PER_CHUNK / 2 + 2) glds_piece<2>(isrc, idst);
-                                if (s == KSTEPS_PER_CHUNK / 2 + 3) { glds_piece<3>(isrc, idst); issue_next(); }
+                                if (s == KSTEPS_PER_CHUNK / 2 + 0) glds_piece<0>(isrc, lane_off, idst);
+                                if (s == KSTEPS_PER_CHUNK / 2 + 1) glds_piece<1>(isrc, lane_off, idst);
+                                if (s == KSTEPS_PER_CHUNK / 2 + 2) glds_piece<2>(isrc, lane_off, idst);
+                                if (s == KSTEPS_PER_CHUNK / 2 + 3) { glds_piece<3>(isrc, lane_off, idst); issue_next(); }
 #endif
                                 acc[4 * og + 1] = MFMA16(av.y, b, (c == 0 && s == 0) ? bias4[1] : acc[4 * og + 1]);
                                 acc[4 * og + 2] = MFMA16(av.z, b, (c == 0 && s == 0) ? bias4[2] : acc[4 * og + 2]);

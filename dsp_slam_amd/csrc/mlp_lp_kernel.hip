@@ -65,7 +65,8 @@ __device__ __forceinline__ float lp_round(float x) {
 
 struct LpRing {            // weight-stream state, all wave-uniform
     int issue_pos, issue_slot, rd_slot, total_chunks;
-    const char* wbase;     // this lane's source address inside chunk 0
+    const char* wbase;     // this wave's source address inside chunk 0
+    unsigned lane_off;     // lane * 16: the per-lane part of every source address
     const char* isrc;      // ... inside the chunk being issued
     unsigned ring0, idst;  // LDS byte addresses: ring start + this wave's quarter; destination of the chunk being issued
     char* ring_ptr;
@@ -176,10 +177,10 @@ __device__ __forceinline__ void lp_pass(const LpPass pd, u32x4 (&in)[32], u32x4 
 #endif
 #if !defined(LP_ABL_NOISSUE)
                 // refill of the slot freed by the barrier above: one DMA piece per k-step, behind an MFMA
-                if (sl == LP_KSTEPS_PER_CHUNK / 2 + 0) glds_piece<0>(rg.isrc, rg.idst);
-                if (sl == LP_KSTEPS_PER_CHUNK / 2 + 1) glds_piece<1>(rg.isrc, rg.idst);
-                if (sl == LP_KSTEPS_PER_CHUNK / 2 + 2) glds_piece<2>(rg.isrc, rg.idst);
-                if (sl == LP_KSTEPS_PER_CHUNK / 2 + 3) { glds_piece<3>(rg.isrc, rg.idst); lp_issue_next(rg); }
+                if (sl == LP_KSTEPS_PER_CHUNK / 2 + 0) glds_piece<0>(rg.isrc, rg.lane_off, rg.idst);
+                if (sl == LP_KSTEPS_PER_CHUNK / 2 + 1) glds_piece<1>(rg.isrc, rg.lane_off, rg.idst);
+                if (sl == LP_KSTEPS_PER_CHUNK / 2 + 2) glds_piece<2>(rg.isrc, rg.lane_off, rg.idst);
+                if (sl == LP_KSTEPS_PER_CHUNK / 2 + 3) { glds_piece<3>(rg.isrc, rg.lane_off, rg.idst); lp_issue_next(rg); }
 #endif
 #if !defined(LP_ABL_NOMFMA)
                 acc[par][1] = lp_mfma<BF>(a1, b, s == 0 ? bias[1] : acc[par][1]);
@@ -227,14 +228,15 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpArgs a) {
 
     LpRing rg;
     rg.issue_pos = 0; rg.issue_slot = 0; rg.rd_slot = 0; rg.total_chunks = a.total_chunks;
-    rg.wbase = reinterpret_cast<const char*>(a.wstream) + wave * 4096 + lane * 16;
+    rg.wbase = reinterpret_cast<const char*>(a.wstream) + wave * 4096;   // wave-uniform; the lane part is rg.lane_off
+    rg.lane_off = lane * 16;
     rg.isrc = rg.wbase;
     rg.ring0 = lds_addr(ring_ptr) + wave * 4096;
     rg.idst = rg.ring0;
     rg.ring_ptr = ring_ptr;
 #pragma unroll
     for (int i = 0; i < LP_NBUF - 1; ++i) {
-        glds_quarter(rg.isrc, rg.idst);
+        glds_quarter(rg.isrc, rg.lane_off, rg.idst);
         lp_issue_next(rg);
     }
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(GLDS_PER_CHUNK * (LP_NBUF - 2)) : "memory");

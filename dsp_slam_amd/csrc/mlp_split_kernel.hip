@@ -53,7 +53,8 @@ __global__ __launch_bounds__(256, 1) void mlp_split_kernel(const MlpArgs a) {
 
     // ---- this wave's weight stream (wave-uniform state) -----------------------------------------------------------------
     const int total_minis = (BWD ? a.split_len[wave] : a.split_len_fwd[wave]) * (CHUNK_BYTES / MINI_BYTES);
-    const char* wbase = reinterpret_cast<const char*>(a.wsplit) + (size_t)a.split_off[wave] * CHUNK_BYTES + lane * 16;
+    const char* wbase = reinterpret_cast<const char*>(a.wsplit) + (size_t)a.split_off[wave] * CHUNK_BYTES;   // wave-uniform
+    const unsigned lane_off = lane * 16;
     int issue_pos = 0, issue_slot = 0, rd_slot = 0;
     const char* isrc = wbase;
     unsigned idst = ring0;
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256, 1) void mlp_split_kernel(const MlpArgs a) {
         idst = ring0 + issue_slot * MINI_BYTES;
     };
 #pragma unroll
-    for (int i = 0; i < SNB - 1; ++i) { glds_quarter(isrc, idst); issue_next(); }
+    for (int i = 0; i < SNB - 1; ++i) { glds_quarter(isrc, lane_off, idst); issue_next(); }
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (SNB - 2)) : "memory");     // mini-chunk 0 has landed
     f32x4 abuf[4];
     abuf[0] = *reinterpret_cast<const f32x4*>(ring_ptr + lane * 16);
@@ -210,10 +211,10 @@ __global__ __launch_bounds__(256, 1) void mlp_split_kernel(const MlpArgs a) {
                                 const float b = sin_[16 * c + s];
                                 acc[4 * ol + 0] = MFMA16(av.x, b, (c == 0 && s == 0) ? bias4[0] : acc[4 * ol + 0]);
                                 // refill of the slot behind the read pointer: one DMA piece per k-step, behind an MFMA
-                                if (m == 0) glds_piece<0>(isrc, idst);
-                                if (m == 1) glds_piece<1>(isrc, idst);
-                                if (m == 2) glds_piece<2>(isrc, idst);
-                                if (m == 3) { glds_piece<3>(isrc, idst); issue_next(); }
+                                if (m == 0) glds_piece<0>(isrc, lane_off, idst);
+                                if (m == 1) glds_piece<1>(isrc, lane_off, idst);
+                                if (m == 2) glds_piece<2>(isrc, lane_off, idst);
+                                if (m == 3) { glds_piece<3>(isrc, lane_off, idst); issue_next(); }
                                 acc[4 * ol + 1] = MFMA16(av.y, b, (c == 0 && s == 0) ? bias4[1] : acc[4 * ol + 1]);
                                 acc[4 * ol + 2] = MFMA16(av.z, b, (c == 0 && s == 0) ? bias4[2] : acc[4 * ol + 2]);
                                 acc[4 * ol + 3] = MFMA16(av.w, b, (c == 0 && s == 0) ? bias4[3] : acc[4 * ol + 3]);
