@@ -294,6 +294,7 @@ bool pack_decoder_lp_host(PackedLp* out, const dsp_decoder_desc* d, bool bf) {
     const int hidden = d->n_layers - 1, lat = d->latent_in;
     constexpr int NCH = 4, NOG = 2 * NCH;
     if (hidden < 2 || hidden > LP_MAX_PASSES || lat < 2 || lat >= hidden) return false;
+    if (hidden & 1) return false;      // the kernel's last-layer body reads slab X: an even number of passes (DeepSDF's 8)
     const int in_dim = d->code_len + 3, width = d->out_dims[0];            // narrower nets are embedded with zero rows / columns
     if (width < 16 || width > WIDTH) return false;
     for (int k = 0; k < d->n_layers; ++k) {

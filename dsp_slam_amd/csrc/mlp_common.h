@@ -14,6 +14,12 @@ constexpr int CODEBIAS_BYTES = 2 * WIDTH * 4;              // per-object code co
 constexpr int MASK_SLOTS = 8;
 constexpr int MASK_BYTES = MASK_SLOTS * 8 * 256 * 2;       // [slot][og][tid] u16 = 32 KiB
 constexpr int PREFETCH = 2;                   // A operands are read this many k-steps ahead of their MFMAs (<= 3 with 4 buffers)
+// A operands are read from LDS in groups of PAIR_READS k-steps, one s_waitcnt per group, instead of one read + one wait per k-step:
+// every instruction between two MFMAs costs matrix-pipe time even in the MFMA's shadow (measured: 1 read + 1 wait per k-step 0.885 of
+// peak, groups of 2: 0.903, groups of 4: 0.898; 0 rebuilds the per-k-step form)
+#ifndef PAIR_READS
+#define PAIR_READS 2
+#endif
 constexpr int GLDS_PER_CHUNK = 4;             // per wave: 4 x 1 KiB pieces of a 16 KiB chunk
 
 #define MFMA16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x4f32((A), (B), (C), 0, 0, 0)

@@ -84,11 +84,18 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
     for (int i = 0; i < NBUF - 1; ++i) issue();
     // chunk 0 visible to every wave; from here on the barrier for chunk q+1 sits in the middle of chunk q
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(GLDS_PER_CHUNK * (NBUF - 2)) : "memory");
+#if PAIR_READS
+    f32x4 abuf[2 * PAIR_READS];
+#else
     f32x4 abuf[4];   // A operands run PREFETCH k-steps ahead of the MFMAs, across chunk / group / pass seams
                      // (4 slots, not 3: 16 k-steps per chunk must be a multiple of the rotation length)
+#endif
     abuf[0] = *reinterpret_cast<const f32x4*>(ring_ptr + lane * 16);
     abuf[1] = *reinterpret_cast<const f32x4*>(ring_ptr + lane * 16 + 1024);
     if (PREFETCH > 2) abuf[2] = *reinterpret_cast<const f32x4*>(ring_ptr + lane * 16 + 2048);
+#if PAIR_READS
+    if (PAIR_READS > 2) { abuf[2] = *reinterpret_cast<const f32x4*>(ring_ptr + lane * 16 + 2048); abuf[3] = *reinterpret_cast<const f32x4*>(ring_ptr + lane * 16 + 3072); }
+#endif
 
     float sin_[128];   // input slab of the current pass:  sin_[4t+r] = row 16t + 4g + r of point pl
     f32x4 acc[32];     // output slab being produced: the MFMA accumulators of all 32 row tiles
@@ -249,13 +256,34 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
                                     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(GLDS_PER_CHUNK * (NBUF - 3)) : "memory");
 #endif
                                 }
+#if PAIR_READS
+                                // A operands in groups of RG k-steps: one wait (lgkmcnt(0): the group read RG k-steps ago) and RG reads
+                                // (k-steps s+RG .. s+2RG-1) every RG-th k-step -- 1 + 1/RG non-MFMA instructions per k-step instead of 2
+                                constexpr int RG = PAIR_READS;
+                                if ((s % RG) == 0) {
+                                    __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0), vmcnt / expcnt untouched
+                                    __builtin_amdgcn_sched_barrier(0);      // keep it ahead of the k-step's first MFMA
+#pragma unroll
+                                    for (int q = 0; q < RG; ++q) {
+                                        const int sp = s + RG + q;
+                                        abuf[sp % (2 * RG)] = (sp < KSTEPS_PER_CHUNK)
+                                                           ? *reinterpret_cast<const f32x4*>(cb + sp * 1024)
+                                                           : *reinterpret_cast<const f32x4*>(nb + (sp - KSTEPS_PER_CHUNK) * 1024);
+                                    }
+                                }
+#else
                                 const int sp = s + PREFETCH;
 #if !defined(ABL_NOLDS)
                                 abuf[sp % 4] = (sp < KSTEPS_PER_CHUNK)
                                                    ? *reinterpret_cast<const f32x4*>(cb + sp * 1024)
                                                    : *reinterpret_cast<const f32x4*>(nb + (sp - KSTEPS_PER_CHUNK) * 1024);
 #endif
+#endif
+#if PAIR_READS
+                                const f32x4 av = abuf[s % (2 * PAIR_READS)];
+#else
                                 const f32x4 av = abuf[s % 4];
+#endif
                                 const float b = sin_[16 * c + s];
                                 acc[4 * og + 0] = MFMA16(av.x, b, (c == 0 && s == 0) ? bias4[0] : acc[4 * og + 0]);
 #if !defined(ABL_NOISSUE)

@@ -55,6 +55,19 @@ __device__ __forceinline__ unsigned lp_pack(float lo, float hi) {
         return __builtin_bit_cast(unsigned, __builtin_convertvector(v, h2));
 }
 
+// relu + round + pack of two accumulators.  f16: round first, then ONE v_pk_max_f16 on the pair -- max(round(x), 0) == round(max(x, 0)),
+// rounding keeps the sign (a -0 that survives multiplies to a zero product).  bf16 has no packed max on gfx950: relu in fp32, then pack.
+template <bool BF>
+__device__ __forceinline__ unsigned lp_relu_pack(float lo, float hi) {
+    if constexpr (BF) {
+        return lp_pack<BF>(relu1(lo), relu1(hi));
+    } else {
+        unsigned r;
+        asm("v_pk_max_f16 %0, %1, 0" : "=v"(r) : "v"(lp_pack<BF>(lo, hi)));
+        return r;
+    }
+}
+
 template <bool BF>
 __device__ __forceinline__ float lp_round(float x) {
     if constexpr (BF)
@@ -95,21 +108,25 @@ __device__ __forceinline__ void lp_load_rows(const float* tab, int g, int hh, f3
 // pair q of row tile j = registers (2 q, 2 q + 1) -> k-step 2 (2 g + j) + (q >> 2), component q & 3.
 // (g, q0, q1 are compile-time constants after the callers' loops are unrolled; the loop bounds here are literal so that
 // every register index folds.)
-template <bool BF>
+template <bool BF, bool LAST>
 __device__ __forceinline__ void lp_epilogue(int g, int q0, int q1, const f32x16 (&acc)[2], const float* dp, int hh, u32x4 (&out)[32], float& part) {
     // quad qd = 4 consecutive accumulator registers of row tile j = rows 64 g + 32 j + 8 i + 4 hh + 0..3 = one float4 of the dot row
 #pragma unroll
     for (int qd = 0; qd < 8; ++qd) {
         if (qd >= q0 && qd < q1) {
             const int j = qd >> 2, i = qd & 3;
-            const f32x4 w = *reinterpret_cast<const f32x4*>(dp + 64 * g + 32 * j + 8 * i + 4 * hh);
-            const float v0 = relu1(acc[j][4 * i + 0]), v1 = relu1(acc[j][4 * i + 1]), v2 = relu1(acc[j][4 * i + 2]), v3 = relu1(acc[j][4 * i + 3]);
-            out[2 * (2 * g + j) + (i >> 1)][2 * (i & 1) + 0] = lp_pack<BF>(v0, v1);
-            out[2 * (2 * g + j) + (i >> 1)][2 * (i & 1) + 1] = lp_pack<BF>(v2, v3);
-            part = fmaf(v0, w.x, part);
-            part = fmaf(v1, w.y, part);
-            part = fmaf(v2, w.z, part);
-            part = fmaf(v3, w.w, part);
+            if (LAST) {
+                // last hidden layer: nothing reads its slab; only the final 512 -> 1 layer's dot product on the un-rounded values
+                const f32x4 w = *reinterpret_cast<const f32x4*>(dp + 64 * g + 32 * j + 8 * i + 4 * hh);
+                part = fmaf(relu1(acc[j][4 * i + 0]), w.x, part);
+                part = fmaf(relu1(acc[j][4 * i + 1]), w.y, part);
+                part = fmaf(relu1(acc[j][4 * i + 2]), w.z, part);
+                part = fmaf(relu1(acc[j][4 * i + 3]), w.w, part);
+            } else {
+                // (no dot-product FMAs here: only the last hidden layer feeds the final layer)
+                out[2 * (2 * g + j) + (i >> 1)][2 * (i & 1) + 0] = lp_relu_pack<BF>(acc[j][4 * i + 0], acc[j][4 * i + 1]);
+                out[2 * (2 * g + j) + (i >> 1)][2 * (i & 1) + 1] = lp_relu_pack<BF>(acc[j][4 * i + 2], acc[j][4 * i + 3]);
+            }
         }
     }
 }
@@ -118,7 +135,7 @@ __device__ __forceinline__ void lp_epilogue(int g, int q0, int q1, const f32x16 
 // register slabs.  A pass is 8 output groups x NCH chunks of straight-line code: everything that differs between layers is
 // data (bias / dot-row pointers, prologue selects) -- hipcc answers run-time control flow inside this body with hundreds of
 // register moves at every join.  NCH = 1 for the first layer (its K is the xyz k-steps only), LP_NCH for the others.
-template <bool BF, int NCH>
+template <bool BF, int NCH, bool LAST>
 __device__ __forceinline__ void lp_pass(const LpPass pd, u32x4 (&in)[32], u32x4 (&out)[32], f32x16 (&acc)[2][2],
                                         u32x4 (&abuf)[4][2], LpRing& rg, const u32x4 (&xb)[LP_XYZ_KSTEPS], const float* bp,
                                         const float* dp, int lane, int hh, float& part) {
@@ -164,11 +181,26 @@ __device__ __forceinline__ void lp_pass(const LpPass pd, u32x4 (&in)[32], u32x4 
                     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(GLDS_PER_CHUNK * (LP_NBUF - 3)) : "memory");
 #endif
                 }
+#if defined(LP_PAIR_READS)   // measured: no gain here (121.6 vs 121.2 ms per step) and 20 more spilled registers
+                // A fragments of two k-steps per group, one lgkmcnt wait per group (mlp_common.h: every instruction between MFMAs costs)
+                if ((sl & 1) == 0) {
+                    __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0), vmcnt / expcnt untouched
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int sp = sl + 2 + q;
+                        const char* src = (sp < LP_KSTEPS_PER_CHUNK) ? cbp + sp * LP_KSTEP_BYTES : nbp + (sp - LP_KSTEPS_PER_CHUNK) * LP_KSTEP_BYTES;
+                        abuf[sp % 4][0] = *reinterpret_cast<const u32x4*>(src);
+                        abuf[sp % 4][1] = *reinterpret_cast<const u32x4*>(src + 1024);
+                    }
+                }
+#else
                 const int sp = sl + LP_PREFETCH;
                 const char* src = (sp < LP_KSTEPS_PER_CHUNK) ? cbp + sp * LP_KSTEP_BYTES : nbp + (sp - LP_KSTEPS_PER_CHUNK) * LP_KSTEP_BYTES;
 #if !defined(LP_ABL_NOLDS)
                 abuf[sp % 4][0] = *reinterpret_cast<const u32x4*>(src);
                 abuf[sp % 4][1] = *reinterpret_cast<const u32x4*>(src + 1024);
+#endif
 #endif
                 const u32x4 a0 = abuf[sl % 4][0], a1 = abuf[sl % 4][1];
                 const u32x4 b = in[s];
@@ -189,10 +221,10 @@ __device__ __forceinline__ void lp_pass(const LpPass pd, u32x4 (&in)[32], u32x4 
 #if !defined(LP_ABL_NOEPI)
                 // epilogue of the previous group, two accumulator quads per k-step behind this group's MFMAs
                 if (g > 0) {
-                    if (s == 2) lp_epilogue<BF>(g - 1, 0, 2, acc[par ^ 1], dp, hh, out, part);
-                    if (s == 3) lp_epilogue<BF>(g - 1, 2, 4, acc[par ^ 1], dp, hh, out, part);
-                    if (s == 4) lp_epilogue<BF>(g - 1, 4, 6, acc[par ^ 1], dp, hh, out, part);
-                    if (s == 5) lp_epilogue<BF>(g - 1, 6, 8, acc[par ^ 1], dp, hh, out, part);
+                    if (s == 2) lp_epilogue<BF, LAST>(g - 1, 0, 2, acc[par ^ 1], dp, hh, out, part);
+                    if (s == 3) lp_epilogue<BF, LAST>(g - 1, 2, 4, acc[par ^ 1], dp, hh, out, part);
+                    if (s == 4) lp_epilogue<BF, LAST>(g - 1, 4, 6, acc[par ^ 1], dp, hh, out, part);
+                    if (s == 5) lp_epilogue<BF, LAST>(g - 1, 6, 8, acc[par ^ 1], dp, hh, out, part);
                 }
 #endif
                 __builtin_amdgcn_sched_barrier(0);
@@ -201,7 +233,7 @@ __device__ __forceinline__ void lp_pass(const LpPass pd, u32x4 (&in)[32], u32x4 
         }
     }
     // the last group's epilogue has no MFMAs of its own pass to hide behind
-    lp_epilogue<BF>(LP_NOG - 1, 0, 8, acc[(LP_NOG - 1) & 1], dp, hh, out, part);
+    lp_epilogue<BF, LAST>(LP_NOG - 1, 0, 8, acc[(LP_NOG - 1) & 1], dp, hh, out, part);
 }
 
 template <bool BF>
@@ -303,13 +335,17 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpArgs a) {
         float part = 0.f;
         // slabs ping-pong: the first layer reads Y (its xyz k-steps) and writes X, layer 1 reads X and writes Y, ...
         auto bias_of = [&](const LpPass& pd) { return pd.bias_row == -2 ? cb_l + WIDTH : (pd.bias_row == -3 ? cb_l : bias_l + pd.bias_row * WIDTH); };
-        auto dot_of = [&](const LpPass& pd) { return pd.last ? wl : zero_l; };
-        lp_pass<BF, 1>(a.pass[0], Y, X, acc, abuf, rg, xb, bias_of(a.pass[0]), dot_of(a.pass[0]), lane, hh, part);
-        for (int ps = 1; ps < a.n_pass; ps += 2) {
-            lp_pass<BF, LP_NCH>(a.pass[ps], X, Y, acc, abuf, rg, xb, bias_of(a.pass[ps]), dot_of(a.pass[ps]), lane, hh, part);
-            if (ps + 1 < a.n_pass)
-                lp_pass<BF, LP_NCH>(a.pass[ps + 1], Y, X, acc, abuf, rg, xb, bias_of(a.pass[ps + 1]), dot_of(a.pass[ps + 1]), lane, hh, part);
+        // Pass bodies: first layer (Y -> X), hidden layers X -> Y and Y -> X, and the LAST hidden layer, which reads X and writes no
+        // slab (only the final layer's dot product on the un-rounded accumulators).  With an odd number of passes the last layer's
+        // input lands in Y: it is moved to X first (128 register moves per tile) rather than instantiating a fifth body.
+        const int n_mid = a.n_pass - 2;      // hidden layers between the first and the last one
+        lp_pass<BF, 1, false>(a.pass[0], Y, X, acc, abuf, rg, xb, bias_of(a.pass[0]), zero_l, lane, hh, part);
+        for (int ps = 1; ps <= n_mid; ps += 2) {
+            lp_pass<BF, LP_NCH, false>(a.pass[ps], X, Y, acc, abuf, rg, xb, bias_of(a.pass[ps]), zero_l, lane, hh, part);
+            if (ps + 1 <= n_mid)
+                lp_pass<BF, LP_NCH, false>(a.pass[ps + 1], Y, X, acc, abuf, rg, xb, bias_of(a.pass[ps + 1]), zero_l, lane, hh, part);
         }
+        lp_pass<BF, LP_NCH, true>(a.pass[a.n_pass - 1], X, Y, acc, abuf, rg, xb, bias_of(a.pass[a.n_pass - 1]), wl, lane, hh, part);
         part += __shfl_xor(part, 32);
         const float y = tanhf(part + a.b_last);
         if (valid && hh == 0) a.out_sdf[a.index ? src : pidx + td.w] = y;

@@ -204,9 +204,24 @@ __global__ __launch_bounds__(256, 1) void mlp_split_kernel(const MlpArgs a) {
                                     // after it and the two pieces issued so far in this one are still in flight
                                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (SNB - 3) + 2) : "memory");
                                 }
+#if PAIR_READS == 2
+                                // A operands in pairs, one lgkmcnt wait per pair (mlp_common.h): at m == 2 the pair belongs to the next
+                                // mini-chunk, which the vmcnt wait above has just proven landed
+                                if ((s & 1) == 0) {
+                                    __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0), vmcnt / expcnt untouched
+                                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                    for (int q = 0; q < 2; ++q) {
+                                        const int sp = m + 2 + q;
+                                        abuf[(s + 2 + q) % 4] = (sp < 4) ? *reinterpret_cast<const f32x4*>(cbp + sp * 1024)
+                                                                         : *reinterpret_cast<const f32x4*>(nbp + (sp - 4) * 1024);
+                                    }
+                                }
+#else
                                 const int sp = m + PREFETCH;
                                 abuf[(s + PREFETCH) % 4] = (sp < 4) ? *reinterpret_cast<const f32x4*>(cbp + sp * 1024)
                                                                     : *reinterpret_cast<const f32x4*>(nbp + (sp - 4) * 1024);
+#endif
                                 const f32x4 av = abuf[s % 4];
                                 const float b = sin_[16 * c + s];
                                 acc[4 * ol + 0] = MFMA16(av.x, b, (c == 0 && s == 0) ? bias4[0] : acc[4 * ol + 0]);
