@@ -31,25 +31,26 @@ constexpr int GLDS_PER_CHUNK = 4;             // per wave: 4 x 1 KiB pieces of a
 // Addressing: the stream position is wave-uniform, so it travels as an SGPR pair (saddr) and the per-lane part is the constant
 // 32-bit offset lane*16 -- half the address registers the 64-bit per-lane form sends through the address unit per instruction
 // (GLDS_SADDR 0 rebuilds that form for comparison).
+// M0 is written and NOT restored: hipcc treats M0 as reserved and sets it itself right before any instruction of its own that needs
+// it; in these kernels it emits none (gfx9+ LDS instructions do not read M0), which tests/test_cabi_symbols.py checks on the built
+// code objects (every M0 reference must be one of these writes).  Two SALU instructions fewer per piece, in the MFMA stream.
 #ifndef GLDS_SADDR
 #define GLDS_SADDR 1
 #endif
 __device__ __forceinline__ void glds_quarter(const char* gsrc_uniform, unsigned lane_off, unsigned lds_dst) {
-    unsigned keep;
 #if GLDS_SADDR
     asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
+        "s_mov_b32 m0, %2\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
-        "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-        "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
-        "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
+        "global_load_lds_dwordx4 %0, %1\n\t"
+        "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+        "global_load_lds_dwordx4 %0, %1 offset:2048\n\t"
+        "global_load_lds_dwordx4 %0, %1 offset:3072"
+        :
         : "v"(lane_off), "s"(gsrc_uniform), "s"(lds_dst)
         : "memory");
 #else
+    unsigned keep;
     const char* gsrc = gsrc_uniform + lane_off;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
@@ -69,18 +70,16 @@ __device__ __forceinline__ void glds_quarter(const char* gsrc_uniform, unsigned 
 // One 1 KiB piece of the quarter: PIECE selects the immediate offset (moves source and destination alike).
 template <int PIECE>
 __device__ __forceinline__ void glds_piece(const char* gsrc_uniform, unsigned lane_off, unsigned lds_dst) {
-    unsigned keep;
 #if GLDS_SADDR
     asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
+        "s_mov_b32 m0, %2\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2 offset:%4\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
+        "global_load_lds_dwordx4 %0, %1 offset:%3"
+        :
         : "v"(lane_off), "s"(gsrc_uniform), "s"(lds_dst), "n"(PIECE * 1024)
         : "memory");
 #else
+    unsigned keep;
     const char* gsrc = gsrc_uniform + lane_off;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"

@@ -51,3 +51,36 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "dsp_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
+
+
+def test_m0_is_only_written_by_the_lds_dma_helpers(tmp_path):
+    """mlp_common.h's LDS-DMA helpers set M0 (the LDS destination) and do not restore it: valid as long as hipcc itself never relies on
+    M0 in these kernels.  Checked on the built gfx950 code objects: every instruction that mentions m0 is `s_mov_b32 m0, sN`, and each
+    is followed -- after the one hazard s_nop -- by a global_load_lds."""
+    import shutil
+    import subprocess
+    from dsp_slam_amd import build as B
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    L.load()        # builds the objects if they are stale
+    n_writes = 0
+    for src in ("mlp_kernel.hip", "mlp_lp_kernel.hip", "mlp_split_kernel.hip"):
+        obj = os.path.join(B.OBJ_DIR, src + ".o")
+        if not os.path.exists(obj):
+            pytest.skip("object files not kept on this box")
+        work = tmp_path / src
+        work.mkdir()
+        shutil.copy(obj, work / "k.o")
+        subprocess.run([objdump, "--offloading", "k.o"], cwd=work, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+        co = [f for f in os.listdir(work) if "gfx950" in f]
+        assert len(co) == 1, os.listdir(work)
+        dis = subprocess.run([objdump, "-d", co[0]], cwd=work, stdout=subprocess.PIPE, text=True, check=True).stdout.splitlines()
+        ins = [ln.split("//")[0].split() for ln in dis if "\t" in ln and not ln.rstrip().endswith(":")]
+        ins = [t for t in ins if t]
+        for i, t in enumerate(ins):
+            if any(x.rstrip(",") == "m0" for x in t):
+                assert t[0] == "s_mov_b32" and t[1].rstrip(",") == "m0", " ".join(t)
+                assert ins[i + 1][0] == "s_nop" and ins[i + 2][0] == "global_load_lds_dwordx4", " ".join(ins[i + 1] + ins[i + 2])
+                n_writes += 1
+    assert n_writes > 1000
