@@ -93,6 +93,26 @@ __device__ __forceinline__ void glds_piece(const char* gsrc_uniform, unsigned la
 #endif
 }
 
+// The four pieces of a chunk share one LDS destination base: M0 is set once (glds_set_dst, at the barrier that frees the slot) and the
+// pieces are bare loads -- 5 instructions per chunk and wave in the MFMA stream instead of 12.  M0 has to survive the k-steps in
+// between; nothing else in these kernels writes it (tests/test_cabi_symbols.py checks the code objects).
+#ifndef GLDS_M0_PER_PIECE
+#define GLDS_M0_PER_PIECE 0      // 1: every piece writes M0 itself (A/B switch)
+#endif
+__device__ __forceinline__ void glds_set_dst(unsigned lds_dst) {
+#if !GLDS_M0_PER_PIECE
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" : : "s"(lds_dst) : "memory");
+#endif
+}
+template <int PIECE>
+__device__ __forceinline__ void glds_piece_m0(const char* gsrc_uniform, unsigned lane_off, unsigned lds_dst) {
+#if GLDS_M0_PER_PIECE
+    glds_piece<PIECE>(gsrc_uniform, lane_off, lds_dst);
+#else
+    asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" : : "v"(lane_off), "s"(gsrc_uniform), "n"(PIECE * 1024) : "memory");
+#endif
+}
+
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
 }

@@ -288,10 +288,10 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
                                 acc[4 * og + 0] = MFMA16(av.x, b, (c == 0 && s == 0) ? bias4[0] : acc[4 * og + 0]);
 #if !defined(ABL_NOISSUE)
                                 // refill of the slot freed by the barrier above: one DMA piece per k-step, behind an MFMA
-                                if (s == KSTEPS_PER_CHUNK / 2 + 0) glds_piece<0>(isrc, lane_off, idst);
-                                if (s == KSTEPS_PER_CHUNK / 2 + 1) glds_piece<1>(isrc, lane_off, idst);
-                                if (s == KSTEPS_PER_CHUNK / 2 + 2) glds_piece<2>(isrc, lane_off, idst);
-                                if (s == KSTEPS_PER_CHUNK / 2 + 3) { glds_piece<3>(isrc, lane_off, idst); issue_next(); }
+                                if (s == KSTEPS_PER_CHUNK / 2 + 0) { glds_set_dst(idst); glds_piece_m0<0>(isrc, lane_off, idst); };
+                                if (s == KSTEPS_PER_CHUNK / 2 + 1) glds_piece_m0<1>(isrc, lane_off, idst);
+                                if (s == KSTEPS_PER_CHUNK / 2 + 2) glds_piece_m0<2>(isrc, lane_off, idst);
+                                if (s == KSTEPS_PER_CHUNK / 2 + 3) { glds_piece_m0<3>(isrc, lane_off, idst); issue_next(); }
 #endif
                                 acc[4 * og + 1] = MFMA16(av.y, b, (c == 0 && s == 0) ? bias4[1] : acc[4 * og + 1]);
                                 acc[4 * og + 2] = MFMA16(av.z, b, (c == 0 && s == 0) ? bias4[2] : acc[4 * og + 2]);

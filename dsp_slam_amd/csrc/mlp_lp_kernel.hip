@@ -209,10 +209,10 @@ __device__ __forceinline__ void lp_pass(const LpPass pd, u32x4 (&in)[32], u32x4 
 #endif
 #if !defined(LP_ABL_NOISSUE)
                 // refill of the slot freed by the barrier above: one DMA piece per k-step, behind an MFMA
-                if (sl == LP_KSTEPS_PER_CHUNK / 2 + 0) glds_piece<0>(rg.isrc, rg.lane_off, rg.idst);
-                if (sl == LP_KSTEPS_PER_CHUNK / 2 + 1) glds_piece<1>(rg.isrc, rg.lane_off, rg.idst);
-                if (sl == LP_KSTEPS_PER_CHUNK / 2 + 2) glds_piece<2>(rg.isrc, rg.lane_off, rg.idst);
-                if (sl == LP_KSTEPS_PER_CHUNK / 2 + 3) { glds_piece<3>(rg.isrc, rg.lane_off, rg.idst); lp_issue_next(rg); }
+                if (sl == LP_KSTEPS_PER_CHUNK / 2 + 0) { glds_set_dst(rg.idst); glds_piece_m0<0>(rg.isrc, rg.lane_off, rg.idst); };
+                if (sl == LP_KSTEPS_PER_CHUNK / 2 + 1) glds_piece_m0<1>(rg.isrc, rg.lane_off, rg.idst);
+                if (sl == LP_KSTEPS_PER_CHUNK / 2 + 2) glds_piece_m0<2>(rg.isrc, rg.lane_off, rg.idst);
+                if (sl == LP_KSTEPS_PER_CHUNK / 2 + 3) { glds_piece_m0<3>(rg.isrc, rg.lane_off, rg.idst); lp_issue_next(rg); }
 #endif
 #if !defined(LP_ABL_NOMFMA)
                 acc[par][1] = lp_mfma<BF>(a1, b, s == 0 ? bias[1] : acc[par][1]);

@@ -226,10 +226,10 @@ __global__ __launch_bounds__(256, 1) void mlp_split_kernel(const MlpArgs a) {
                                 const float b = sin_[16 * c + s];
                                 acc[4 * ol + 0] = MFMA16(av.x, b, (c == 0 && s == 0) ? bias4[0] : acc[4 * ol + 0]);
                                 // refill of the slot behind the read pointer: one DMA piece per k-step, behind an MFMA
-                                if (m == 0) glds_piece<0>(isrc, lane_off, idst);
-                                if (m == 1) glds_piece<1>(isrc, lane_off, idst);
-                                if (m == 2) glds_piece<2>(isrc, lane_off, idst);
-                                if (m == 3) { glds_piece<3>(isrc, lane_off, idst); issue_next(); }
+                                if (m == 0) { glds_set_dst(idst); glds_piece_m0<0>(isrc, lane_off, idst); };
+                                if (m == 1) glds_piece_m0<1>(isrc, lane_off, idst);
+                                if (m == 2) glds_piece_m0<2>(isrc, lane_off, idst);
+                                if (m == 3) { glds_piece_m0<3>(isrc, lane_off, idst); issue_next(); }
                                 acc[4 * ol + 1] = MFMA16(av.y, b, (c == 0 && s == 0) ? bias4[1] : acc[4 * ol + 1]);
                                 acc[4 * ol + 2] = MFMA16(av.z, b, (c == 0 && s == 0) ? bias4[2] : acc[4 * ol + 2]);
                                 acc[4 * ol + 3] = MFMA16(av.w, b, (c == 0 && s == 0) ? bias4[3] : acc[4 * ol + 3]);
