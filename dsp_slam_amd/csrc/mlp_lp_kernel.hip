@@ -336,14 +336,14 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpArgs a) {
         // slabs ping-pong: the first layer reads Y (its xyz k-steps) and writes X, layer 1 reads X and writes Y, ...
         auto bias_of = [&](const LpPass& pd) { return pd.bias_row == -2 ? cb_l + WIDTH : (pd.bias_row == -3 ? cb_l : bias_l + pd.bias_row * WIDTH); };
         // Pass bodies: first layer (Y -> X), hidden layers X -> Y and Y -> X, and the LAST hidden layer, which reads X and writes no
-        // slab (only the final layer's dot product on the un-rounded accumulators).  With an odd number of passes the last layer's
-        // input lands in Y: it is moved to X first (128 register moves per tile) rather than instantiating a fifth body.
+        // slab (only the final layer's dot product on the un-rounded accumulators).  The pass count is even (pack_decoder_lp_host
+        // refuses others: the prepass is then off), so the last layer's input is always in X and the loop has no conditional half --
+        // a join there costs ~120 spilled registers per tile.
         const int n_mid = a.n_pass - 2;      // hidden layers between the first and the last one
         lp_pass<BF, 1, false>(a.pass[0], Y, X, acc, abuf, rg, xb, bias_of(a.pass[0]), zero_l, lane, hh, part);
-        for (int ps = 1; ps <= n_mid; ps += 2) {
+        for (int ps = 1; ps < n_mid; ps += 2) {       // n_mid is even (the host refuses odd pass counts): always both halves, no join
             lp_pass<BF, LP_NCH, false>(a.pass[ps], X, Y, acc, abuf, rg, xb, bias_of(a.pass[ps]), zero_l, lane, hh, part);
-            if (ps + 1 <= n_mid)
-                lp_pass<BF, LP_NCH, false>(a.pass[ps + 1], Y, X, acc, abuf, rg, xb, bias_of(a.pass[ps + 1]), zero_l, lane, hh, part);
+            lp_pass<BF, LP_NCH, false>(a.pass[ps + 1], Y, X, acc, abuf, rg, xb, bias_of(a.pass[ps + 1]), zero_l, lane, hh, part);
         }
         lp_pass<BF, LP_NCH, true>(a.pass[a.n_pass - 1], X, Y, acc, abuf, rg, xb, bias_of(a.pass[a.n_pass - 1]), wl, lane, hh, part);
         part += __shfl_xor(part, 32);

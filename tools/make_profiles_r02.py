@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""profiles/r02_*.md and profiles/pmc_traffic.json from the outputs of tools/run_profiles_r02.sh (gpurun_out/<tag>/), with the
+derived numbers (TFLOP/s, matrix-pipe busy, clocks, bytes per point) computed here rather than by hand.
+
+    python tools/make_profiles_r02.py [gpurun_out/r02]
+"""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r02")
+DST = os.path.join(ROOT, "profiles")
+F_FWD = 3671040.0
+PEAK32, PEAK16 = 157.3, 2500.0
+
+K1 = "_ZN3dsp10mlp_kernelILi1ELb0EEEvNS_7MlpArgsE.kd"
+K2 = "_ZN3dsp10mlp_kernelILi2ELb0EEEvNS_7MlpArgsE.kd"
+K2R = "_ZN3dsp10mlp_kernelILi3ELb0EEEvNS_7MlpArgsE.kd"
+K0 = "_ZN3dsp13mlp_lp_kernelILb0EEEvNS_6LpArgsE.kd"
+
+
+def read(name):
+    return open(os.path.join(SRC, name)).read()
+
+
+def bench(name):
+    return json.loads(read(name).strip().splitlines()[-1])
+
+
+def pmc(name):
+    rows, dur = {}, {}
+    for line in read(name).splitlines():
+        m = re.match(r"\| (\S+) \| (\S+) \| (\d+) \| (\S+) \| (\S+) \|", line)
+        if m and m.group(2) != "counter":
+            rows[(m.group(1), m.group(2))] = (int(m.group(3)), float(m.group(4)))
+        m = re.match(r"duration: (\S+)\s+dispatches (\d+)\s+total ([\d.]+) ms", line)
+        if m:
+            dur[m.group(1)] = (int(m.group(2)), float(m.group(3)))
+    return rows, dur
+
+
+def stats_rows(name):
+    out = {}
+    for line in read(name).splitlines():
+        c = [x.strip() for x in line.split("|")]
+        if len(c) > 8 and c[1].startswith("_ZN3dsp") or (len(c) > 8 and c[1].startswith("__amd")):
+            out[c[1]] = dict(calls=int(c[2]), total_ms=float(c[3]), avg_us=float(c[4]), pct=float(c[7]))
+    return out
+
+
+def table_only(name):
+    return "\n".join(l for l in read(name).splitlines() if l.startswith("|") or l.startswith("duration:"))
+
+
+def main():
+    b, boff, b4, b5 = bench("bench.json"), bench("bench_prepass_off.json"), bench("bench_cfg4.json"), bench("bench_cfg5.json")
+
+    # ---- bench lines -------------------------------------------------------------------------------------------------------------
+    def row(label, d):
+        r, p = d["roofline"], d.get("prepass")
+        return "| %s | %.1f | %.1f | %.3f | %.3f | %s |" % (label, d["value"], d["ms_per_step"], r["frac"], r["jac_kernel_frac"],
+                                                         "%.0f (%.3f)" % (p["achieved"], p["frac"]) if p else "-")
+    lines = ["# Round 2 -- bench lines as printed on an MI355X (one gpurun call, `tools/run_profiles_r02.sh`; this file by `tools/make_profiles_r02.py`)",
+             "", "`python bench.py --steps 5 --warmup 1 [--config ...] [--prepass off]`  (state at the end of round 2; the lines of the first round-2 profile",
+             "run -- 110.2 objects/s, before the instruction-stream work on the decoder kernels -- are in the git history of this file)", "",
+             "| config | objects/s | ms per step | fp32 forward kernel frac of 157.3 TFLOP/s | jacobian kernels frac | prepass kernel TFLOP/s (frac of 2500) |", "|---|---|---|---|---|---|",
+             row("cfg2x64", b), row("cfg2x64, prepass off", boff), row("cfg4", b4), row("cfg5", b5), ""]
+    for title, d in (("cfg2x64 (the headline configuration), f16 prepass", b), ("cfg2x64, --prepass off (round 1 behaviour)", boff),
+                     ("cfg4: 128 objects per GPU through shard_objects", b4), ("cfg5: 4000-point objects, Redwood hyper-parameters, cars + chairs32 decoders", b5)):
+        lines += ["## " + title, "", "```json", json.dumps(d), "```", ""]
+    open(os.path.join(DST, "r02_bench_lines.md"), "w").write("\n".join(lines))
+
+    # ---- kernel stats ------------------------------------------------------------------------------------------------------------
+    st = stats_rows("kernel_stats.md")
+    r = b["roofline"]
+    by = r["ms_per_step_by_kernel"]
+    k1, k2, k2r, k0 = st[K1], st[K2], st[K2R], st[K0]
+    pts_per_launch = r["alg_flop_per_launch"] / F_FWD
+    lp = b["prepass"]
+    others = sum(v["total_ms"] for k, v in st.items() if k not in (K1, K2, K2R, K0) and "mlp_" not in k)
+    n_steps = 6.0
+    text = ["# Round 2 -- rocprofv3 kernel stats of the bench command", "",
+            "`cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --latency-runs 1`",
+            "(64 cfg2 objects per step, f16 prepass on; 6 steps incl. the warm-up + the two latency probes).  Table by `tools/rocpd_stats.py`, this file by",
+            "`tools/make_profiles_r02.py`.  The bench line of the same build, un-profiled: `profiles/r02_bench_lines.md` (%.1f objects/s, %.1f ms per step)." % (b["value"], b["ms_per_step"]),
+            "", table_only("kernel_stats.md"), "", "Reading (per step of 64 objects x 10 iterations):", "",
+            "* `mlp_kernel<1>` (fp32 forward over the samples the prepass could not classify, relu masks exported): 10 launches, **%.2f ms average**"
+            % (k1["avg_us"] / 1e3),
+            "  (HIP events inside `bench.py`, un-profiled: %.2f ms) -- %.0f k points each = %.2f TFLOP per launch = **%.1f TFLOP/s = %.3f of the 157.3 TFLOP/s fp32 MFMA peak**"
+            % (r["avg_launch_ms"], pts_per_launch / 1e3, r["alg_flop_per_launch"] / 1e12, r["alg_flop_per_launch"] / (k1["avg_us"] * 1e-6) / 1e12,
+               r["alg_flop_per_launch"] / (k1["avg_us"] * 1e-6) / 1e12 / PEAK32),
+            "  (bench: %.3f).  Round 1: 100 launches x 10.2 ms; first round-2 profile: 20.97 ms (0.860) before the instruction-stream work (DESIGN.md, K1)." % r["frac"],
+            "* `mlp_kernel<3>` (render rows, backward sweep only from those masks): 10 launches x %.2f ms; `mlp_kernel<2>` (surface points, forward + backward):"
+            % (k2r["avg_us"] / 1e3),
+            "  10 x %.2f ms (the %d calls include the latency probes); together %.3f of peak in the bench." % (k2["avg_us"] / 1e3, k2["calls"], r["jac_kernel_frac"]),
+            "* `mlp_lp_kernel<f16>` (the prepass, `v_mfma_f32_32x32x16_f16`): 100 launches x %.2f ms = %.0f ms per step, %.0f k points per launch ="
+            % (lp["avg_launch_ms"], by["prepass"], lp["alg_flop_per_launch"] / F_FWD / 1e3),
+            "  %.2f TFLOP -> **%.2f PFLOP/s = %.3f of the 2.5 PFLOP/s dense 16-bit peak** (priced separately from the fp32 fraction)."
+            % (lp["alg_flop_per_launch"] / 1e12, lp["achieved"] / 1e3, lp["frac"]),
+            "* everything else (sampling, band selection, occupancy scan, compaction, Gram, solve, tile lists): %.1f ms per step = %.1f %%."
+            % (by["other"], 100 * by["other"] / b["ms_per_step"]), ""]
+    open(os.path.join(DST, "r02_kernel_stats.md"), "w").write("\n".join(text))
+
+    # ---- PMC ---------------------------------------------------------------------------------------------------------------------
+    mf, dm = pmc("pmc_mfma.md")
+    fe, df = pmc("pmc_fetch.md")
+    wr, _ = pmc("pmc_write.md")
+    ld, _ = pmc("pmc_lds.md")
+
+    def busy(k):
+        return mf[(k, "SQ_VALU_MFMA_BUSY_CYCLES")][1] / (mf[(k, "GRBM_GUI_ACTIVE")][1] / 8 * 1024)
+
+    def clk(k):
+        return mf[(k, "GRBM_GUI_ACTIVE")][1] / 8 / (dm[k][1] * 1e-3) / 1e9
+
+    n1 = dm[K1][0]
+    # points per launch from the un-profiled bench of the same run (same workload, same seeds)
+    k1_pts = pts_per_launch * n1
+    k1_fetch = fe[(K1, "FETCH_SIZE")][1] * 1024 * 2
+    k0_pts = lp["alg_flop_per_launch"] / F_FWD * 10 * (dm[K0][0] // 100) * 10     # 100 launches per step
+    steps_in_pmc = dm[K1][0] / 10.0
+    k0_pts = lp["alg_flop_per_launch"] / F_FWD * 100 * steps_in_pmc
+    k0_fetch = fe[(K0, "FETCH_SIZE")][1] * 1024 * 2
+    wave1 = mf[(K1, "SQ_WAVE_CYCLES")][1]
+    wave0 = ld[(K0, "SQ_ACTIVE_INST_ANY")][1] + 0.0
+    txt = ["# Round 2 -- rocprofv3 PMC passes at the bench configuration", "",
+           "Four separate `--pmc` passes (no `--stats`, no tracing; one counter group per run) over",
+           "`python bench.py --steps 1 --warmup 1 --no-cpu-baseline --latency-runs 1` -- **64 objects per GPU, the bench configuration** (round 1's pass was",
+           "taken at 32).  2 steps = %d launches of the fp32 forward kernel `mlp_kernel<1>`, 200 of the prepass kernel (+ ~60 from the latency probes)." % n1,
+           "Tables by `tools/rocpd_pmc.py` (kernels matching `mlp_`), this file by `tools/make_profiles_r02.py`.", "",
+           "## FETCH_SIZE (KiB)", "", table_only("pmc_fetch.md"), "", "## WRITE_SIZE (KiB)", "", table_only("pmc_write.md"), "",
+           "## MFMA / busy counters", "", table_only("pmc_mfma.md"), "", "## LDS / wait counters", "", table_only("pmc_lds.md"), "", "## Reading", "",
+           "**`mlp_kernel<1>` -- fp32 forward decoder over the unclassified band (%d launches, %.1f ms in the counter run)**" % (n1, dm[K1][1]), "",
+           "* `SQ_INSTS_VALU_MFMA_MOPS_F32` %.4g x 512 FLOP = %.1f TFLOP issued to the matrix pipe = %.1f TFLOP/s (the bench prices the algorithmic"
+           % (mf[(K1, "SQ_INSTS_VALU_MFMA_MOPS_F32")][1], mf[(K1, "SQ_INSTS_VALU_MFMA_MOPS_F32")][1] * 512 / 1e12,
+              mf[(K1, "SQ_INSTS_VALU_MFMA_MOPS_F32")][1] * 512 / (dm[K1][1] * 1e-3) / 1e12),
+           "  3.671 MFLOP/point, %.1f TFLOP/s: layer 0 and the code columns run on the VALU / as per-object biases)." % r["achieved"],
+           "* Matrix pipe busy: `SQ_VALU_MFMA_BUSY_CYCLES` %.4g / (`GRBM_GUI_ACTIVE` %.4g / 8 XCDs x 256 CUs x 4 SIMDs) = **%.1f %%**"
+           % (mf[(K1, "SQ_VALU_MFMA_BUSY_CYCLES")][1], mf[(K1, "GRBM_GUI_ACTIVE")][1], 100 * busy(K1)),
+           "  (first round-2 profile: 84.0 %%; round 1: 80.9 %%); shader clock %.2f GHz." % clk(K1),
+           "* Fabric reads: `FETCH_SIZE` %.4g KiB x 2 (gfx950 half-count correction, MI355X_MICROARCH.md) = %.1f GB over %.2f M points ="
+           % (fe[(K1, "FETCH_SIZE")][1], k1_fetch / 1e9, k1_pts / 1e6),
+           "  **%.2f KB per decoded point, %.2f GB per launch, %.0f GB/s = %.1f %% of the 8 TB/s HBM peak**: the 6.8 MB fp32 weight stream does not fit an"
+           % (k1_fetch / k1_pts / 1e3, k1_fetch / n1 / 1e9, k1_fetch / (df[K1][1] * 1e-3) / 1e9, 100 * k1_fetch / (df[K1][1] * 1e-3) / 8e12),
+           "  XCD's 4 MiB L2 and is re-fetched from the Infinity Cache by ~3 % of the 106 KB every tile streams from L2.  Algorithmic: 20 B per point.  Not a bound.",
+           "* `WRITE_SIZE` %.4g KiB: sdf values and the exported relu masks of band samples (512 B each)." % wr[(K1, "WRITE_SIZE")][1],
+           "* LDS: %d bank conflicts; `SQ_WAIT_INST_LDS` %.2f %% of wave cycles."
+           % (ld[(K1, "SQ_LDS_BANK_CONFLICT")][1], 100 * ld[(K1, "SQ_WAIT_INST_LDS")][1] / wave1), "",
+           "**`mlp_lp_kernel<f16>` -- the prepass (%d launches, %.1f ms)**" % (dm[K0][0], dm[K0][1]), "",
+           "* `SQ_INSTS_VALU_MFMA_MOPS_F16` %.4g x 512 FLOP = %.0f TFLOP = **%.2f PFLOP/s issued** (algorithmic %.2f in the bench: the 445-row layer is padded to"
+           % (mf[(K0, "SQ_INSTS_VALU_MFMA_MOPS_F16")][1], mf[(K0, "SQ_INSTS_VALU_MFMA_MOPS_F16")][1] * 512 / 1e12,
+              mf[(K0, "SQ_INSTS_VALU_MFMA_MOPS_F16")][1] * 512 / (dm[K0][1] * 1e-3) / 1e15, lp["achieved"] / 1e3),
+           "  512 rows and the xyz k-steps carry split-precision products).",
+           "* Matrix pipe busy: **%.1f %%** (first round-2 profile: 53.8 %%); shader clock averaged over launches of very different length %.2f GHz (the long"
+           % (100 * busy(K0), clk(K0)),
+           "  ones run at 1.7-1.8 GHz: `tools/gpu_prepass_probe.py`) -- the chip clocks down under 16-bit MFMA load, so part of every cycle saved comes back",
+           "  as clock, not throughput (MI355X_MICROARCH.md, DVFS).",
+           "* Fabric reads: %.4g KiB x 2 = %.1f GB over %.1f M points = **%.0f B per point**: the 3.6 MB f16 weight stream fits the 4 MiB L2."
+           % (fe[(K0, "FETCH_SIZE")][1], k0_fetch / 1e9, k0_pts / 1e6, k0_fetch / k0_pts),
+           "  `WRITE_SIZE` %.4g KiB = %.0f B per point (4 B of sdf per point + write-allocate granularity; the kernel has no scratch any more)."
+           % (wr[(K0, "WRITE_SIZE")][1], wr[(K0, "WRITE_SIZE")][1] * 1024 / k0_pts),
+           "* LDS: %d bank conflicts (A fragments are read as lane-linear `ds_read_b128`)." % ld[(K0, "SQ_LDS_BANK_CONFLICT")][1], "",
+           "**Jacobian kernels**: `mlp_kernel<3>` (backward only) %.1f %% matrix-pipe busy, `mlp_kernel<2>` (forward + backward) %.1f %%." % (100 * busy(K2R), 100 * busy(K2)), ""]
+    open(os.path.join(DST, "r02_pmc.md"), "w").write("\n".join(txt))
+    traffic = {
+        "fwd_fetch_bytes_per_point": round(k1_fetch / k1_pts, 1),
+        "lp_fetch_bytes_per_point": round(k0_fetch / k0_pts, 1),
+        "source": "profiles/r02_pmc.md",
+        "note": ("rocprofv3 --pmc FETCH_SIZE pass at the bench configuration, 64 objects per GPU (profiles/r02_pmc.md): %.2f KB of L2-fabric reads per point "
+                 "the fp32 forward kernel decodes (x2 gfx950 correction applied) = Infinity-Cache-served re-reads of the 6.8 MB fp32 weight stream, %.0f GB/s = "
+                 "%.1f %% of the HBM peak; algorithmic 20 B/point.  Prepass kernel: %.0f B/point (its 3.6 MB f16 stream fits the 4 MiB L2)"
+                 % (k1_fetch / k1_pts / 1e3, k1_fetch / (df[K1][1] * 1e-3) / 1e9, 100 * k1_fetch / (df[K1][1] * 1e-3) / 8e12, k0_fetch / k0_pts)),
+    }
+    json.dump(traffic, open(os.path.join(DST, "pmc_traffic.json"), "w"), indent=1)
+
+    # ---- latency -----------------------------------------------------------------------------------------------------------------
+    ls = stats_rows("latency_kernel_stats.md")
+    runs = [v["calls"] for k, v in ls.items() if "k_solve" in k][0] // 10
+    per_run = sum(v["total_ms"] for v in ls.values()) / runs
+    tail = [l for l in read("latency_run.txt").splitlines() if not l.startswith("W2") and not l.startswith("E2") and l.strip()][-4:]
+    split = [v for k, v in ls.items() if "mlp_split_kernel" in k][0]
+    lpk = [v for k, v in ls.items() if "mlp_lp_kernel" in k][0]
+    solve = [v for k, v in ls.items() if "k_solve" in k][0]
+    book = sum(v["total_ms"] for k, v in ls.items() if not any(x in k for x in ("mlp_", "k_solve", "__amd", "k_init_state", "k_finalize", "k_code_bias")))
+    ltxt = ["# Round 2 -- single-detection latency path, rocprofv3 kernel stats", "",
+            "`cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -- python tools/gpu_small_loop.py <M> <Bg> <reps>`: a resident batch of ONE object",
+            "re-run `reps`+1 times (10 joint Gauss-Newton iterations each); tables by `tools/rocpd_stats.py`, this file by `tools/make_profiles_r02.py`.",
+            "Automatic kernel choice (no setters).", "",
+            "## Real-KITTI-size detection: 250 surface points + 200 background rays (450 rays x 50 samples), %d runs -- %.2f ms of kernels per run under the profiler"
+            % (runs, per_run),
+            "## (%.2f ms p50 in `bench.py`, un-profiled); first round-2 profile 6.25 / 5.77 ms, round 1: 11.06 ms" % b["latency_kitti_size_ms_p50"], "",
+            table_only("latency_kernel_stats.md"), "", "```"] + tail + ["```", "",
+            "Per iteration (%d iterations): ONE prepass launch over every in-sphere sample (%.0f us), ONE latency-form jacobian launch over surface points +"
+            % (solve["calls"], lpk["avg_us"]),
+            "band samples (%.0f us: the band samples get forward + backward speculatively, their sdf is scattered back for the occupancy scan; 283 us before"
+            % split["avg_us"],
+            "the SGPR-base LDS-DMA and the paired A-operand reads), `k_solve` %.0f us (it also computes the next iteration's code bias), and the small"
+            % solve["avg_us"],
+            "bookkeeping launches (`k_front_fused`, `k_band_fused`, `k_render_scan`, `k_render_tail_fused`, `k_gram`, 2 x `k_build_tiles`, `k_gram_reduce`):",
+            "**%.0f us per iteration = %.2f ms per call** (round 1: ~300 launches, 2.4 ms).  11 launches per iteration instead of 27."
+            % (1e3 * book / solve["calls"], book / runs), "",
+            "## cfg2-size object: 2000 surface points + 500 background rays (2500 rays) -- %.2f ms p50 in `bench.py`" % b["latency_ms_p50"], "",
+            table_only("latency_cfg2_kernel_stats.md"), ""]
+    open(os.path.join(DST, "r02_latency_kernel_stats.md"), "w").write("\n".join(ltxt))
+    print("wrote profiles/r02_{bench_lines,kernel_stats,pmc,latency_kernel_stats}.md and pmc_traffic.json")
+    print("K1 busy %.1f%% clk %.2f; K2 %.1f%%; K2r %.1f%%; K0 busy %.1f%% clk %.2f" % (100 * busy(K1), clk(K1), 100 * busy(K2), 100 * busy(K2R), 100 * busy(K0), clk(K0)))
+    print("K1 fetch B/pt %.0f  K0 fetch B/pt %.0f write B/pt %.0f" % (k1_fetch / k1_pts, k0_fetch / k0_pts, wr[(K0, "WRITE_SIZE")][1] * 1024 / k0_pts))
+
+
+if __name__ == "__main__":
+    main()
