@@ -142,3 +142,45 @@ def test_narrower_decoders_run_embedded(code_len, width):
     assert np.abs(s2 - y).max() < 5e-6 and np.abs(g2 - g).max() < 1e-5 * max(1.0, np.abs(g).max())
     assert np.abs(e.decode_sdf_prepass(code, pts, L.PREPASS_F16) - y).max() < 2e-3
     e.close()
+
+
+@pytest.mark.parametrize("depth,lat", [(6, 3), (7, 4)])
+def test_other_depths_run(depth, lat):
+    """6 hidden layers: the prepass is on and exact; 7 (an odd number of passes): the prepass kernel does not take the decoder, the library
+    says so (DSP_E_STATE / DspError) and the optimiser runs with every sample on the fp32 kernel -- same results as prepass off."""
+    from dsp_slam_amd import synth
+    sp = copy.deepcopy(fixtures.SPECS)
+    sp["NetworkSpecs"].update(dims=[512] * depth, latent_in=[lat], norm_layers=list(range(depth)), dropout=list(range(depth)))
+    dec = O.fold_decoder(fixtures.random_state_dict(5 + depth, sp), sp)
+    e = E.Engine(dec.layers, dec.latent_in, dec.code_len, device=0)
+    rng = np.random.default_rng(depth)
+    code = (rng.normal(size=64) * 0.3).astype(np.float32)
+    pts = rng.uniform(-1, 1, size=(3000, 3)).astype(np.float32)
+    y, g = O.get_batch_sdf_jacobian(dec, code, pts)
+    assert np.abs(e.decode_sdf(code, pts) - y).max() < 5e-6
+    s2, g2 = e.sdf_jacobian(code, pts)
+    assert np.abs(s2 - y).max() < 5e-6 and np.abs(g2 - g).max() < 1e-5 * max(1.0, np.abs(g).max())
+    prm = E.gn_params(num_iterations=3)
+    objs = synth.make_batch(2, first_seed=1200 + depth, n_surface=300, n_background=80)
+    args = ([o["t_cam_obj_init"] for o in objs], [o["pts"] for o in objs], [o["rays"] for o in objs], [o["depth"] for o in objs])
+    out = {}
+    for mode in (L.PREPASS_OFF, -1):
+        b = e.batch(prm, *args)
+        b.set_prepass(mode)
+        b.run()
+        out[mode] = (b.results(), b.stats())
+        b.close()
+    for k in range(4):
+        assert np.array_equal(out[-1][0][k], out[L.PREPASS_OFF][0][k])
+    if depth % 2 == 0:
+        assert out[-1][1]["prepass_mode"] == L.PREPASS_F16 and out[-1][1]["n_prepass_points"] > 0
+        assert np.abs(e.decode_sdf_prepass(code, pts, L.PREPASS_F16) - y).max() < 2e-3
+        err, delta = e.prepass_calibration(L.PREPASS_F16)
+        assert 0 < err and delta >= 5 * err * 0.999
+    else:
+        assert out[-1][1]["prepass_mode"] == L.PREPASS_OFF and out[-1][1]["n_prepass_points"] == 0
+        with pytest.raises(L.DspError):
+            e.decode_sdf_prepass(code, pts, L.PREPASS_F16)
+        with pytest.raises(L.DspError):
+            e.prepass_calibration(L.PREPASS_F16)
+    e.close()

@@ -124,3 +124,33 @@ def test_other_code_lengths_and_widths(code_len, width):
     got = LE.run_wave(pk, lp, code, pts32, L.PREPASS_F16)
     assert np.abs(got - LE.reference_forward(dec, code, pts32, L.PREPASS_F16)).max() < 5e-5
     assert np.abs(got - O.decode_sdf(dec, code, pts32)).max() < 2e-3
+
+
+@pytest.mark.parametrize("depth,lat", [(6, 3), (7, 4), (4, 2)])
+def test_other_depths(depth, lat):
+    """Decoder.__init__ is generic over the number of hidden layers too (deep_sdf_decoder.py:27-47): 4, 6 and 7 hidden layers through
+    the packed fp32 stream (forward + input gradient) and, for an even number of passes, the prepass stream; with an odd number the
+    prepass is refused (its last-layer body reads slab X) and the library runs every sample through the fp32 kernel."""
+    import copy
+    import lp_emulator as LE
+    from dsp_slam_amd import _lib as L
+    sp = copy.deepcopy(fixtures.SPECS)
+    sp["NetworkSpecs"].update(dims=[512] * depth, latent_in=[lat], norm_layers=list(range(depth)), dropout=list(range(depth)))
+    dec = O.fold_decoder(fixtures.random_state_dict(5 + depth, sp), sp)
+    assert len(dec.layers) == depth + 1
+    pk = KE.debug_pack(dec.layers, dec.latent_in, dec.code_len)
+    rng = np.random.default_rng(depth)
+    code = (rng.normal(size=64) * 0.3).astype(np.float32)
+    pts = rng.uniform(-0.8, 0.8, size=(16, 3)).astype(np.float32)
+    sdf, grad = KE.run_wave(pk, code, pts, bwd=True)
+    y, g = O.get_batch_sdf_jacobian(dec, code, pts)
+    assert np.abs(sdf - y).max() < 2e-6 and np.abs(grad - g).max() < 1e-5 * max(1.0, np.abs(g).max())
+    if depth % 2 == 0:
+        lp = LE.debug_pack(pk["_holder"], L.PREPASS_F16)
+        assert lp["passes"].shape[0] == depth
+        pts32 = rng.uniform(-0.8, 0.8, size=(32, 3)).astype(np.float32)
+        got = LE.run_wave(pk, lp, code, pts32, L.PREPASS_F16)
+        assert np.abs(got - LE.reference_forward(dec, code, pts32, L.PREPASS_F16)).max() < 5e-5
+    else:
+        with pytest.raises(L.DspError):
+            LE.debug_pack(pk["_holder"], L.PREPASS_F16)
