@@ -30,15 +30,11 @@ constexpr int GLDS_PER_CHUNK = 4;             // per wave: 4 x 1 KiB pieces of a
 // Invisible to hipcc's s_waitcnt bookkeeping by design: completion is counted by hand (vmcnt) below.
 // Addressing: the stream position is wave-uniform, so it travels as an SGPR pair (saddr) and the per-lane part is the constant
 // 32-bit offset lane*16 -- half the address registers the 64-bit per-lane form sends through the address unit per instruction
-// (GLDS_SADDR 0 rebuilds that form for comparison).
+// (measured: K1 0.862 -> 0.883 of peak against the per-lane form).
 // M0 is written and NOT restored: hipcc treats M0 as reserved and sets it itself right before any instruction of its own that needs
 // it; in these kernels it emits none (gfx9+ LDS instructions do not read M0), which tests/test_cabi_symbols.py checks on the built
 // code objects (every M0 reference must be one of these writes).  Two SALU instructions fewer per piece, in the MFMA stream.
-#ifndef GLDS_SADDR
-#define GLDS_SADDR 1
-#endif
 __device__ __forceinline__ void glds_quarter(const char* gsrc_uniform, unsigned lane_off, unsigned lds_dst) {
-#if GLDS_SADDR
     asm volatile(
         "s_mov_b32 m0, %2\n\t"
         "s_nop 0\n\t"
@@ -49,28 +45,11 @@ __device__ __forceinline__ void glds_quarter(const char* gsrc_uniform, unsigned 
         :
         : "v"(lane_off), "s"(gsrc_uniform), "s"(lds_dst)
         : "memory");
-#else
-    unsigned keep;
-    const char* gsrc = gsrc_uniform + lane_off;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
-        "global_load_lds_dwordx4 %1, off offset:1024\n\t"
-        "global_load_lds_dwordx4 %1, off offset:2048\n\t"
-        "global_load_lds_dwordx4 %1, off offset:3072\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(gsrc), "s"(lds_dst)
-        : "memory");
-#endif
 }
 
 // One 1 KiB piece of the quarter: PIECE selects the immediate offset (moves source and destination alike).
 template <int PIECE>
 __device__ __forceinline__ void glds_piece(const char* gsrc_uniform, unsigned lane_off, unsigned lds_dst) {
-#if GLDS_SADDR
     asm volatile(
         "s_mov_b32 m0, %2\n\t"
         "s_nop 0\n\t"
@@ -78,19 +57,6 @@ __device__ __forceinline__ void glds_piece(const char* gsrc_uniform, unsigned la
         :
         : "v"(lane_off), "s"(gsrc_uniform), "s"(lds_dst), "n"(PIECE * 1024)
         : "memory");
-#else
-    unsigned keep;
-    const char* gsrc = gsrc_uniform + lane_off;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off offset:%3\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(gsrc), "s"(lds_dst), "n"(PIECE * 1024)
-        : "memory");
-#endif
 }
 
 // The four pieces of a chunk share one LDS destination base: M0 is set once (glds_set_dst, at the barrier that frees the slot) and the
