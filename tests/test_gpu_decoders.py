@@ -14,7 +14,7 @@ import pytest
 from conftest import golden, parity_log
 from oracle import dsp_oracle as O
 from dsp_slam_amd import fixtures, synth, engine as E, _lib as L
-from test_gpu_parity import compare_linearisation, one_iteration_oracle, rel, LAST_LINEARISATION
+from test_gpu_parity import compare_linearisation, end_to_end_differences, one_iteration_oracle, rel, LAST_LINEARISATION
 
 pytestmark = pytest.mark.gpu
 
@@ -89,12 +89,14 @@ def test_chairs32_reconstruction_vs_reference_golden(eng32, chairs32_decoder):
                rel_b=[p["rel_b"] for p in per], oracle_jitter_rel_H=[p["oracle_jitter_rel_H"] for p in per], K=[p["K"] for p in per])
     assert strict >= 3
     # chained result against the reference's, inside the reference's own round-off spread
-    sens_t = max(np.abs(a - g["t_cam_obj"]).max() for a in [g["ulp_t_cam_obj"]] + list(g["ulps_t_cam_obj"]))
-    sens_c = max(np.abs(a - g["code"]).max() for a in [g["ulp_code"]] + list(g["ulps_code"]))
-    d_t, d_c = np.abs(t[0] - g["t_cam_obj"]).max(), np.abs(code[0] - g["code"]).max()
-    parity_log(kind="end_to_end", case="golden_recon_chairs32.npz", n_draws=9, rot=float("nan"), rot_sens=float("nan"), scale=float("nan"),
-               scale_sens=float("nan"), trans=float("nan"), trans_sens=float("nan"), code=float(d_c), code_sens=float(sens_c),
-               loss=float(abs(loss[0] - float(g["loss"])) / abs(float(g["loss"]))), t_abs=float(d_t), t_abs_sens=float(sens_t))
+    m, sens, n_draws = end_to_end_differences(g, t[0], code[0])
+    rec = dict(m)
+    rec.update({k + "_sens": v for k, v in sens.items()})
+    parity_log(kind="end_to_end", case="golden_recon_chairs32.npz", n_draws=n_draws,
+               loss=float(abs(loss[0] - float(g["loss"])) / abs(float(g["loss"]))), **rec)
+    d_t, sens_t, d_c, sens_c = m["t_abs"], sens["t_abs"], m["code"], sens["code"]
+    for q in ("rot", "scale", "trans"):
+        assert m[q] <= max(1e-4, 3 * sens[q]), (q, m[q], sens[q])
     assert d_t <= max(1e-4 * np.abs(g["t_cam_obj"]).max(), 3 * sens_t) and d_c <= max(1e-4, 3 * sens_c)
 
 

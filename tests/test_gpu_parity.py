@@ -250,6 +250,28 @@ def test_reconstruct_redwood_each_iteration(eng, oracle_decoder):
     _check_iterations(oracle_decoder, obj, traces, oprm, cfg["optimizer"]["joint_optim"]["k4"], "redwood")
 
 
+def end_to_end_differences(g, t44, code):
+    """Chained result against a golden: rotation (R / scale: absolute), scale (relative), translation (relative to |t|), code
+    (absolute), whole matrix (absolute) -- and the same quantities for the reference's own spread (its 1 + 8 re-runs with every input
+    element moved to an adjacent float32, golden fields ulp_* / ulps_*).  Returns (measured, spread, number of draws)."""
+    def split(m44):
+        m44 = np.asarray(m44, np.float64)
+        sc = np.cbrt(np.linalg.det(m44[:3, :3]))
+        return m44[:3, :3] / sc, sc, m44[:3, 3]
+
+    r_g, s_g, p_g = split(g["t_cam_obj"])
+
+    def diffs(m44, cd):
+        r_a, s_a, p_a = split(m44)
+        return dict(rot=float(np.abs(r_a - r_g).max()), scale=float(abs(s_a - s_g) / s_g),
+                    trans=float(np.linalg.norm(p_a - p_g) / np.linalg.norm(p_g)), code=float(np.abs(cd - g["code"]).max()),
+                    t_abs=float(np.abs(np.asarray(m44, np.float64) - g["t_cam_obj"]).max()))
+
+    m = diffs(t44, code)
+    draws = [diffs(g["ulp_t_cam_obj"], g["ulp_code"])] + [diffs(a, c) for a, c in zip(g["ulps_t_cam_obj"], g["ulps_code"])]
+    return m, {k: max(d[k] for d in draws) for k in m}, len(draws)
+
+
 @pytest.mark.parametrize("name", ["golden_recon_small.npz", "golden_recon_cfg1.npz", "golden_recon_redwood.npz", "golden_recon_freiburg.npz",
                                   "golden_recon_cfg2.npz"])
 def test_reconstruct_end_to_end(eng, name):
@@ -274,25 +296,11 @@ def test_reconstruct_end_to_end(eng, name):
     t, code, loss, status = eng.reconstruct_batch(prm, [g["in_t_cam_obj_init"]], [g["in_pts"]], [g["in_rays"]], [g["in_depth"]], code0)
     assert status[0] == 0 and bool(g["is_good"])
 
-    def split(t44):
-        t44 = np.asarray(t44, np.float64)
-        sc = np.cbrt(np.linalg.det(t44[:3, :3]))
-        return t44[:3, :3] / sc, sc, t44[:3, 3]
-
-    def diffs(t44, cd):
-        r_a, s_a, p_a = split(t44)
-        return dict(rot=float(np.abs(r_a - r_g).max()), scale=float(abs(s_a - s_g) / s_g),
-                    trans=float(np.linalg.norm(p_a - p_g) / np.linalg.norm(p_g)), code=float(np.abs(cd - g["code"]).max()),
-                    t_abs=float(np.abs(np.asarray(t44, np.float64) - g["t_cam_obj"]).max()))
-
-    r_g, s_g, p_g = split(g["t_cam_obj"])
-    m = diffs(t[0], code[0])
-    draws = [diffs(g["ulp_t_cam_obj"], g["ulp_code"])] + [diffs(a, c) for a, c in zip(g["ulps_t_cam_obj"], g["ulps_code"])]
-    sens = {k: max(d[k] for d in draws) for k in m}
+    m, sens, n_draws = end_to_end_differences(g, t[0], code[0])
     rec = {k: m[k] for k in m}
     rec.update({k + "_sens": sens[k] for k in sens})
     rec["loss"] = float(abs(loss[0] - float(g["loss"])) / max(abs(float(g["loss"])), 1e-12))
-    parity_log(kind="end_to_end", case=name, n_draws=len(draws), **rec)
+    parity_log(kind="end_to_end", case=name, n_draws=n_draws, **rec)
     print("%s: rot %.2e (reference spread under 1-ulp inputs %.2e) scale %.2e (%.2e) trans %.2e (%.2e) code %.2e (%.2e)" % (
         name, m["rot"], sens["rot"], m["scale"], sens["scale"], m["trans"], sens["trans"], m["code"], sens["code"]))
     for q in ("rot", "scale", "trans", "code"):
