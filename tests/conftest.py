@@ -52,15 +52,19 @@ def oracle_decoder(cars_state_dict):
     return dsp_oracle.fold_decoder(cars_state_dict, fixtures.SPECS)
 
 
+_SESSION_T0 = __import__("time").time()
+
+
 def parity_log(**record):
-    """GPU parity tests append what they MEASURED (not only that it passed) to gpurun_out/parity.jsonl; tools/make_parity_report.py
-    turns the file into profiles/parity_rNN.md after a GPU run."""
+    """GPU parity tests append what they MEASURED (not only that it passed) to gpurun_out/parity/<session start>.jsonl -- one file per
+    pytest session, so that partial re-runs on another box add to the earlier records instead of replacing them when gpurun merges the
+    directory back; tools/make_parity_report.py turns the directory into profiles/parity_rNN.md (latest record per case)."""
     import json
     import time
-    out = os.path.join(ROOT, "gpurun_out")
+    out = os.path.join(ROOT, "gpurun_out", "parity")
     os.makedirs(out, exist_ok=True)
     record["_t"] = time.time()
-    with open(os.path.join(out, "parity.jsonl"), "a") as f:
+    with open(os.path.join(out, "%d_%d.jsonl" % (int(_SESSION_T0), os.getpid())), "a") as f:
         f.write(json.dumps({k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in record.items()}) + "\n")
 
 

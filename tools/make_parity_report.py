@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""gpurun_out/parity.jsonl (written by the -m gpu parity tests, tests/conftest.py:parity_log) -> a markdown report:
-   python tools/make_parity_report.py [gpurun_out/parity.jsonl] > profiles/parity_rNN.md"""
+"""gpurun_out/parity/*.jsonl (one file per pytest session, written by the -m gpu parity tests: tests/conftest.py:parity_log) -> a
+markdown report with the latest record per case:
+   python tools/make_parity_report.py [gpurun_out/parity | file.jsonl] > profiles/parity_rNN.md"""
 import json
 import os
 import sys
@@ -9,8 +10,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def main():
-    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "parity.jsonl")
-    recs = [json.loads(l) for l in open(path) if l.strip()]
+    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "parity")
+    files = sorted(os.path.join(path, f) for f in os.listdir(path) if f.endswith(".jsonl")) if os.path.isdir(path) else [path]
+    legacy = os.path.join(ROOT, "gpurun_out", "parity.jsonl")      # single-file form of earlier runs
+    if os.path.isdir(path) and os.path.exists(legacy):
+        files = [legacy] + files
+    recs = sorted((json.loads(l) for fn in files for l in open(fn) if l.strip()), key=lambda r: r.get("_t", 0.0))
     # keep the latest record per (kind, case)
     last = {}
     for r in recs:
