@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Fit a decoder fixture to the analytic rounded-box family of dsp_slam_amd/synth.py -- long enough that its SDF error is far
+below the render term's cut-off threshold (th = 0.01), so that the reference's Gauss-Newton iteration on it CONVERGES instead
+of wandering (a fixture fitted to RMS ~ th manufactures threshold flips and makes the reference's
+own chained result round-off-chaotic).
+
+Self-contained torch (no reference import): runs on the GPU box,
+    gpurun -- python tools/fit_decoder_gpu.py --name cars --steps 30000 --out gpurun_out/decoder_cars.npz
+and, slowly, on CPU.  The module below has the reference Decoder's parameter names and shapes (deep_sdf/deep_sdf_decoder.py:
+linK.weight_g / weight_v / bias under weight-norm, lin8.weight / bias plain), so the saved state dict loads into the reference's
+class unchanged (checked in the build container by tools/make_golden.py, which runs the reference on it).
+
+weight_v is stored as bf16 bit patterns (dsp_slam_amd/fixtures.py).  To make that lossless the second half of the fit runs with
+weight_v rounded to bf16 in the forward pass (straight-through gradient to the fp32 master copy): the network that is saved IS
+the network that was optimised.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from dsp_slam_amd import synth  # noqa: E402
+from dsp_slam_amd.fixtures import SPECS, save_decoder_npz  # noqa: E402
+
+
+def bf16_round(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+class WNLinear(nn.Module):
+    """y = (g * v / |v|_row) x + bias : the parametrisation nn.utils.weight_norm gives nn.Linear (same state-dict keys)."""
+
+    def __init__(self, n_in, n_out):
+        super().__init__()
+        lin = nn.Linear(n_in, n_out)
+        self.weight_v = nn.Parameter(lin.weight.detach().clone())
+        self.weight_g = nn.Parameter(lin.weight.detach().norm(dim=1, keepdim=True))
+        self.bias = nn.Parameter(lin.bias.detach().clone())
+        self.quantised = False
+
+    def forward(self, x):
+        v = self.weight_v
+        if self.quantised:
+            v = v + (bf16_round(v) - v).detach()
+        w = self.weight_g * v / v.norm(dim=1, keepdim=True)
+        return torch.nn.functional.linear(x, w, self.bias)
+
+
+class PlainLinear(nn.Module):
+    def __init__(self, n_in, n_out):
+        super().__init__()
+        lin = nn.Linear(n_in, n_out)
+        self.weight = nn.Parameter(lin.weight.detach().clone())
+        self.bias = nn.Parameter(lin.bias.detach().clone())
+        self.quantised = False
+
+    def forward(self, x):
+        w = self.weight
+        if self.quantised:
+            w = w + (bf16_round(w) - w).detach()
+        return torch.nn.functional.linear(x, w, self.bias)
+
+
+class FixtureDecoder(nn.Module):
+    """The upstream DeepSDF example architecture in eval mode (dropout inert, no layer norm under weight norm)."""
+
+    def __init__(self, code_len, specs):
+        super().__init__()
+        d0 = code_len + 3
+        dims = [d0] + list(specs["dims"]) + [1]
+        self.latent_in = list(specs["latent_in"])
+        self.n = len(dims)
+        for layer in range(self.n - 1):
+            out_dim = dims[layer + 1] - d0 if (layer + 1) in self.latent_in else dims[layer + 1]
+            wn = specs["weight_norm"] and layer in specs["norm_layers"]
+            setattr(self, "lin%d" % layer, (WNLinear if wn else PlainLinear)(dims[layer], out_dim))
+
+    def set_quantised(self, q):
+        for layer in range(self.n - 1):
+            getattr(self, "lin%d" % layer).quantised = q
+
+    def forward(self, inp):
+        x = inp
+        for layer in range(self.n - 1):
+            if layer in self.latent_in:
+                x = torch.cat([x, inp], 1)
+            x = getattr(self, "lin%d" % layer)(x)
+            if layer < self.n - 2:
+                x = torch.relu(x)
+        return torch.tanh(x)
+
+
+def rounded_box_sdf_t(p, code3, half, rnd):
+    b = half * (1.0 + 0.2 * torch.tanh(code3))
+    q = p.abs() - b
+    outside = torch.clamp(q, min=0.0).norm(dim=-1)
+    inside = torch.clamp(q.max(dim=-1).values, max=0.0)
+    return outside + inside - rnd
+
+
+def sample_batch(gen, n, code_len, half, dev, code_sigma):
+    f64 = torch.float64
+    codes = torch.zeros(n, code_len, dtype=f64, device=dev)
+    codes[:, :3] = torch.randn(n, 3, generator=gen, dtype=f64, device=dev) * code_sigma
+    codes[:, 3:] = torch.randn(n, code_len - 3, generator=gen, dtype=f64, device=dev) * 0.05
+    n_uni = n // 3
+    u = torch.randn(n_uni, 3, generator=gen, dtype=f64, device=dev)
+    u = u / u.norm(dim=-1, keepdim=True)
+    p_uni = u * (1.05 * torch.rand(n_uni, 1, generator=gen, dtype=f64, device=dev) ** (1.0 / 3.0))
+    m = n - n_uni
+    d = torch.randn(m, 3, generator=gen, dtype=f64, device=dev)
+    d = d / d.norm(dim=-1, keepdim=True)
+    lo = torch.zeros(m, dtype=f64, device=dev)
+    hi = torch.full((m,), 1.6, dtype=f64, device=dev)
+    c3 = codes[n_uni:, :3]
+    for _ in range(16):      # 1.6 / 2^16: the labels below are exact for wherever the points end up
+        mid = 0.5 * (lo + hi)
+        inside = rounded_box_sdf_t(d * mid[:, None], c3, half, synth.BOX_ROUND) < 0
+        lo = torch.where(inside, mid, lo)
+        hi = torch.where(inside, hi, mid)
+    p_surf = d * (0.5 * (lo + hi))[:, None]
+    # three bands around the surface: the render term lives inside |sdf| < 0.01, the GN steps cross a few centimetres
+    r = torch.rand(m, 1, generator=gen, dtype=f64, device=dev)
+    sig = torch.where(r < 0.4, 0.005, torch.where(r < 0.8, 0.02, 0.08))
+    p_near = p_surf + torch.randn(m, 3, generator=gen, dtype=f64, device=dev) * sig
+    p = torch.cat([p_uni, p_near], 0)
+    sdf = rounded_box_sdf_t(p, codes[:, :3], half, synth.BOX_ROUND)
+    x = torch.cat([codes, p], -1).to(torch.float32)
+    return x, sdf.to(torch.float32)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--name", default="cars")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--steps", type=int, default=30000)
+    ap.add_argument("--batch", type=int, default=32768)
+    ap.add_argument("--code-len", type=int, default=SPECS["CodeLength"])
+    ap.add_argument("--half", type=float, nargs=3, default=None)
+    ap.add_argument("--code-sigma", type=float, default=0.45)
+    ap.add_argument("--lr", type=float, default=1e-3)
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+
+    dev = torch.device("cuda:0" if torch.cuda.is_available() else "cpu")
+    torch.manual_seed(args.seed)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(args.seed)
+    half = torch.tensor(synth.BOX_HALF if args.half is None else np.asarray(args.half, np.float64), dtype=torch.float64, device=dev)
+    dec = FixtureDecoder(args.code_len, SPECS["NetworkSpecs"]).to(dev)
+    opt = torch.optim.Adam(dec.parameters(), lr=args.lr)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=args.steps, eta_min=2e-6)
+    clamp = 0.1
+    t0 = time.time()
+    for step in range(args.steps):
+        if step == args.steps // 2:
+            dec.set_quantised(True)
+        x, y = sample_batch(gen, args.batch, args.code_len, half, dev, args.code_sigma)
+        pred = dec(x).squeeze(-1)
+        loss = (torch.clamp(pred, -clamp, clamp) - torch.clamp(y, -clamp, clamp)).abs().mean()
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        sched.step()
+        if step % 500 == 0 or step == args.steps - 1:
+            print("step %d  clamped-L1 %.6f  lr %.2e (%.0fs)" % (step, loss.item(), sched.get_last_lr()[0], time.time() - t0), flush=True)
+
+    # the saved network: weight_v / lin8.weight exactly bf16-representable
+    dec.set_quantised(False)
+    with torch.no_grad():
+        for layer in range(dec.n - 1):
+            lin = getattr(dec, "lin%d" % layer)
+            if hasattr(lin, "weight_v"):
+                lin.weight_v.copy_(bf16_round(lin.weight_v))
+            else:
+                lin.weight.copy_(bf16_round(lin.weight))
+        # held-out check of what was saved
+        gen.manual_seed(args.seed + 12345)
+        x, y = sample_batch(gen, 200000, args.code_len, half, dev, 0.3)
+        pred = dec(x).squeeze(-1)
+        err = (pred - y)
+        near = y.abs() < 0.02
+        print("held-out: rms %.3e  near-surface(|sdf|<0.02) rms %.3e  max %.3e" % (
+            err.pow(2).mean().sqrt().item(), err[near].pow(2).mean().sqrt().item(), err[near].abs().max().item()))
+    xg = x[near][:20000].clone().requires_grad_(True)
+    dec(xg).sum().backward()
+    gn = xg.grad[:, -3:].norm(dim=-1)
+    print("|grad_xyz| near the surface: mean %.4f  min %.4f  max %.4f ; |grad_code[3:]| max %.3e" % (
+        gn.mean().item(), gn.min().item(), gn.max().item(), xg.grad[:, 3:-3].abs().max().item()))
+
+    sd = {k: v.detach().cpu() for k, v in dec.state_dict().items()}
+    out = args.out or os.path.join(ROOT, "tests", "golden", "decoder_%s.npz" % args.name)
+    os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
+    save_decoder_npz(sd, out, code_len=args.code_len)
+    print("wrote", out, "%.2f MB" % (os.path.getsize(out) / 1e6))
+
+
+if __name__ == "__main__":
+    main()
