@@ -23,9 +23,13 @@ The JSON line also carries
                 of those launches;
   prepass       the low-precision classification kernel in front of it (mlp_lp_kernel, f16 MFMA), priced SEPARATELY
                 against the dense 16-bit MFMA peak -- never mixed into the fp32 fraction;
-  cpu_baseline  the reference itself (kind "reference") when DSP_REFERENCE_ROOT points at a DSP-SLAM checkout, else the
-                CPU oracle (kind "port": oracle/dsp_oracle.py, torch-CPU sgemm), timed on this box's host cores on ONE
-                cfg2 object (rank 0, N=1 only) -- a reported baseline, not a target.
+  prepass_off   the same batch timed in the same run with the prepass OFF (every in-sphere sample through the fp32 kernel, as the
+                reference evaluates it): objects/s, ms_per_step and the fp32 kernel's roofline fraction of THAT run;
+  cpu_baseline  the reference itself (kind "reference") when DSP_REFERENCE_ROOT points at a DSP-SLAM checkout, else
+                oracle/torch_baseline.py (kind "torch-restatement": the reference's own torch op sequence written out, bit-identical
+                results; `calibrated_vs_reference` = its time / the unmodified reference's, measured in the build container,
+                profiles/cpu_baseline_calibration.json), timed on this box's host cores on ONE cfg2 object (rank 0, N=1 only) --
+                a reported baseline, not a target.
 """
 import argparse
 import json
@@ -91,6 +95,7 @@ def main():
     ap.add_argument("--objects-per-gpu", type=int, default=0)   # 0 = the config's own size
     ap.add_argument("--prepass", choices=sorted(PREPASS), default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prepass-off", action="store_true")     # skip the prepass-off sub-record
     ap.add_argument("--latency-runs", type=int, default=9)
     args = ap.parse_args()
 
@@ -170,11 +175,10 @@ def main():
     def step():
         for bt in batches:
             bt.run()
-        packed = np.concatenate([D.pack_results(*bt.results()) for bt in batches], 0)
-        if dist is not None:     # the single collective of the path: results to rank 0 over RCCL / xGMI
-            gathered[0] = D.gather_results(packed, shards, dist, device=torch.device("cuda", local_rank))
+        if dist is not None:     # the single collective of the path: results device -> RCCL gather over xGMI -> rank 0's host, no host bounce
+            gathered[0] = D.gather_results_device(batches, shards, dist, device=torch.device("cuda", local_rank))
         else:
-            gathered[0] = packed
+            gathered[0] = np.concatenate([D.pack_results(*bt.results()) for bt in batches], 0)
 
     def sync():
         torch.cuda.synchronize()
@@ -182,23 +186,44 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    t0 = time.perf_counter()
-    acc = {}
-    for _ in range(args.steps):
-        step()
+    NOT_SUMMED = ("prepass_mode", "prepass_delta", "prepass_max_err", "prepass_guard_max_err")
+
+    def timed(n_warm, n_steps):
+        """n_warm untimed + exactly n_steps timed steps, barrier + synchronize on both sides, MAX over ranks.
+        -> (elapsed of the slowest rank, every rank's own elapsed, summed kernel stats of this rank)"""
+        for _ in range(n_warm):
+            step()
+        sync()
+        t0 = time.perf_counter()
+        acc = {}
+        for _ in range(n_steps):
+            step()
+            for bt in batches:
+                st = bt.stats()
+                for k, v in st.items():
+                    acc[k] = (acc.get(k, 0.0) + v) if k not in NOT_SUMMED else max(acc.get(k, 0.0), v)
+        own = time.perf_counter() - t0      # this rank's own time for its steps (before the closing barrier): shows imbalance
+        sync()
+        elapsed = time.perf_counter() - t0
+        per_rank = [own]
+        if dist is not None:
+            tt = torch.tensor([elapsed, own], dtype=torch.float64, device="cuda")
+            allt = [torch.empty_like(tt) for _ in range(world)]
+            dist.all_gather(allt, tt)
+            elapsed = max(float(x[0].item()) for x in allt)
+            per_rank = [float(x[1].item()) for x in allt]
+        return elapsed, per_rank, acc
+
+    elapsed, per_rank_s, acc = timed(args.warmup, args.steps)
+    # the same batch with the prepass OFF, timed in the same run (every rank takes part: the steps contain the collective)
+    off_run = None
+    if args.config == "cfg2x64" and int(acc.get("prepass_mode", 0)) != 0 and not args.no_prepass_off:
         for bt in batches:
-            st = bt.stats()
-            for k, v in st.items():
-                acc[k] = acc.get(k, 0.0) + v if k not in ("prepass_mode", "prepass_delta", "prepass_max_err") else v
-    sync()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+            bt.set_prepass(0)
+        off_steps = max(1, min(args.steps, 3))
+        off_run = timed(1, off_steps) + (off_steps,)
+        for bt in batches:
+            bt.set_prepass(PREPASS[args.prepass])
     n_good = int(sum(int((bt.results()[3] == 0).sum()) for bt in batches))
     n_total = sum(b - a for a, b in shards)
 
@@ -229,6 +254,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "ms_per_step_by_rank": [round(x / args.steps * 1e3, 3) for x in per_rank_s],
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -278,6 +304,23 @@ def main():
             "points_over_insphere": round(lp_pts / max(insphere_pts, 1.0), 4),
             "delta": acc.get("prepass_delta"),
             "traffic": pmc.get("lp_fetch_bytes_per_point", 0.0) * lp_pts / max(n_lp, 1) or None,
+        }
+
+    if mode:
+        result["prepass"]["guard"] = {"trips": acc.get("prepass_guard_trips", 0.0), "reruns": acc.get("prepass_guard_rerun", 0.0),
+                                      "max_err_seen": acc.get("prepass_guard_max_err", 0.0),
+                                      "note": "always on: the fp32 kernel re-decodes the widened band + 1/64 of the classified samples and compares"}
+    if off_run is not None:
+        o_el, o_ranks, o_acc, o_steps = off_run
+        o_tf = o_acc["n_fwd_points"] * F_FWD / (o_acc["ms_mlp_fwd"] * 1e-3) / 1e12 if o_acc["ms_mlp_fwd"] > 0 else 0.0
+        o_jflop = o_acc["n_jac_points"] * F_JAC + o_acc["n_render_rows"] * (F_JAC - F_FWD)
+        result["prepass_off"] = {
+            "value": round(n_total * o_steps / o_el, 3), "unit": "objects/s", "steps": o_steps, "ms_per_step": round(o_el / o_steps * 1e3, 3),
+            "roofline_frac": round(o_tf / PEAK_FP32_MFMA_TFLOPS, 4), "fwd_fp32_tflops": round(o_tf, 2),
+            "fwd_avg_launch_ms": round(o_acc["ms_mlp_fwd"] / max(o_acc["n_mlp_fwd_launches"], 1), 4),
+            "jac_kernel_frac": round(o_jflop / (o_acc["ms_mlp_jac"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if o_acc["ms_mlp_jac"] > 0 else None,
+            "whole_path_fp32_tflops": round((o_acc["n_fwd_points"] * F_FWD + o_jflop) / o_el / 1e12 * world, 2),
+            "note": "same batch, same process, prepass off: every sample in front of a ray's first solid sample decoded by the fp32 kernel; results bit-identical to the headline run",
         }
 
     if world == 1 and args.config == "cfg2x64":
@@ -330,45 +373,52 @@ def main():
             result["pose_only"] = {"error": repr(e)}
 
     if world == 1 and not args.no_cpu_baseline:
-        from oracle import dsp_oracle as O      # checker/baseline only -- never on the product path
-        dec = O.fold_decoder(sd, fixtures.SPECS)
+        # checker / baseline code only -- never on the product path
+        from oracle import dsp_oracle as O, torch_baseline as TB
         oprm = O.GNParams(**(dict(k1=10.0, k2=100.0, k3=2.5, k4=0.0, b1=0.2, b2=0.02, lr=1.0, s_damp=100.0, num_iterations=5) if args.config == "cfg5" else {}))
+        tb_dec = TB.build_decoder(sd, fixtures.SPECS)          # parameters keep requires_grad, as the reference leaves them
         # pick the intra-op thread count that runs a small object fastest (128-thread hosts are slower at 128 than at 16-32)
         small = synth.make_object(999, n_surface=500, n_background=0)
-        oprm5 = O.GNParams(num_iterations=2)
+        oprm2 = O.GNParams(num_iterations=2)
         ncpu = os.cpu_count() or 1
         best_threads, best_t = None, None
         for nt in sorted({min(ncpu, x) for x in (8, 16, 32, 64, ncpu)}):
             torch.set_num_threads(nt)
-            O.reconstruct_object(dec, oprm5, small["t_cam_obj_init"], small["pts"], small["rays"], small["depth"])
+            TB.reconstruct_object(tb_dec, oprm2, small["t_cam_obj_init"], small["pts"], small["rays"], small["depth"])
             t1 = time.perf_counter()
-            O.reconstruct_object(dec, oprm5, small["t_cam_obj_init"], small["pts"], small["rays"], small["depth"])
+            TB.reconstruct_object(tb_dec, oprm2, small["t_cam_obj_init"], small["pts"], small["rays"], small["depth"])
             dt_s = time.perf_counter() - t1
             if best_t is None or dt_s < best_t:
                 best_threads, best_t = nt, dt_s
         torch.set_num_threads(best_threads)
         o = objs[0]
-        kind, dt = "port", None
+        kind, dt = "torch-restatement", None
         if args.config != "cfg5" and os.environ.get("DSP_REFERENCE_ROOT"):     # never probed unless asked for: the GPU box has no checkout
             dt = reference_cpu_baseline(o, best_threads)
             if dt is not None:
                 kind = "reference"
         t1 = time.perf_counter()
-        r = O.reconstruct_object(dec, oprm, o["t_cam_obj_init"], o["pts"], o["rays"], o["depth"])
-        dt_port = time.perf_counter() - t1
+        r = TB.reconstruct_object(tb_dec, oprm, o["t_cam_obj_init"], o["pts"], o["rays"], o["depth"])
+        dt_tb = time.perf_counter() - t1
         if dt is None:
-            dt = dt_port
+            dt = dt_tb
+        cal_path = os.path.join(ROOT, "profiles", "cpu_baseline_calibration.json")
+        cal = json.load(open(cal_path)) if os.path.exists(cal_path) else {}
         gpu_t = D.unpack_results(gathered[0])[0][0]
         result["cpu_baseline"] = {
             "value": round(1.0 / dt, 4),
             "unit": "objects/s",
             "cores": int(best_threads),
             "kind": kind,
+            "calibrated_vs_reference": cal.get("torch_baseline_over_reference"),
+            "calibration": "profiles/cpu_baseline_calibration.json: oracle/torch_baseline.py takes %s x the unmodified reference's time on the same cfg2 object "
+                           "(build container, %s threads), results bit-identical" % (cal.get("torch_baseline_over_reference"), cal.get("threads")),
             "sample": "1 %s object (seed %d), all %d GN iterations, %s on %d of %d host threads (fastest of a small sweep); %.2f s%s" % (
                 "cfg5 (4000-pt)" if args.config == "cfg5" else "cfg2", 1 + rank * B, oprm.num_iterations,
                 "the unmodified reference (reconstruct/optimizer.py via oracle/ref_shim.py, torch CPU)" if kind == "reference"
-                else "oracle/dsp_oracle.py with torch-CPU sgemm (no reference checkout on this box: DSP_REFERENCE_ROOT unset)",
-                best_threads, ncpu, dt, "; the oracle port took %.2f s" % dt_port if kind == "reference" else ""),
+                else "oracle/torch_baseline.py: the reference's torch op sequence restated (weight-normed nn.Linear chain, autograd input gradient with "
+                     "parameters requiring grad, bmm Gram, torch.inverse) -- no reference checkout on this box",
+                best_threads, ncpu, dt, "; the torch restatement took %.2f s" % dt_tb if kind == "reference" else ""),
             "gpu_vs_cpu": round(value * dt, 1),
             "pose_max_abs_diff_vs_gpu": float(np.abs(r["t_cam_obj"] - gpu_t).max()) if r["is_good"] else None,
         }

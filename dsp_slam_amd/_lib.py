@@ -41,7 +41,9 @@ class Stats(C.Structure):
                 ("n_mlp_fwd_launches", C.c_int32), ("n_mlp_jac_launches", C.c_int32), ("n_insphere_points", C.c_double), ("n_render_rows", C.c_double),
                 ("n_prepass_points", C.c_double), ("ms_mlp_prepass", C.c_double), ("n_mlp_prepass_launches", C.c_int32),
                 ("prepass_mode", C.c_int32), ("prepass_delta", C.c_float), ("prepass_max_err", C.c_float),
-                ("prepass_misclassified", C.c_double), ("prepass_audited", C.c_double)]
+                ("prepass_misclassified", C.c_double), ("prepass_audited", C.c_double),
+                ("prepass_guard_trips", C.c_double), ("prepass_guard_objects", C.c_double), ("prepass_guard_max_err", C.c_float),
+                ("prepass_guard_rerun", C.c_int32)]
 
 
 class DspError(RuntimeError):
@@ -54,6 +56,9 @@ _lib = None
 _VP = C.c_void_p
 SYMBOLS = [
     ("dsp_abi_version", C.c_int, []),
+    ("dsp_device_count", C.c_int, []),
+    ("dsp_build_info", C.c_char_p, []),
+    ("dsp_runtime_versions", C.c_int, [c_i32p, c_i32p]),
     ("dsp_create", C.c_int, [C.POINTER(DecoderDesc), C.c_int, C.POINTER(_VP)]),
     ("dsp_destroy", None, [_VP]),
     ("dsp_last_error", C.c_char_p, [_VP]),
@@ -80,13 +85,21 @@ SYMBOLS = [
     ("dsp_batch_set_speculative_band", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_set_prepass", C.c_int, [_VP, C.c_int, C.c_float]),
     ("dsp_prepass_calibration", C.c_int, [_VP, C.c_int, c_f32p, c_f32p]),
+    ("dsp_prepass_calibration_table", C.c_int, [_VP, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p]),
     ("dsp_batch_set_prepass_audit", C.c_int, [_VP, C.c_int]),
+    ("dsp_batch_set_prepass_guard", C.c_int, [_VP, C.c_int]),
+    ("dsp_batch_set_start_state", C.c_int, [_VP, c_f32p, c_f32p, c_f32p]),
+    ("dsp_batch_set_iterations", C.c_int, [_VP, C.c_int32]),
+    ("dsp_batch_set_depth_schedule", C.c_int, [_VP, c_f32p, C.c_int32]),
+    ("dsp_batch_debug_samples", C.c_int, [_VP, C.c_int32, C.POINTER(C.c_uint64), c_f32p, c_f32p, C.c_int64]),
     ("dsp_batch_set_split_rows", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_enable_trace", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_trace", C.c_int, [_VP, C.c_int32, c_f32p, c_f32p, c_f32p, c_i64p, c_i64p, c_i64p, c_f32p, c_f32p, C.POINTER(C.c_uint32), c_f32p]),
     ("dsp_batch_destroy", None, [_VP]),
     ("dsp_pack_results", None, [C.c_int32, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p]),
     ("dsp_gather_results", C.c_int, [C.POINTER(_VP), C.c_int32, C.POINTER(c_f32p), c_i32p, c_f32p]),
+    ("dsp_gather_batch_results", C.c_int, [C.POINTER(_VP), C.c_int32, c_f32p]),
+    ("dsp_batch_results_packed_dev", C.c_int, [_VP, C.c_void_p]),
     ("dsp_extract_mesh", C.c_int, [_VP, c_f32p, C.c_int32, C.c_int32, c_i64p, c_i64p]),
     ("dsp_marching_cubes", C.c_int, [_VP, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, c_i64p, c_i64p]),
     ("dsp_mesh_fetch", C.c_int, [_VP, c_f32p, C.c_int64, c_i32p, C.c_int64]),

@@ -41,10 +41,12 @@ OBJ_DIR = os.path.join(LIB_DIR, "obj")
 def _compile_one(hipcc, src, verbose):
     obj = os.path.join(OBJ_DIR, src + ".o")
     deps = [os.path.join(CSRC, src)] + HEADERS + [os.path.abspath(__file__)]
+    if src == "dsp_gn.hip":
+        deps.append(os.path.join(LIB_DIR, "build_info.h"))
     if os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps):
         return obj
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-Wno-unused-value",
-           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + EXTRA_FLAGS.get(src, []) + [os.path.join(CSRC, src), "-o", obj + ".tmp"]
+           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-I" + LIB_DIR] + EXTRA_FLAGS.get(src, []) + [os.path.join(CSRC, src), "-o", obj + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
@@ -52,6 +54,80 @@ def _compile_one(hipcc, src, verbose):
         raise RuntimeError("hipcc failed on %s:\n%s" % (src, r.stdout))
     os.replace(obj + ".tmp", obj)
     return obj
+
+
+# ---- ISA assumptions, enforced where the library is BUILT ----------------------------------------------------------------------------
+# The decoder kernels rest on three properties of the generated code that hipcc does not promise (DESIGN.md "K1"):
+#   * M0 (the LDS-DMA destination) is written ONLY by mlp_common.h's helpers (`s_mov_b32 m0, sN` + hazard `s_nop`) and never by hipcc:
+#     the helpers leave it set across the k-steps that issue a chunk's pieces and do not restore it;
+#   * the fp32 decoder kernels and the f16 prepass kernel keep their activation slabs in registers: no scratch memory, no spills;
+#   * the LDS-DMA loads are really there (global_load_lds_dwordx4), i.e. the inline asm was not dropped.
+# A different hipcc may break any of them silently (wrong results for M0, a 10x slowdown for scratch), so the build FAILS instead.
+OBJDUMP_CANDIDATES = ("/opt/rocm/lib/llvm/bin/llvm-objdump", "/opt/rocm/llvm/bin/llvm-objdump")
+READELF_CANDIDATES = ("/opt/rocm/lib/llvm/bin/llvm-readelf", "/opt/rocm/llvm/bin/llvm-readelf")
+NO_SCRATCH_KERNELS = ("mlp_kernelILi0", "mlp_kernelILi1", "mlp_kernelILi2", "mlp_kernelILi3", "mlp_split_kernel", "mlp_lp_kernelILb0")
+
+
+class IsaCheckError(RuntimeError):
+    pass
+
+
+def check_isa(verbose=False):
+    """Disassemble the gfx950 code objects of the decoder kernels and check the assumptions above.  Returns a dict of what was counted;
+    raises IsaCheckError on a violation, RuntimeError when the LLVM tools are missing (set DSP_SKIP_ISA_CHECK=1 to build anyway)."""
+    import tempfile
+    objdump = next((c for c in OBJDUMP_CANDIDATES if os.path.exists(c)), None)
+    readelf = next((c for c in READELF_CANDIDATES if os.path.exists(c)), None)
+    if not objdump or not readelf:
+        raise RuntimeError("llvm-objdump / llvm-readelf not found: cannot check the ISA assumptions of the decoder kernels")
+    report = {"m0_writes": 0, "lds_dma_loads": 0, "kernels": {}}
+    for src in ("mlp_kernel.hip", "mlp_lp_kernel.hip", "mlp_split_kernel.hip"):
+        obj = os.path.join(OBJ_DIR, src + ".o")
+        with tempfile.TemporaryDirectory(prefix="dsp_isa_") as work:
+            shutil.copy(obj, os.path.join(work, "k.o"))
+            subprocess.run([objdump, "--offloading", "k.o"], cwd=work, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            co = [f for f in os.listdir(work) if "gfx950" in f]
+            if len(co) != 1:
+                raise IsaCheckError("%s: expected one gfx950 code object, found %s" % (src, co))
+            dis = subprocess.run([objdump, "-d", co[0]], cwd=work, stdout=subprocess.PIPE, text=True, check=True).stdout.splitlines()
+            notes = subprocess.run([readelf, "--notes", co[0]], cwd=work, stdout=subprocess.PIPE, text=True, check=True).stdout.splitlines()
+        ins = [ln.split("//")[0].split() for ln in dis if "\t" in ln and not ln.rstrip().endswith(":")]
+        ins = [t for t in ins if t]
+        for i, t in enumerate(ins):
+            if any(x.rstrip(",") == "m0" for x in t):
+                if not (t[0] == "s_mov_b32" and t[1].rstrip(",") == "m0" and ins[i + 1][0] == "s_nop"):
+                    raise IsaCheckError("%s: M0 is touched outside the LDS-DMA helpers: `%s`" % (src, " ".join(t)))
+                report["m0_writes"] += 1
+        loads = sum(1 for t in ins if t[0] == "global_load_lds_dwordx4")
+        if loads < 400:
+            raise IsaCheckError("%s: only %d global_load_lds_dwordx4 instructions (the LDS-DMA stream is missing)" % (src, loads))
+        report["lds_dma_loads"] += loads
+        cur = {}
+        for ln in notes:          # AMDGPU metadata: one block of `.key: value` lines per kernel
+            ln = ln.strip().lstrip("- ").strip()
+            for key in (".name", ".private_segment_fixed_size", ".vgpr_count", ".agpr_count", ".vgpr_spill_count", ".sgpr_spill_count"):
+                if ln.startswith(key + ":"):
+                    cur[key] = ln.split(":", 1)[1].strip()
+            if ".name" in cur and ".private_segment_fixed_size" in cur and ".vgpr_count" in cur and ".vgpr_spill_count" in cur and (
+                    ".agpr_count" in cur) and ".sgpr_spill_count" in cur:
+                report["kernels"][cur[".name"]] = {k[1:]: int(v) for k, v in cur.items() if k != ".name"}
+                cur = {}
+    for name, k in report["kernels"].items():
+        if any(tag in name for tag in NO_SCRATCH_KERNELS) and (k["private_segment_fixed_size"] or k["vgpr_spill_count"]):
+            raise IsaCheckError("%s uses scratch memory (%d B, %d spilled VGPRs): the activation slabs no longer live in registers" % (
+                name, k["private_segment_fixed_size"], k["vgpr_spill_count"]))
+    if report["m0_writes"] < 250 or len(report["kernels"]) < 8:
+        raise IsaCheckError("ISA check saw too little: %d M0 writes, %d kernels" % (report["m0_writes"], len(report["kernels"])))
+    if verbose:
+        print("ISA check: %d M0 writes (all by the LDS-DMA helpers), %d LDS-DMA loads, %d decoder kernels without scratch" % (
+            report["m0_writes"], report["lds_dma_loads"], len(report["kernels"])))
+    return report
+
+
+def hipcc_version(hipcc):
+    r = subprocess.run([hipcc, "--version"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    lines = [ln.strip() for ln in r.stdout.splitlines() if ln.strip()]
+    return " | ".join(lines[:2]) if lines else "unknown"
 
 
 def build(force=False, verbose=False):
@@ -63,9 +139,17 @@ def build(force=False, verbose=False):
         for f in os.listdir(OBJ_DIR):
             os.remove(os.path.join(OBJ_DIR, f))
     hipcc = _hipcc()
+    # what compiled this library travels inside it (dsp_build_info): the GPU tests log it next to the runtime's version
+    info = os.path.join(LIB_DIR, "build_info.h")
+    text = '#define DSP_BUILD_HIPCC "%s"\n' % hipcc_version(hipcc).replace("\\", "/").replace('"', "'")
+    if not os.path.exists(info) or open(info).read() != text:
+        with open(info, "w") as f:
+            f.write(text)
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         objs = list(ex.map(lambda s: _compile_one(hipcc, s, verbose), SOURCES))
+    if os.environ.get("DSP_SKIP_ISA_CHECK") != "1":
+        check_isa(verbose)          # before linking: a library that violates the assumptions is never produced
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH + ".tmp"]
     if verbose:
         print(" ".join(cmd))

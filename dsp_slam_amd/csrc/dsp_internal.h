@@ -60,6 +60,11 @@ struct MlpArgs {
     int lat_tile;               // 16-row slab tile of the latent_in layer's re-injected xyz: 27 (rows 445..447, 64-D codes) or 29 (477..479, 32-D)
     float* out_sdf;             // FWD: [n_points]
     float* out_grad;            // BWD: [n_points][GRAD_STRIDE]
+    // always-on guard of the low-precision pre-classification (prepass_guard, mlp_common.h): the fp32 kernels compare every sample they
+    // re-decode with the prepass value it replaces.  guard = per-object words {lp_delta (float), trips, max error (float bits)} of object 0,
+    // guard_stride words apart (inside ObjState); nullptr = off
+    unsigned* guard;
+    int guard_stride;
     float* sdf_scatter;         // BWD, optional: tiles from *scatter_tile_begin on also store their sdf at sdf_scatter[int(pt.w)] (speculative band rows)
     const int* scatter_tile_begin;
     const float* wsplit;        // latency form (mlp_split_kernel): the same chunks laid out per wave (see pack_decoder)
@@ -145,12 +150,27 @@ struct ObjState {           // per-object optimiser state, lives on the device f
     int n_alive;
     int P;                  // samples selected for the current front-to-back pass
     unsigned vsum, ksum;    // order-independent checksums of the in-sphere set and of the kept (jacobian) sample set
+    // prepass: this object's margin (from the magnitude of its CURRENT code, lp_delta_of), and what the guard saw
+    float lp_delta;
+    unsigned guard_trips;   // waves that re-decoded a sample whose prepass value was off by >= lp_delta / 2
+    unsigned guard_err;     // largest |sdf_lp - sdf_fp32| over the re-decoded samples (float bits)
+    int pad0;
+};
+static_assert(sizeof(ObjState) % 16 == 0, "ObjState is addressed as float4-aligned rows");
+
+// Prepass margin as a function of the code's largest entry: calibrate_prepass (dsp_gn.hip) measures the largest |sdf_lp - sdf_fp32|
+// with codes drawn at each of these magnitudes; delta is interpolated between them (linear extrapolation above, capped at 0.5).
+constexpr int LP_NMAG = 5;
+struct LpDeltaTab {
+    float mag[LP_NMAG];
+    float delta[LP_NMAG];
 };
 
 struct GnParamsDev {
     float k1, k2, k3, k4, b1, b2, lr, s_damp, cut_off;
     int n_depth, pose_only;
     int code_len;       // of the decoder (32 or 64); the state always carries CODE_LEN entries
+    LpDeltaTab lp;      // prepass margin table of the dtype in use (all entries equal when the caller fixed delta)
 };
 
 // kernels_mlp / kernels_gn launchers
@@ -162,7 +182,8 @@ hipError_t mlp_split_prepare_device();
 hipError_t launch_mlp_split(bool bwd, const MlpArgs& args, int n_blocks, hipStream_t stream);   // 16-point tiles; forward (+ backward)
 hipError_t mlp_lp_prepare_device();
 hipError_t launch_mlp_lp(bool bf16, const LpArgs& args, int n_blocks, hipStream_t stream);   // 128-point tiles, forward only
-void launch_init_state(ObjState* st, const float* t, const float* codes, const float* scale, int B, int D, int pose_only, hipStream_t s);
+void launch_init_state(ObjState* st, const float* t, const float* codes, const float* scale, const float* depths /*optional B x 64*/, int B, int D, int pose_only,
+                       const LpDeltaTab& lp, hipStream_t s);
 void launch_sample_count(const ObjConst* oc, ObjState* st, const float* rays, unsigned long long* m, int* c, int D, int maxR, int B, hipStream_t s);
 void launch_scan_rays(const ObjConst* oc, ObjState* st, const int* cnt, int* off, int which, int B, hipStream_t s);
 void launch_sample_write(const ObjConst* oc, const ObjState* st, const float* rays, const unsigned long long* m, const int* off, float4* spts,
@@ -170,18 +191,20 @@ void launch_sample_write(const ObjConst* oc, const ObjState* st, const float* ra
 void launch_surface(const ObjConst* oc, const ObjState* st, const float* pts, float4* jpts, float2* jaux, int maxM, int B, hipStream_t s);
 void launch_build_tiles(const ObjConst* oc, const ObjState* st, int B, int mode, int4* tiles, int* n_tiles, double* counters, int add_v, int tile_pts,
                         int cnt_slot, hipStream_t s);   // mode 3 = mode 1 with the band samples (P) in place of the kept render rows (K)   // cnt_slot: counter the point count of a mode 0 / 2 list is added to
-void launch_band_select(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff, const float* ssdf, float thd,
-                        int* pcnt, int* poff, int* plist, int maxR, int B, hipStream_t s);
+// th = cut_off; the widened band of object b is |sdf_lp| < th + st[b].lp_delta.  guard_salt: samples OUTSIDE the band whose id hash
+// (xor salt) is 0 mod 64 are selected too, so that the fp32 kernel re-decodes them and prepass_guard compares (0 = no guard samples)
+void launch_band_select(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff, const float* ssdf, float th,
+                        unsigned guard_salt, int* pcnt, int* poff, int* plist, int maxR, int B, hipStream_t s);
 // fused per-object forms (latency path): front = sample_count + scan + sample_write + surface; band = count + scan + write;
 // render tail = scan + sum_m + render_write (behind k_render_scan, one wave per ray over the whole chip)
 void launch_front_fused(const ObjConst* oc, ObjState* st, const float* rays, const float* pts, unsigned long long* raymask, int* raycnt, int* rayoff,
                         float4* spts, float* ssdf, unsigned char* alive, float4* jpts, float2* jaux, int D, int B, hipStream_t s);
-void launch_band_fused(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff, const float* ssdf, float thd, int* pcnt,
-                       int* poff, int* plist, const float4* spts, float4* jpts, int* srow, int B, hipStream_t s);   // jpts / srow: speculative band rows (or null)
+void launch_band_fused(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff, const float* ssdf, float th, unsigned guard_salt,
+                       int* pcnt, int* poff, int* plist, const float4* spts, float4* jpts, int* srow, int B, hipStream_t s);   // jpts / srow: speculative band rows (or null)
 void launch_render_tail_fused(const ObjConst* oc, ObjState* st, const int* raycnt, const int* rayoff, const float4* spts, const float* sdeds,
                               const float* ray_res, const int* kcnt, int* koff, const int* mcnt, float4* jpts, float2* jaux, const int* srow, int* jrow,
                               int B, hipStream_t s);
-void launch_prepass_audit(const ObjConst* oc, const ObjState* st, const float* ssdf, const float* saudit, float th, float thd, unsigned* out,
+void launch_prepass_audit(const ObjConst* oc, const ObjState* st, const float* ssdf, const float* saudit, float th, unsigned* out,
                           int B, hipStream_t s);
 void launch_render_scan(const ObjConst* oc, ObjState* st, const unsigned long long* m, const int* off, const float* ssdf, const float* depth,
                         float* sdeds, float* ray_res, int* kcnt, int* mcnt, int D, float th, int maxR, int B, hipStream_t s);
@@ -199,16 +222,17 @@ void launch_pass_select(const ObjConst* oc, ObjState* st, const unsigned long lo
 void launch_pass_write(const ObjConst* oc, const ObjState* st, const unsigned long long* raymask, const int* rayoff, const unsigned char* alive,
                        const int* poff, int* plist, const PassSpec& ps, int maxR, int B, hipStream_t s);
 void launch_pass_update(const ObjConst* oc, const ObjState* st, const unsigned long long* raymask, const int* rayoff, unsigned char* alive,
-                        const float* ssdf, float th, const PassSpec& ps, int maxR, int B, hipStream_t s);
+                        const float* ssdf, float th, int use_lp_delta, const PassSpec& ps, int maxR, int B, hipStream_t s);   // use_lp_delta: a ray stops at sdf <= -(th + st[b].lp_delta)
 void launch_sum_m(const ObjConst* oc, ObjState* st, const int* mcnt, int B, hipStream_t s);
 void launch_gram(const ObjConst* oc, const ObjState* st, const float4* jpts, const float2* jaux, const float* jgrad, const int* jrow,
                  const unsigned char* alive, float* partials, int n_slices, float b_sdf, float b_render, int robust, int n_terms, int B, hipStream_t s);
 void launch_jrows(const ObjConst* oc, const ObjState* st, const float4* jpts, const float2* jaux, const float* jgrad, const int* jrow, int term, float* rows,
                   int cap, hipStream_t s);   // jrow (optional): render row i takes its gradient from jgrad row jrow[i]
 void launch_solve(const ObjConst* oc, ObjState* st, const float* partials, double* gsum, int n_slices, const GnParamsDev& prm, int iter,
-                  float* trace, const float* codew, const float* b0, const float* blat, float* cbias, int B, hipStream_t s);   // cbias: next iteration's code bias
+                  float* trace, const float* codew, const float* b0, const float* blat, float* cbias, const float* depths_next, int B, hipStream_t s);   // cbias: next iteration's code bias; depths_next: optional B x 64 override of the next iteration's depth samples
 void launch_inlier_filter(const ObjConst* oc, ObjState* st, const float* jgrad, unsigned char* alive, int maxM, int B, hipStream_t s);
-void launch_finalize(ObjState* st, const float* scale, int B, int pose_only, float* t, float* code, float* loss, int* status, hipStream_t s);
+constexpr int DSP_RESULT_WIDTH_DEV = 82;   // == DSP_RESULT_WIDTH (dsp_gn.h): t_cam_obj 16 | code 64 | loss | status
+void launch_finalize(ObjState* st, const float* scale, int B, int pose_only, float* t, float* code, float* loss, int* status, float* packed, hipStream_t s);
 
 hipError_t debug_solve_clocks(unsigned long long* out8);
 

@@ -101,23 +101,51 @@ __device__ void derive_iter_state(ObjState& s, int n_depth) {
                                         : __fsub_rn(dmax, __fmul_rn(step, (float)(n_depth - 1 - i)));
 }
 
-__global__ void k_init_state(ObjState* st, const float* t_cam_obj, const float* codes, const float* scale_in,
-                             int n_obj, int n_depth, int pose_only) {
+// Prepass margin of an object from the largest entry of its current code (LpDeltaTab: measured per decoder at dsp_create with codes
+// drawn at the listed magnitudes).  Piecewise linear, extrapolated above the last magnitude, never below the first entry, capped at
+// 0.5 (a band that wide sends every sample to the fp32 kernel); a non-finite code gets the cap.
+__device__ __forceinline__ float lp_delta_of(float zmax, const LpDeltaTab& t) {
+    if (!(zmax < 1e30f)) return 0.5f;
+    float d = t.delta[0];
+#pragma unroll
+    for (int i = 0; i + 1 < LP_NMAG; ++i) {
+        const float m0 = t.mag[i], m1 = t.mag[i + 1];
+        if (zmax > m0 && (zmax <= m1 || i + 2 == LP_NMAG)) d = t.delta[i] + (t.delta[i + 1] - t.delta[i]) * ((zmax - m0) / (m1 - m0));
+    }
+    return fminf(fmaxf(d, t.delta[0]), 0.5f);
+}
+
+__global__ void k_init_state(ObjState* st, const float* t_cam_obj, const float* codes, const float* scale_in, const float* depths,
+                             int n_obj, int n_depth, int pose_only, LpDeltaTab lp) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_obj) return;
     ObjState& s = st[b];
     double tco[16], toc[16];
     for (int i = 0; i < 16; ++i) tco[i] = (double)t_cam_obj[16 * b + i];
-    if (pose_only) {   // optimizer.py:52-55: R *= scale before inverting
+    if (pose_only & 1) {   // optimizer.py:52-55: R *= scale before inverting
         const double sc = (double)scale_in[b];
         for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) tco[4 * r + c] = (double)(float)(tco[4 * r + c] * sc);
     }
     s.status = DSP_STATUS_GOOD;
-    if (!inv4(tco, toc)) { s.status = DSP_STATUS_NAN; for (int i = 0; i < 16; ++i) toc[i] = (i % 5 == 0); }
+    if (pose_only & 2) {          // the input IS the camera->object matrix (dsp_batch_set_start_state): taken as it is
+        for (int i = 0; i < 16; ++i) toc[i] = tco[i];
+    } else if (!inv4(tco, toc)) { s.status = DSP_STATUS_NAN; for (int i = 0; i < 16; ++i) toc[i] = (i % 5 == 0); }
+    pose_only &= 1;
     for (int i = 0; i < 16; ++i) s.t_oc[i] = (float)toc[i];
     for (int i = 0; i < CODE_LEN; ++i) s.code[i] = codes ? codes[CODE_LEN * b + i] : 0.f;
     s.loss = 0.f; s.V = 0; s.m = 0; s.K = 0; s.n_alive = -1; s.vsum = 0; s.ksum = 0;
-    if (!pose_only) derive_iter_state(s, n_depth);
+    float zmax = 0.f;
+    for (int i = 0; i < CODE_LEN; ++i) { const float a = fabsf(s.code[i]); zmax = (a > zmax || a != a) ? a : zmax; }
+    s.lp_delta = lp_delta_of(zmax, lp);
+    s.guard_trips = 0; s.guard_err = 0;
+    if (!pose_only) {
+        derive_iter_state(s, n_depth);
+        if (depths) {     // forensics: the first iteration samples exactly these depths (dsp_batch_set_start_state)
+            for (int i = 0; i < n_depth; ++i) s.depths[i] = depths[MAX_DEPTH_SAMPLES * b + i];
+            s.dmin = s.depths[0];
+            s.dmax = s.depths[n_depth - 1];
+        }
+    }
 }
 
 // membership checksum of a sample id (ray << 6 | depth index): wrap-around sum of a per-id hash, so two runs agree on it
@@ -301,7 +329,7 @@ __global__ void k_pass_write(const ObjConst* oc, const ObjState* st, const unsig
 }
 
 __global__ void k_pass_update(const ObjConst* oc, const ObjState* st, const unsigned long long* raymask, const int* rayoff,
-                              unsigned char* alive, const float* ssdf, float th, int j0, int j1, int n_depth, int pass, int last,
+                              unsigned char* alive, const float* ssdf, float th, int use_lp_delta, int j0, int j1, int n_depth, int pass, int last,
                               unsigned char* hint, unsigned char* plo) {
     const int b = blockIdx.y;
     const ObjConst c = oc[b];
@@ -309,6 +337,7 @@ __global__ void k_pass_update(const ObjConst* oc, const ObjState* st, const unsi
     if (r >= c.n_rays) return;
     const int gr = c.ray_off + r;
     if (st[b].status != DSP_STATUS_GOOD || !alive[gr]) return;
+    if (use_lp_delta) th += st[b].lp_delta;      // prepass values: only a CERTAINLY solid sample stops the ray
     int lo, hi;
     pass_range(gr, j0, j1, n_depth, pass, last, hint, plo, lo, hi);
     const unsigned long long mask = raymask[gr];
@@ -337,63 +366,78 @@ __global__ void k_pass_update(const ObjConst* oc, const ObjState* st, const unsi
 // 0, so nothing there can reach the result.  What is left for the fp32 kernel: the samples IN FRONT of a ray's first
 // certainly-solid sample whose |sdf_lp| < th + delta.  Their exact values then replace the low-precision ones in ssdf; the
 // classified samples keep sdf_lp (any value beyond +-th gives the same occupancy bit for bit).
+// Guard samples: a 1/64 sample (id hash xor a per-launch salt) of the samples the prepass CLASSIFIED -- beyond the widened band, up to
+// and including the ray's first certainly-solid sample -- joins the list, so that the fp32 kernel re-decodes it and prepass_guard
+// (mlp_common.h) compares the two values.  Its exact value then replaces the prepass value: the same occupancy, bit for bit, whenever
+// the classification was right.  salt == 0: no guard samples.
+__device__ __forceinline__ bool guard_pick(unsigned id, unsigned salt) { return salt != 0u && ((id_hash(id) ^ salt) & 63u) == 0u; }
+
 __device__ __forceinline__ void band_count_ray(const ObjConst& c, const ObjState& s, const unsigned long long* raymask, const int* rayoff,
-                                               const float* ssdf, float thd, int* pcnt, int r) {
+                                               const float* ssdf, float th, unsigned salt, int* pcnt, int r) {
     const int gr = c.ray_off + r;
     int n = 0;
     if (s.status == DSP_STATUS_GOOD) {
-        const int cnt = __popcll(raymask[gr]);
+        const float thd = th + s.lp_delta;
+        unsigned long long mask = raymask[gr];
         const float* sd = ssdf + c.samp_off + rayoff[gr];
-        for (int i = 0; i < cnt; ++i) {
+        for (int i = 0; mask; ++i) {
+            const int j = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
             const float v = sd[i];
+            const bool pick = v != 1.0f && guard_pick(((unsigned)r << 6) | (unsigned)j, salt);
+            n += (fabsf(v) < thd || pick) ? 1 : 0;
             if (v <= -thd) break;
-            n += (fabsf(v) < thd) ? 1 : 0;
         }
     }
     pcnt[gr] = n;
 }
 
 __device__ __forceinline__ void band_write_ray(const ObjConst& c, const ObjState& s, const unsigned long long* raymask, const int* rayoff,
-                                               const float* ssdf, float thd, const int* poff, int* plist, int r) {
+                                               const float* ssdf, float th, unsigned salt, const int* poff, int* plist, int r) {
     const int gr = c.ray_off + r;
     if (s.status != DSP_STATUS_GOOD) return;
-    const int cnt = __popcll(raymask[gr]);
+    const float thd = th + s.lp_delta;
+    unsigned long long mask = raymask[gr];
     const int base = c.samp_off + rayoff[gr];
     int* dst = plist + c.samp_off + poff[gr];
-    for (int i = 0; i < cnt; ++i) {
+    for (int i = 0; mask; ++i) {
+        const int j = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
         const float v = ssdf[base + i];
+        const bool pick = v != 1.0f && guard_pick(((unsigned)r << 6) | (unsigned)j, salt);
+        if (fabsf(v) < thd || pick) *dst++ = base + i;
         if (v <= -thd) break;
-        if (fabsf(v) < thd) *dst++ = base + i;
     }
 }
 
 __global__ void k_band_count(const ObjConst* oc, const ObjState* st, const unsigned long long* raymask, const int* rayoff,
-                             const float* ssdf, float thd, int* pcnt) {
+                             const float* ssdf, float th, unsigned salt, int* pcnt) {
     const int b = blockIdx.y;
     const ObjConst c = oc[b];
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= c.n_rays) return;
-    band_count_ray(c, st[b], raymask, rayoff, ssdf, thd, pcnt, r);
+    band_count_ray(c, st[b], raymask, rayoff, ssdf, th, salt, pcnt, r);
 }
 
 __global__ void k_band_write(const ObjConst* oc, const ObjState* st, const unsigned long long* raymask, const int* rayoff,
-                             const float* ssdf, float thd, const int* poff, int* plist) {
+                             const float* ssdf, float th, unsigned salt, const int* poff, int* plist) {
     const int b = blockIdx.y;
     const ObjConst c = oc[b];
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= c.n_rays) return;
-    band_write_ray(c, st[b], raymask, rayoff, ssdf, thd, poff, plist, r);
+    band_write_ray(c, st[b], raymask, rayoff, ssdf, th, salt, poff, plist, r);
 }
 
 // audit (tests / calibration): saudit = fp32 sdf of EVERY in-sphere sample, ssdf = prepass values (+1 where not decoded).
 // out[0] = max |sdf_lp - sdf_fp32| (float bits), out[1] = samples the prepass classified against the fp32 value
 // (sdf_lp >= thd but sdf_fp32 < th, or sdf_lp <= -thd but sdf_fp32 > -th), out[2] = samples compared.
-__global__ void k_prepass_audit(const ObjConst* oc, const ObjState* st, const float* ssdf, const float* saudit, float th, float thd,
+__global__ void k_prepass_audit(const ObjConst* oc, const ObjState* st, const float* ssdf, const float* saudit, float th,
                                 unsigned* out) {
     const int b = blockIdx.y;
     const ObjConst c = oc[b];
     const ObjState& s = st[b];
     if (s.status != DSP_STATUS_GOOD) return;
+    const float thd = th + s.lp_delta;
     float worst = 0.f;
     unsigned bad = 0, n = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < s.V; i += gridDim.x * blockDim.x) {
@@ -709,36 +753,49 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_front_fused(const ObjConst* o
 // k_band_count + k_scan_rays(2) + k_band_write: one THREAD per ray, the ray's <= 64 sample values as independent loads (the
 // front-to-back walk of band_count_ray becomes mask arithmetic: first certainly-solid sample = lowest set bit)
 __device__ __forceinline__ unsigned long long band_select_thread(const ObjConst& c, const unsigned long long* raymask, const int* rayoff,
-                                                                 const float* ssdf, float thd, int r, int& base) {
+                                                                 const float* ssdf, float thd, unsigned salt, int r, int& base) {
     const int gr = c.ray_off + r;
-    const int cnt = __popcll(raymask[gr]);
+    const unsigned long long rmask = raymask[gr];
+    const int cnt = __popcll(rmask);
     base = c.samp_off + rayoff[gr];
-    unsigned long long solid = 0ull, band = 0ull;
+    unsigned long long solid = 0ull, band = 0ull, decoded = 0ull;
 #pragma unroll
     for (int k = 0; k < 64; ++k) {
         const float v = ssdf[k < cnt ? base + k : c.samp_off];
         if (k < cnt && v <= -thd) solid |= 1ull << k;
         if (k < cnt && fabsf(v) < thd) band |= 1ull << k;
+        if (k < cnt && v != 1.0f) decoded |= 1ull << k;
     }
-    const int first = solid ? __ffsll((long long)solid) - 1 : 64;     // samples from the first certainly-solid one on are skipped
+    const int first = solid ? __ffsll((long long)solid) - 1 : 64;     // samples behind the first certainly-solid one are skipped
+    if (salt) {       // guard samples (band_count_ray): classified samples up to and including the first certainly-solid one
+        unsigned long long m = rmask, pick = 0ull;
+        for (int k = 0; m; ++k) {
+            const int j = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            if (guard_pick(((unsigned)r << 6) | (unsigned)j, salt)) pick |= 1ull << k;
+        }
+        band |= pick & decoded;
+        return first >= 63 ? band : band & ((2ull << first) - 1ull);
+    }
     return first >= 64 ? band : band & ((1ull << first) - 1ull);
 }
 
 __global__ __launch_bounds__(FUSED_THREADS) void k_band_fused(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff,
-                                                              const float* ssdf, float thd, int* pcnt, int* poff, int* plist, const float4* spts,
+                                                              const float* ssdf, float th, unsigned salt, int* pcnt, int* poff, int* plist, const float4* spts,
                                                               float4* jpts, int* srow) {
     __shared__ int part[FUSED_THREADS];
     const int b = blockIdx.x;
     const ObjConst c = oc[b];
     const bool good = st[b].status == DSP_STATUS_GOOD;
+    const float thd = th + st[b].lp_delta;
     int base;
-    for (int r = threadIdx.x; r < c.n_rays; r += FUSED_THREADS) pcnt[c.ray_off + r] = good ? __popcll(band_select_thread(c, raymask, rayoff, ssdf, thd, r, base)) : 0;
+    for (int r = threadIdx.x; r < c.n_rays; r += FUSED_THREADS) pcnt[c.ray_off + r] = good ? __popcll(band_select_thread(c, raymask, rayoff, ssdf, thd, salt, r, base)) : 0;
     __syncthreads();
     scan_rays_block<FUSED_THREADS>(c, st, b, pcnt, poff, 2, part);
     __syncthreads();
     if (good) {
         for (int r = threadIdx.x; r < c.n_rays; r += FUSED_THREADS) {
-            unsigned long long sel = band_select_thread(c, raymask, rayoff, ssdf, thd, r, base);
+            unsigned long long sel = band_select_thread(c, raymask, rayoff, ssdf, thd, salt, r, base);
             int pos = poff[c.ray_off + r];
             while (sel) {
                 const int idx = base + __ffsll((long long)sel) - 1;
@@ -1013,7 +1070,7 @@ constexpr int SOLVE_THREADS = 1024;   // 16 waves: the elimination is instructio
 
 __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, ObjState* st, const double* gsum, GnParamsDev prm, int iter,
                                                          const float* codew, const float* cb0, const float* cblat, float* cbias,
-                                               float* trace /*nullable*/, int n_obj) {
+                                               float* trace /*nullable*/, const float* depths_next /*nullable: forensics*/, int n_obj) {
     __shared__ double A[NSOLVE][NSOLVE + 1];
     const int b = blockIdx.x, tid = threadIdx.x;
     const bool stamp = (b == 0 && tid == 0);
@@ -1212,14 +1269,30 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
         for (int i = 0; i < 16; ++i) s.t_oc[i] = nt[i];
         s.vsum = 0; s.ksum = 0;
         if (stamp) g_solve_clk[3] = wall_clock64();
-        if (!prm.pose_only) derive_iter_state(s, prm.n_depth);
+        if (!prm.pose_only) {
+            derive_iter_state(s, prm.n_depth);
+            if (depths_next) {     // forensics (dsp_batch_set_depth_schedule): the next iteration samples exactly these depths
+                for (int i = 0; i < prm.n_depth; ++i) s.depths[i] = depths_next[MAX_DEPTH_SAMPLES * b + i];
+                s.dmin = s.depths[0];
+                s.dmax = s.depths[prm.n_depth - 1];
+            }
+        }
         if (stamp) g_solve_clk[4] = wall_clock64();
     }
     // 4. the next iteration's per-object code bias (k_code_bias: same k-ordered fmaf chains), while this workgroup holds the new code
     if (!prm.pose_only && cbias) {
         __shared__ float zc[CODE_LEN];
         __syncthreads();
-        if (tid < CODE_LEN) zc[tid] = s.code[tid];
+        if (tid < CODE_LEN) {
+            const float zv = s.code[tid];
+            zc[tid] = zv;
+            // the prepass margin follows the code (wave 0 holds all CODE_LEN = 64 entries)
+            float zmax = fabsf(zv);
+            bool bad = zv != zv;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) { zmax = fmaxf(zmax, __shfl_xor(zmax, d)); bad = bad || __shfl_xor((int)bad, d); }
+            if (tid == 0) s.lp_delta = lp_delta_of(bad ? __int_as_float(0x7f800000) : zmax, prm.lp);
+        }
         __syncthreads();
         for (int e = tid; e < 2 * WIDTH; e += SOLVE_THREADS) {
             const int which = e / WIDTH, o = e % WIDTH;
@@ -1255,7 +1328,7 @@ __global__ __launch_bounds__(256) void k_count_alive(const ObjConst* oc, ObjStat
 
 // final result: T_co = inv(T_oc) (optimizer.py:200; 81-84 for pose-only, which also divides the scale out)
 __global__ void k_finalize(ObjState* st, const float* scale_in, int n_obj, int pose_only, float* out_t, float* out_code,
-                           float* out_loss, int* out_status) {
+                           float* out_loss, int* out_status, float* out_packed) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_obj) return;
     const ObjState& s = st[b];
@@ -1270,6 +1343,12 @@ __global__ void k_finalize(ObjState* st, const float* scale_in, int n_obj, int p
     for (int i = 0; i < CODE_LEN; ++i) out_code[CODE_LEN * b + i] = s.code[i];
     out_loss[b] = s.loss;
     out_status[b] = s.status;
+    // the same results as one DSP_RESULT_WIDTH row (t_cam_obj 16 | code 64 | loss | status): what the multi-GPU gather sends, device-resident
+    float* row = out_packed + (size_t)DSP_RESULT_WIDTH_DEV * b;
+    for (int i = 0; i < 16; ++i) row[i] = out_t[16 * b + i];
+    for (int i = 0; i < CODE_LEN; ++i) row[16 + i] = s.code[i];
+    row[80] = s.loss;
+    row[81] = (float)s.status;
 }
 
 // per-object code contribution to layer 0 and to the latent_in layer (one workgroup per object):
@@ -1297,8 +1376,9 @@ __global__ __launch_bounds__(256) void k_code_bias(const float* codew, const flo
 void launch_code_bias(const float* codew, const float* b0, const float* blat, const float* codes, int code_stride, float* out, int n_obj, hipStream_t s) {
     hipLaunchKernelGGL(k_code_bias, dim3(n_obj), dim3(256), 0, s, codew, b0, blat, codes, code_stride, out);
 }
-void launch_init_state(ObjState* st, const float* t, const float* codes, const float* scale, int B, int D, int pose_only, hipStream_t s) {
-    hipLaunchKernelGGL(k_init_state, dim3((B + 63) / 64), dim3(64), 0, s, st, t, codes, scale, B, D, pose_only);
+void launch_init_state(ObjState* st, const float* t, const float* codes, const float* scale, const float* depths, int B, int D, int pose_only,
+                       const LpDeltaTab& lp, hipStream_t s) {
+    hipLaunchKernelGGL(k_init_state, dim3((B + 63) / 64), dim3(64), 0, s, st, t, codes, scale, depths, B, D, pose_only, lp);
 }
 void launch_sample_count(const ObjConst* oc, ObjState* st, const float* rays, unsigned long long* m, int* c, int D, int maxR, int B, hipStream_t s) {
     hipLaunchKernelGGL(k_sample_count, GRID2(maxR, B), dim3(256), 0, s, oc, st, rays, m, c, D);
@@ -1321,27 +1401,27 @@ void launch_pass_write(const ObjConst* oc, const ObjState* st, const unsigned lo
                        ps.pass, ps.last, ps.hint, ps.plo);
 }
 void launch_pass_update(const ObjConst* oc, const ObjState* st, const unsigned long long* raymask, const int* rayoff, unsigned char* alive,
-                        const float* ssdf, float th, const PassSpec& ps, int maxR, int B, hipStream_t s) {
-    hipLaunchKernelGGL(k_pass_update, GRID2(maxR, B), dim3(256), 0, s, oc, st, raymask, rayoff, alive, ssdf, th, ps.j0, ps.j1, ps.n_depth,
+                        const float* ssdf, float th, int use_lp_delta, const PassSpec& ps, int maxR, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_pass_update, GRID2(maxR, B), dim3(256), 0, s, oc, st, raymask, rayoff, alive, ssdf, th, use_lp_delta, ps.j0, ps.j1, ps.n_depth,
                        ps.pass, ps.last, ps.hint, ps.plo);
 }
-void launch_band_select(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff, const float* ssdf, float thd,
-                        int* pcnt, int* poff, int* plist, int maxR, int B, hipStream_t s) {
-    hipLaunchKernelGGL(k_band_count, GRID2(maxR, B), dim3(256), 0, s, oc, st, raymask, rayoff, ssdf, thd, pcnt);
+void launch_band_select(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff, const float* ssdf, float th,
+                        unsigned guard_salt, int* pcnt, int* poff, int* plist, int maxR, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_band_count, GRID2(maxR, B), dim3(256), 0, s, oc, st, raymask, rayoff, ssdf, th, guard_salt, pcnt);
     hipLaunchKernelGGL(k_scan_rays, dim3(B), dim3(256), 0, s, oc, st, pcnt, poff, 2);
-    hipLaunchKernelGGL(k_band_write, GRID2(maxR, B), dim3(256), 0, s, oc, st, raymask, rayoff, ssdf, thd, poff, plist);
+    hipLaunchKernelGGL(k_band_write, GRID2(maxR, B), dim3(256), 0, s, oc, st, raymask, rayoff, ssdf, th, guard_salt, poff, plist);
 }
-void launch_prepass_audit(const ObjConst* oc, const ObjState* st, const float* ssdf, const float* saudit, float th, float thd, unsigned* out,
+void launch_prepass_audit(const ObjConst* oc, const ObjState* st, const float* ssdf, const float* saudit, float th, unsigned* out,
                           int B, hipStream_t s) {
-    hipLaunchKernelGGL(k_prepass_audit, dim3(64, B), dim3(256), 0, s, oc, st, ssdf, saudit, th, thd, out);
+    hipLaunchKernelGGL(k_prepass_audit, dim3(64, B), dim3(256), 0, s, oc, st, ssdf, saudit, th, out);
 }
 void launch_front_fused(const ObjConst* oc, ObjState* st, const float* rays, const float* pts, unsigned long long* raymask, int* raycnt, int* rayoff,
                         float4* spts, float* ssdf, unsigned char* alive, float4* jpts, float2* jaux, int D, int B, hipStream_t s) {
     hipLaunchKernelGGL(k_front_fused, dim3(B), dim3(FUSED_THREADS), 0, s, oc, st, rays, pts, raymask, raycnt, rayoff, spts, ssdf, alive, jpts, jaux, D);
 }
-void launch_band_fused(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff, const float* ssdf, float thd, int* pcnt,
-                       int* poff, int* plist, const float4* spts, float4* jpts, int* srow, int B, hipStream_t s) {
-    hipLaunchKernelGGL(k_band_fused, dim3(B), dim3(FUSED_THREADS), 0, s, oc, st, raymask, rayoff, ssdf, thd, pcnt, poff, plist, spts, jpts, srow);
+void launch_band_fused(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff, const float* ssdf, float th, unsigned guard_salt,
+                       int* pcnt, int* poff, int* plist, const float4* spts, float4* jpts, int* srow, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_band_fused, dim3(B), dim3(FUSED_THREADS), 0, s, oc, st, raymask, rayoff, ssdf, th, guard_salt, pcnt, poff, plist, spts, jpts, srow);
 }
 void launch_render_tail_fused(const ObjConst* oc, ObjState* st, const int* raycnt, const int* rayoff, const float4* spts, const float* sdeds,
                               const float* ray_res, const int* kcnt, int* koff, const int* mcnt, float4* jpts, float2* jaux, const int* srow, int* jrow,
@@ -1377,16 +1457,16 @@ void launch_jrows(const ObjConst* oc, const ObjState* st, const float4* jpts, co
     hipLaunchKernelGGL(k_jrows, dim3((cap + 255) / 256), dim3(256), 0, s, oc, st, jpts, jaux, jgrad, jrow, term, rows);
 }
 void launch_solve(const ObjConst* oc, ObjState* st, const float* partials, double* gsum, int n_slices, const GnParamsDev& prm, int iter,
-                  float* trace, const float* codew, const float* b0, const float* blat, float* cbias, int B, hipStream_t s) {
+                  float* trace, const float* codew, const float* b0, const float* blat, float* cbias, const float* depths_next, int B, hipStream_t s) {
     hipLaunchKernelGGL(k_gram_reduce, dim3((72 * 72 + 255) / 256, B, prm.pose_only ? 1 : 2), dim3(256), 0, s, st, partials, n_slices, gsum);
-    hipLaunchKernelGGL(k_solve, dim3(B), dim3(SOLVE_THREADS), 0, s, oc, st, gsum, prm, iter, codew, b0, blat, cbias, trace, B);
+    hipLaunchKernelGGL(k_solve, dim3(B), dim3(SOLVE_THREADS), 0, s, oc, st, gsum, prm, iter, codew, b0, blat, cbias, trace, depths_next, B);
 }
 void launch_inlier_filter(const ObjConst* oc, ObjState* st, const float* jgrad, unsigned char* alive, int maxM, int B, hipStream_t s) {
     hipLaunchKernelGGL(k_inlier_filter, GRID2(maxM, B), dim3(256), 0, s, oc, st, jgrad, alive);
     hipLaunchKernelGGL(k_count_alive, dim3(B), dim3(256), 0, s, oc, st, alive);
 }
-void launch_finalize(ObjState* st, const float* scale, int B, int pose_only, float* t, float* code, float* loss, int* status, hipStream_t s) {
-    hipLaunchKernelGGL(k_finalize, dim3((B + 63) / 64), dim3(64), 0, s, st, scale, B, pose_only, t, code, loss, status);
+void launch_finalize(ObjState* st, const float* scale, int B, int pose_only, float* t, float* code, float* loss, int* status, float* packed, hipStream_t s) {
+    hipLaunchKernelGGL(k_finalize, dim3((B + 63) / 64), dim3(64), 0, s, st, scale, B, pose_only, t, code, loss, status, packed);
 }
 
 hipError_t debug_solve_clocks(unsigned long long* out8) { return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_solve_clk), 64); }

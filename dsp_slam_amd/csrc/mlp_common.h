@@ -90,4 +90,28 @@ __device__ __forceinline__ float relu1(float x) {
     return r;
 }
 
+// Always-on guard of the low-precision pre-classification (DESIGN.md "Prepass").  The prepass is exact as long as
+// |sdf_lp - sdf_fp32| < lp_delta for every sample it classifies.  The fp32 kernels re-decode every sample the prepass left inside the
+// widened band, plus a 1/64 sample of the ones it classified (k_band_*: guard samples), and each of those still holds its prepass value
+// where the fp32 value is about to be stored: compare them.  A difference of half the object's margin or more is a TRIP (counted per
+// wave, per object): the host then re-runs the batch with the prepass off (batch_run) -- results never depend on a margin that the
+// workload itself has shown to be thin.  The largest difference seen is kept as well (dsp_stats.prepass_guard_max_err).
+// `active`: this lane stores a sample's fp32 sdf; old_lp: what the slot held (1.0f = never decoded by the prepass: no comparison).
+__device__ __forceinline__ void prepass_guard(const MlpArgs& a, int obj, bool active, float old_lp, float y) {
+    float err = 0.f;
+    if (active && old_lp != 1.0f) {
+        err = fabsf(old_lp - y);
+        if (!(err < 1.0f)) err = 1.0f;                  // NaN / inf prepass value
+    }
+    float m = err;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    if (m > 0.f && (threadIdx.x & 63) == 0) {
+        unsigned* w = a.guard + (size_t)obj * a.guard_stride;
+        const float tol = 0.5f * __uint_as_float(w[0]);
+        atomicMax(w + 2, __float_as_uint(m));
+        if (!(m < tol)) atomicAdd(w + 1, 1u);
+    }
+}
+
 }  // namespace dsp

@@ -373,6 +373,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
                 part += __shfl_xor(part, 32);
                 y = tanhf(part + a.b_last);
                 if (!BWD) {
+                    if (a.guard) prepass_guard(a, td.z, valid && g == 0, (valid && g == 0) ? a.out_sdf[a.index ? src : pidx + td.w] : 1.0f, y);
                     if (valid && g == 0) a.out_sdf[a.index ? src : pidx + td.w] = y;
                     if (MODE == 1 && valid && y > -a.th && y < a.th) {
                         // a candidate row of the render term (loss.py:88): export this lane's 64 mask words (8 layers x 8
@@ -412,7 +413,11 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
             const float s2 = __shfl(skipx[2], pl + 48);
             const float sk = (g == 0) ? s0 : (g == 1) ? s1 : s2;
             if (valid) orow[64 + g] = (g < 3) ? (gfirst + sk) : y;
-            if (MODE == 2 && a.sdf_scatter && valid && g == 3 && tile >= *a.scatter_tile_begin) a.sdf_scatter[__float_as_int(pt.w)] = y;
+            if (MODE == 2 && a.sdf_scatter && tile >= *a.scatter_tile_begin) {
+                const bool sc = valid && g == 3;
+                if (a.guard) prepass_guard(a, td.z, sc, sc ? a.sdf_scatter[__float_as_int(pt.w)] : 1.0f, y);
+                if (sc) a.sdf_scatter[__float_as_int(pt.w)] = y;
+            }
         }
         // stores and LDS-DMA share vmcnt and may retire out of order: drain before counting again
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

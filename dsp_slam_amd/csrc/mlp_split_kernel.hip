@@ -298,7 +298,11 @@ __global__ __launch_bounds__(256, 1) void mlp_split_kernel(const MlpArgs a) {
                 part += __shfl_xor(part, 32);
                 y = tanhf(part + a.b_last);
                 if (!BWD) {
-                    if (wave == 0 && g == 0 && valid) a.out_sdf[a.index ? src : pidx + td.w] = y;
+                    if (wave == 0) {      // wave-uniform: the four waves of a tile hold the same 16 points
+                        const bool st = g == 0 && valid;
+                        if (a.guard) prepass_guard(a, td.z, st, st ? a.out_sdf[a.index ? src : pidx + td.w] : 1.0f, y);
+                        if (st) a.out_sdf[a.index ? src : pidx + td.w] = y;
+                    }
                     continue;
                 }
                 const float d = 1.f - y * y;
@@ -340,7 +344,11 @@ __global__ __launch_bounds__(256, 1) void mlp_split_kernel(const MlpArgs a) {
             const float s2 = __shfl(skipx[2], pl + 48);
             const float sk = (g == 0) ? s0 : (g == 1) ? s1 : s2;
             if (valid) orow[64 + g] = (g < 3) ? (gfirst + sk) : y;
-            if (a.sdf_scatter && valid && g == 3 && tile >= *a.scatter_tile_begin) a.sdf_scatter[__float_as_int(pt.w)] = y;
+            if (a.sdf_scatter && tile >= *a.scatter_tile_begin) {
+                const bool sc = valid && g == 3;
+                if (a.guard) prepass_guard(a, td.z, sc, sc ? a.sdf_scatter[__float_as_int(pt.w)] : 1.0f, y);
+                if (sc) a.sdf_scatter[__float_as_int(pt.w)] = y;
+            }
         }
         // stores and LDS-DMA share vmcnt and may retire out of order: drain before counting again
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

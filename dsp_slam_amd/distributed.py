@@ -68,3 +68,24 @@ def gather_results(local_packed, shards, dist, device=None, dst=0):
         return None
     parts = [bufs[r][: shards[r][1] - shards[r][0]].cpu().numpy() for r in range(world)]
     return np.concatenate(parts, 0)
+
+
+def gather_results_device(batches, shards, dist, device, dst=0):
+    """The same single collective without a host bounce: every batch's packed result rows (kept in HBM by the library) are copied
+    device-to-device into this rank's send tensor, ONE dist.gather (RCCL over xGMI) moves the blocks to rank `dst`, ONE device-to-host copy
+    delivers them.  batches: this rank's engine.Batch objects, in object order (their object counts add up to this rank's shard)."""
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
+    n_max = max(b - a for a, b in shards)
+    mine = torch.zeros((max(n_max, 1), RESULT_WIDTH), dtype=torch.float32, device=device)
+    row = 0
+    for bt in batches:
+        bt.results_packed_to_device(mine.data_ptr() + row * RESULT_WIDTH * 4)
+        row += bt.n
+    assert row == shards[rank][1] - shards[rank][0], "the batches do not cover this rank's shard"
+    bufs = [torch.empty_like(mine) for _ in range(world)] if rank == dst else None
+    dist.gather(mine, bufs, dst=dst)
+    if rank != dst:
+        return None
+    host = torch.stack(bufs).cpu().numpy()
+    return np.concatenate([host[r, : shards[r][1] - shards[r][0]] for r in range(world)], 0)

@@ -83,6 +83,51 @@ class Batch(object):
     def set_prepass_audit(self, on=True):
         L.check(L.load().dsp_batch_set_prepass_audit(self._h, int(bool(on))), self.engine._h, "dsp_batch_set_prepass_audit")
 
+    def set_prepass_guard(self, on=True):
+        """The always-on guard of the prepass (include/dsp_gn.h): off only to see what an unguarded run would return."""
+        L.check(L.load().dsp_batch_set_prepass_guard(self._h, int(bool(on))), self.engine._h, "dsp_batch_set_prepass_guard")
+
+    def set_start_state(self, t_obj_cam=None, codes=None, depths=None):
+        """Testing / forensics: start the following runs from these camera->object matrices (taken bit for bit) and / or codes; depths
+        (per object, num_depth_samples values): the first iteration samples the rays at exactly these depths."""
+        t = None if t_obj_cam is None else L.f32(np.stack([np.asarray(x, np.float32).reshape(4, 4) for x in t_obj_cam]))
+        c = None if codes is None else L.f32(np.stack([L.code64(x) for x in codes]))
+        d = None
+        if depths is not None:
+            d = np.zeros((self.n, 64), np.float32)
+            for i, row in enumerate(depths):
+                row = np.asarray(row, np.float32).reshape(-1)
+                d[i, :row.shape[0]] = row
+        L.check(L.load().dsp_batch_set_start_state(self._h, L.ptr(t), L.ptr(c), L.ptr(d)), self.engine._h, "dsp_batch_set_start_state")
+
+    def set_depth_schedule(self, depths=None):
+        """Testing / forensics: depths[e][i] = the depth samples object i uses in iteration e (None = derive them from the pose again)."""
+        if depths is None:
+            L.check(L.load().dsp_batch_set_depth_schedule(self._h, None, 0), self.engine._h, "dsp_batch_set_depth_schedule")
+            return
+        n_it = len(depths)
+        d = np.zeros((n_it, self.n, 64), np.float32)
+        for e in range(n_it):
+            for i in range(self.n):
+                row = np.asarray(depths[e][i], np.float32).reshape(-1)
+                d[e, i, :row.shape[0]] = row
+        L.check(L.load().dsp_batch_set_depth_schedule(self._h, L.ptr(d), n_it), self.engine._h, "dsp_batch_set_depth_schedule")
+
+    def set_iterations(self, n):
+        L.check(L.load().dsp_batch_set_iterations(self._h, int(n)), self.engine._h, "dsp_batch_set_iterations")
+        self.iters = int(n)
+
+    def debug_samples(self, obj, n_rays, n_depth):
+        """(in-sphere mask (n_rays, n_depth) bool, sdf grid, de_ds grid) the last iteration of the last run left for object obj
+        (NaN outside the sphere; de_ds != 0 marks a kept sample)."""
+        rm = np.zeros(n_rays, np.uint64)
+        sdf = np.zeros((n_rays, n_depth), np.float32)
+        deds = np.zeros((n_rays, n_depth), np.float32)
+        L.check(L.load().dsp_batch_debug_samples(self._h, int(obj), L.ptr(rm, C.POINTER(C.c_uint64)), L.ptr(sdf), L.ptr(deds), sdf.size),
+                self.engine._h, "dsp_batch_debug_samples")
+        mask = ((rm[:, None] >> np.arange(n_depth, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(bool)
+        return mask, sdf, deds
+
     def set_speculative_band(self, mode):
         """-1 = automatic, 0 = band samples get a forward launch of their own, 1 = they go straight into the jacobian launch (latency path)."""
         L.check(L.load().dsp_batch_set_speculative_band(self._h, int(mode)), self.engine._h, "dsp_batch_set_speculative_band")
@@ -107,6 +152,11 @@ class Batch(object):
         L.check(L.load().dsp_batch_results(self._h, L.ptr(t), L.ptr(code), L.ptr(loss), L.ptr(status, L.c_i32p)),
                 self.engine._h, "dsp_batch_results")
         return t, np.ascontiguousarray(code[:, :self.engine.code_len]), loss, status
+
+    def results_packed_to_device(self, dst_ptr):
+        """Copy the packed result rows (n x 82 float32, distributed.RESULT_WIDTH) device-to-device to dst_ptr (e.g. a torch tensor's data_ptr() on
+        this batch's GPU): the results never touch the host in front of the multi-GPU gather."""
+        L.check(L.load().dsp_batch_results_packed_dev(self._h, C.c_void_p(int(dst_ptr))), self.engine._h, "dsp_batch_results_packed_dev")
 
     def stats(self):
         s = L.Stats()
@@ -147,6 +197,16 @@ def gather_results_c(engines, packed):
     cnt = np.array([b.shape[0] for b in blocks], np.int32)
     out = np.zeros((int(cnt.sum()), 82), np.float32)
     L.check(L.load().dsp_gather_results(hs, n, ptrs, L.ptr(cnt, L.c_i32p), L.ptr(out)), engines[0]._h, "dsp_gather_results")
+    return out
+
+
+def gather_batches_c(batches):
+    """dsp_gather_batch_results: the same gather straight from device-resident batches (one per GPU, each run before): device ->
+    ncclGather -> host once."""
+    n = len(batches)
+    hs = (C.c_void_p * n)(*[b._h for b in batches])
+    out = np.zeros((sum(b.n for b in batches), 82), np.float32)
+    L.check(L.load().dsp_gather_batch_results(hs, n, L.ptr(out)), batches[0].engine._h, "dsp_gather_batch_results")
     return out
 
 
@@ -211,6 +271,14 @@ class Engine(object):
         err, delta = C.c_float(0), C.c_float(0)
         L.check(L.load().dsp_prepass_calibration(self._h, int(dtype), C.byref(err), C.byref(delta)), self._h, "dsp_prepass_calibration")
         return err.value, delta.value
+
+    def prepass_calibration_table(self, dtype=L.PREPASS_F16):
+        """dict(mags, max_err, delta: 5 entries each; guard_err): the margin as a function of the code's largest entry."""
+        m, e, d = (np.zeros(5, np.float32) for _ in range(3))
+        g = C.c_float(0)
+        L.check(L.load().dsp_prepass_calibration_table(self._h, int(dtype), L.ptr(m), L.ptr(e), L.ptr(d), C.byref(g)), self._h,
+                "dsp_prepass_calibration_table")
+        return dict(mags=m, max_err=e, delta=d, guard_err=g.value)
 
     def decode_sdf_multi(self, codes, pts):
         """(n_codes, 64) codes x one shared (n, 3) point set -> (n_codes, n) sdf, one kernel launch."""

@@ -86,6 +86,12 @@ typedef struct dsp_stats {
     float prepass_max_err;       /* audit only: max |sdf_lp - sdf_fp32| over the audited samples */
     double prepass_misclassified;/* audit only: samples classified against their fp32 value (must be 0) */
     double prepass_audited;      /* audit only: samples compared */
+    /* always-on prepass guard (ABI version 3): every sample the fp32 kernel re-decodes -- the widened band plus a 1/64 sample of the
+     * classified ones -- is compared with the prepass value it replaces */
+    double prepass_guard_trips;  /* waves that saw |sdf_lp - sdf_fp32| >= half the object's margin (0 in a healthy run) */
+    double prepass_guard_objects;/* objects with at least one trip */
+    float prepass_guard_max_err; /* largest |sdf_lp - sdf_fp32| over the compared samples */
+    int32_t prepass_guard_rerun; /* 1: the guard tripped and the results come from a second run with the prepass off */
 } dsp_stats;
 
 /* ---- lifetime --------------------------------------------------------------------------------- */
@@ -95,6 +101,12 @@ int dsp_create(const dsp_decoder_desc* decoder, int device, dsp_handle** out);
 void dsp_destroy(dsp_handle* h);
 const char* dsp_last_error(const dsp_handle* h);   /* h may be NULL: error of the last failed dsp_create */
 int dsp_abi_version(void);
+/* Which compiler produced this library (hipcc --version at build time, clang version, HIP header version) -- the decoder kernels rely on
+ * properties of the generated code that the build checks by disassembly (dsp_slam_amd/build.py: check_isa); and the HIP runtime / driver
+ * versions of the box it is running on (hipRuntimeGetVersion / hipDriverGetVersion encodings). */
+const char* dsp_build_info(void);
+int dsp_runtime_versions(int* hip_runtime, int* hip_driver);
+int dsp_device_count(void);   /* number of gfx950 devices dsp_create accepts (ordinals 0 .. n-1); 0 without a HIP device */
 
 /* ---- decoder ---------------------------------------------------------------------------------- */
 /* decode_sdf(decoder, lat_vec, x)  -- reconstruct/loss_utils.py:51-79.  pts (n,3) object frame -> sdf (n). */
@@ -194,11 +206,23 @@ int dsp_batch_set_ray_pass_bounds(dsp_batch* b, const int32_t* bounds, int n_pas
  * measures the error on the actual workload; results are then identical, bit for bit, to prepass off.
  * mode: -1 automatic (f16 when the decoder geometry is supported), DSP_PREPASS_OFF / _F16 / _BF16; delta < 0 = default. */
 int dsp_batch_set_prepass(dsp_batch* b, int mode, float delta);
-/* The calibration dsp_create made for this decoder: largest |sdf_lp - sdf_fp32| it measured and the margin it derived (DSP_E_STATE when the
- * decoder's geometry has no prepass kernel). */
+/* The calibration dsp_create made for this decoder at a ZERO code: largest |sdf_lp - sdf_fp32| it measured and the margin it derived
+ * (DSP_E_STATE when the decoder's geometry has no prepass kernel); the full table follows. */
 int dsp_prepass_calibration(dsp_handle* h, int dtype, float* max_err, float* delta);
+/* The whole calibration: the prepass error grows with the hidden activations, hence with the code, so dsp_create measures it with codes
+ * drawn uniformly in +-mag on every entry for mag in {0, 0.15, 0.5, 1, 2} (5 entries each: mags, largest error, margin = max(floor,
+ * 5 x largest error up to that magnitude), capped at 0.5).  Every object's margin follows the largest entry of its CURRENT code,
+ * piecewise linearly through this table, re-evaluated after every Gauss-Newton step.  guard_err: largest error a guard trip on this
+ * handle has reported (the margins returned are already raised to 4 x that).  Any pointer may be NULL. */
+int dsp_prepass_calibration_table(dsp_handle* h, int dtype, float* mags, float* max_err, float* delta, float* guard_err);
 /* Audit: every run also decodes all in-sphere samples in fp32 and fills dsp_stats.prepass_max_err / _misclassified / _audited. */
 int dsp_batch_set_prepass_audit(dsp_batch* b, int on);
+/* The guard is ON by default and costs ~1.5 % more fp32 points: with the prepass on, the fp32 kernel also re-decodes a 1/64 sample of
+ * the samples the prepass classified (a different one every launch) and compares every sample it decodes with the prepass value it
+ * replaces.  A difference of half the object's margin or more trips the guard: dsp_batch_run then runs the batch AGAIN with the
+ * prepass off and returns those results (dsp_stats.prepass_guard_rerun = 1), and the handle's margins are raised to 4 x the error
+ * seen.  on = 0 turns the guard off (tests: what an unguarded run would have returned). */
+int dsp_batch_set_prepass_guard(dsp_batch* b, int on);
 /* Render rows (kept ray samples) need the decoder's input gradient at points the forward launches of the same iteration
  * already decoded.  With mask reuse on, those launches export the relu masks of band samples (|sdf| < cut_off, 512 B each)
  * and the render rows run the backward sweep only, in a launch of their own after the surface points' forward + backward
@@ -220,6 +244,24 @@ int dsp_batch_set_fused_bookkeeping(dsp_batch* b, int mode);
  * -1 = automatic (fused bookkeeping on, mask reuse off, surface points + band samples fit one round of 16-point tiles), 0 = off,
  * 1 = on where applicable.  Results are identical for every setting. */
 int dsp_batch_set_speculative_band(dsp_batch* b, int mode);
+/* Testing / forensics: start the following runs from the given camera->object matrices (n_objects x 16, used as they are -- no
+ * inversion, so a recorded state of the reference can be injected bit for bit) and / or codes (n_objects x 64); NULL t_obj_cam returns
+ * to the uploaded object->camera estimates.  depths (optional, n_objects x 64, needs t_obj_cam): the FIRST iteration samples the rays at
+ * exactly these num_depth_samples depths instead of deriving them from the pose (optimizer.py:120-125) -- the reference derives them in
+ * fp32 LAPACK / powf arithmetic that can differ from this library's by 1-2 ulp, which is enough to move samples across the render term's
+ * thresholds.  dsp_batch_set_iterations changes the iteration count of the following runs. */
+int dsp_batch_set_start_state(dsp_batch* b, const float* t_obj_cam, const float* codes, const float* depths);
+int dsp_batch_set_iterations(dsp_batch* b, int32_t n);
+/* Testing / forensics: iteration e < n_iterations of the following runs samples the rays at depths[(e * n_objects + i) * 64 ..] instead of
+ * the depths derived from the pose (n_iterations = 0 turns the schedule off).  The reference derives the 50 depths from torch.inverse /
+ * torch.det / pow / linspace in float32 (optimizer.py:120-125), whose last bit depends on the LAPACK library; feeding the depths it
+ * RECORDED isolates that source of threshold flips from the decoder's own round-off in chained comparisons. */
+int dsp_batch_set_depth_schedule(dsp_batch* b, const float* depths, int32_t n_iterations);
+/* Testing / forensics: the per-sample arrays the LAST iteration of the last run left behind for object obj, expanded to
+ * (n_rays x num_depth_samples) grids: raymask (n_rays; bit j = sample j lies inside the unit sphere), ssdf (the sdf the occupancy
+ * scan read: fp32 inside the band, the prepass value or the placeholder 1.0 elsewhere; NaN = not in the sphere), sdeds (de_ds of a kept
+ * sample, 0 = not kept, NaN = not in the sphere).  cap = floats available in ssdf / sdeds (>= n_rays * num_depth_samples). */
+int dsp_batch_debug_samples(dsp_batch* b, int32_t obj, uint64_t* raymask, float* ssdf, float* sdeds, int64_t cap);
 /* Record per-iteration traces during the following runs (testing; costs ~21 KB per object-iteration). */
 int dsp_batch_enable_trace(dsp_batch* b, int on);
 /* Per-iteration trace of the last run (testing): for iteration e < num_iterations and object i,
@@ -240,6 +282,14 @@ void dsp_pack_results(int32_t n, const float* t_cam_obj, const float* codes, con
  * device-to-device to handles[0]'s GPU by ONE RCCL ncclGather (xGMI; uneven blocks padded to the largest), and returned in `out`
  * concatenated in handle order (sum(n_objects) x DSP_RESULT_WIDTH).  librccl is loaded on first use (dlopen), not linked. */
 int dsp_gather_results(dsp_handle* const* handles, int32_t n_handles, const float* const* results, const int32_t* n_objects, float* out);
+/* The same gather straight from device-resident batches (one per GPU, each run before): every batch keeps its results as packed rows in
+ * HBM, so the data goes device -> ncclGather -> host ONCE (no host bounce in front of the collective).  out: sum of the batches' object
+ * counts x DSP_RESULT_WIDTH, in batch order.  Both gathers hold the mutex of EVERY handle involved (taken in a fixed order) for the whole
+ * call: a dsp_batch_run issued on one of the handles by its own host thread waits, it cannot interleave with the collective. */
+int dsp_gather_batch_results(dsp_batch* const* batches, int32_t n_batches, float* out);
+/* Copy a batch's packed result rows (n_objects x DSP_RESULT_WIDTH) to a DEVICE buffer on the batch's GPU -- e.g. a PyTorch-ROCm tensor's
+ * data_ptr() that a torch.distributed collective then sends (dsp_slam_amd/distributed.py: gather_results_device). */
+int dsp_batch_results_packed_dev(dsp_batch* b, float* dst_dev);
 
 #ifdef __cplusplus
 }

@@ -340,6 +340,8 @@ def compute_render_loss(dec, ray_directions, depth_obs, t_obj_cam, sampled_ray_d
     acc_z = np.where(l_idx < gy[:, None], F32(0), acc)                      # :121
     de_do = (np.sum(acc_z, axis=-1, dtype=F32) / (F32(1.) - o_k)).astype(F32)
     nz = de_do > F32(1e-2)                                                  # :125
+    if stats is not None:      # forensics: everything a threshold decision was made on (tests name flipped samples by these)
+        stats.update(norm=nrm, band=(gx.copy(), gy.copy()), de_do_band=de_do.copy())
     de_do = de_do[nz]
     d_u = d_u[nz]
     delta_d = F32((d_max - d_min) / F32(n_d - 1))
@@ -444,8 +446,9 @@ def reconstruct_object(dec, prm, t_cam_obj, pts, rays, depth, code=None, trace=N
         d_min = F32(t_co[2, 3] - F32(1.0) * scale)
         d_max = F32(t_co[2, 3] + F32(1.0) * scale)
         sampled = linspace_f32(d_min, d_max, prm.num_depth_samples)          # :125
-        if sampled_override is not None:   # tests only: linearise on exactly these depth samples (single-iteration runs)
-            sampled = np.asarray(sampled_override, F32)[:prm.num_depth_samples].copy()
+        if sampled_override is not None:   # tests only: linearise on exactly these depth samples (one row per iteration, or one row for a single-iteration run)
+            so = np.asarray(sampled_override, F32)
+            sampled = (so[e] if so.ndim == 2 else so)[:prm.num_depth_samples].copy()
             d_max = sampled[-1]
         derived_depths = sampled.copy()
         depth_obs[n_fg:] = F32(1.1) * d_max                                  # :126
@@ -485,7 +488,7 @@ def reconstruct_object(dec, prm, t_cam_obj, pts, rays, depth, code=None, trace=N
         dx = (_inv(h) @ b).astype(F32)                                       # :186
         delta_t = exp_sim3(F32(prm.lr) * dx[:pd])                            # :190
         if trace is not None:
-            trace.append(dict(V=st["V"], m=st["m"], K=st["K"], vsum=set_checksum(*st["valid"]), ksum=set_checksum(*st["kept"]),
+            trace.append(dict(V=st["V"], m=st["m"], K=st["K"], vsum=set_checksum(*st["valid"]), ksum=set_checksum(*st["kept"]), sets=st,
                               H=h.copy(), b=b.copy(), dx=dx.copy(), depths=derived_depths,
                               t_obj_cam=t_obj_cam.copy(), code=z.copy(), loss=loss,
                               sdf_loss=float(sdf_loss), render_loss=float(render_loss)))

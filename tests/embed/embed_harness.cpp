@@ -7,6 +7,11 @@
 //               src/LocalMapping_util.cc:179-191 (reconstruct_object -> is_good / t_cam_obj / code),
 //               src/LocalMapping_util.cc:391-413 (5-argument form with a warm-start code, loss, code_len),
 //               src/LocalMapping_util.cc:194-196,426-428 (extract_mesh_from_code -> vertices MatrixXf / faces MatrixXi).
+// With a 4th argument "mono": the MONOCULAR sequence of src/LocalMapping_util.cc:391-428 instead -- 5-argument call with the map object's
+// 64-float vShapeCode, the 180-degree-yaw-flipped second call for an object that is not reconstructed yet, the `loss` comparison that
+// picks one of the two, t_cam_obj -> Matrix4f, code_len read as int, the code cast to a FIXED-SIZE Vector<float,32> when code_len == 32
+// (a size mismatch would throw cast_error there) and copied into the head of a zeroed 64-vector, and that 64-vector handed to
+// extract_mesh_from_code.
 // Eigen is column-major and pybind11's Eigen caster hands numpy Fortran-ordered float32 COPIES; the harness builds the
 // same kind of arrays (py::array::f_style).  Inputs are read from an .npz the Python test wrote; results are printed as
 // "key v0 v1 ..." lines for the test to compare.
@@ -38,6 +43,7 @@ struct PyThreadStateLock {   // reference include/System.h:56-70
 int main(int argc, char** argv) {
     if (argc < 4) { std::fprintf(stderr, "usage: embed_harness <mirror_dir> <cfg.json> <inputs.npz>\n"); return 2; }
     const std::string mirror = argv[1], cfg_file = argv[2], npz = argv[3];
+    const bool mono = argc > 4 && std::string(argv[4]) == "mono";
     std::setvbuf(stdout, nullptr, _IOLBF, 1 << 16);                            // whole lines, so that Python's own prints cannot land inside one
     py::initialize_interpreter();                                              // System.cc:90
     py::object pyCfg, pyDecoder;
@@ -60,6 +66,40 @@ int main(int argc, char** argv) {
             py::object data = py::module::import("numpy").attr("load")(npz);
             auto F = [&](const char* k) { return farr(data[k]); };                // Fortran-ordered float32 copy, like the Eigen caster
 
+            if (mono) {
+                // ProcessDetectedObjects (monocular)                                      (LocalMapping_util.cc:391-428)
+                py::module np = py::module::import("numpy");
+                farr t_co = F("t_cam_obj");
+                py::object shape_code = np.attr("zeros")(64, "float32");                 // pMO->vShapeCode: Vector<float,64>, zero before the first reconstruction
+                py::object a = pyOptimizer.attr("reconstruct_object")(t_co, F("pts"), F("rays"), F("depth"), farr(shape_code));
+                // flipped_Two.col(0) *= -1; flipped_Two.col(2) *= -1  ->  the same columns of SE3Tcw * Two
+                farr t_flip(t_co.attr("copy")("F"));
+                {
+                    auto m = t_flip.mutable_unchecked<2>();
+                    for (int r = 0; r < 4; ++r) { m(r, 0) = -m(r, 0); m(r, 2) = -m(r, 2); }
+                }
+                py::object b = pyOptimizer.attr("reconstruct_object")(t_flip, F("pts"), F("rays"), F("depth"), farr(shape_code));
+                const float loss_a = a.attr("loss").cast<float>(), loss_b = b.attr("loss").cast<float>();     // read unconditionally, as the reference does (:405)
+                std::printf("mono_loss %.9g %.9g\n", loss_a, loss_b);
+                py::object pick = loss_a > loss_b ? b : a;
+                std::printf("mono_pick %d\n", loss_a > loss_b ? 1 : 0);
+                print_arr("mono_t_cam_obj", pick.attr("t_cam_obj"));                     // .cast<Eigen::Matrix4f>()
+                const int code_len = pyOptimizer.attr("code_len").cast<int>();
+                std::printf("code_len %d\n", code_len);
+                py::array_t<float, py::array::c_style | py::array::forcecast> code_arr(pick.attr("code"));
+                // Eigen::Vector<float, 32> / <float, 64> are fixed-size: pybind11's caster refuses any other length
+                if (code_arr.ndim() != 1 || code_arr.shape(0) != (code_len == 32 ? 32 : 64)) throw std::runtime_error("code length does not fit the fixed-size Eigen vector");
+                std::vector<float> code64(64, 0.f);
+                for (py::ssize_t i = 0; i < code_arr.shape(0); ++i) code64[i] = code_arr.data()[i];
+                print_arr("mono_code", pick.attr("code"));
+                py::array_t<float> code64_arr(64, code64.data());
+                py::object pyMesh = pyMeshExtractor.attr("extract_mesh_from_code")(code64_arr);     // the zero-padded 64-vector, also for a 32-D decoder
+                py::array_t<float, py::array::c_style | py::array::forcecast> verts(pyMesh.attr("vertices"));
+                py::array_t<int, py::array::c_style | py::array::forcecast> faces(pyMesh.attr("faces"));
+                std::printf("mesh_shape %lld %lld %lld %lld\n", (long long)verts.shape(0), (long long)verts.shape(1), (long long)faces.shape(0), (long long)faces.shape(1));
+                print_arr("mesh_vertices", pyMesh.attr("vertices"));
+                return;
+            }
             // GetNewObservations: pose-only, result cast to a 4x4 matrix           (LocalMapping_util.cc:109-110)
             py::object se3 = pyOptimizer.attr("estimate_pose_cam_obj")(F("pose_t_co_se3"), data["pose_scale"].cast<float>(), F("pose_pts"), F("pose_code"));
             print_arr("pose_only", se3);

@@ -1,0 +1,115 @@
+"""Divergence forensics for the chained Gauss-Newton comparison (test infrastructure).
+
+The render term decides set membership through three thresholds (reconstruct/loss.py:68 `norm < 1`, :88 `|sdf| < th`, :125
+`de_do > 1e-2`).  A sample within round-off of a threshold may land on the other side in an implementation whose float32 sums are
+ordered differently (MFMA fmaf chain vs BLAS sgemm: 1e-7 on sdf), and from there on the two runs follow different -- equally valid --
+trajectories.  These helpers NAME such flips: which (ray, depth index) switched which set, at which threshold, and how far from the
+threshold the oracle sees it, so that a departure of the chained result is attributed to specific samples instead of argued
+statistically.
+"""
+import numpy as np
+
+from oracle import dsp_oracle as O
+
+# a flip counts as "explained by round-off" when the oracle's value lies this close to the threshold it crossed
+TOL_NORM = 2e-6        # |‖p‖ - 1|: a few ulp of 1.0 (point transform in fp32)
+TOL_SDF = 5e-6         # ||sdf| - th|: the decoder-level agreement bound (tests/test_gpu_parity.py::test_decode_sdf_vs_oracle)
+TOL_DEDO_REL = 2e-2    # |de_do - 1e-2| / 1e-2: de_do ~ 1e-2 only behind samples with 1 - o ~ 1e-2, where an sdf round-off of 2e-7
+                       # is a relative error of 1e-3 per factor of the transmittance product
+
+
+def oracle_linearisation(dec, oprm, pts, rays, depth, t_obj_cam, code, depths=None, sdf_jitter=0.0):
+    """One GN linearisation of the oracle at (t_obj_cam, code); depths: sample the rays at exactly these depths. -> trace dict (with `sets`)."""
+    o1 = O.GNParams(oprm.k1, oprm.k2, oprm.k3, oprm.k4, oprm.b1, oprm.b2, oprm.lr, oprm.s_damp, 1, oprm.code_len,
+                    oprm.num_depth_samples, oprm.cut_off)
+    tr = []
+    O.reconstruct_object(dec, o1, None, pts, rays, depth, code, trace=tr, t_obj_cam0=t_obj_cam, sampled_override=depths, sdf_jitter=sdf_jitter)
+    return tr[0] if tr else None
+
+
+def oracle_grids(st, n_rays, n_depth):
+    """The oracle's per-sample decisions of one linearisation as (n_rays, n_depth) grids."""
+    vx, vy = st["valid"]
+    in_sphere = np.zeros((n_rays, n_depth), bool)
+    in_sphere[vx, vy] = True
+    sdf = np.full((n_rays, n_depth), np.nan, np.float32)
+    sdf[vx, vy] = st["sdf"]
+    kept = np.zeros((n_rays, n_depth), bool)
+    kept[st["kept"][0], st["kept"][1]] = True
+    de_do = np.full((n_rays, n_depth), np.nan, np.float32)
+    de_do[st["band"][0], st["band"][1]] = st["de_do_band"]
+    return dict(in_sphere=in_sphere, sdf=sdf, kept=kept, de_do=de_do, norm=np.asarray(st["norm"], np.float32))
+
+
+def name_flips(dev_mask, dev_sdf, dev_deds, og, th):
+    """Symmetric differences of the device's and the oracle's in-sphere and kept sets, each flipped sample with the threshold it
+    crossed and the oracle's distance from it.  -> list of dicts (empty = identical sets)."""
+    th = float(th)
+    flips = []
+    for r, j in zip(*np.where(dev_mask != og["in_sphere"])):
+        nrm = float(og["norm"][r, j])
+        flips.append(dict(ray=int(r), depth_index=int(j), set="in_sphere", device=bool(dev_mask[r, j]), oracle=bool(og["in_sphere"][r, j]),
+                          threshold="norm<1", value=nrm, margin=abs(nrm - 1.0), explained=abs(nrm - 1.0) <= TOL_NORM))
+    dev_kept = np.isfinite(dev_deds) & (dev_deds != 0) & dev_mask
+    for r, j in zip(*np.where(dev_kept != og["kept"])):
+        if dev_mask[r, j] != og["in_sphere"][r, j]:
+            continue                                  # already listed: the sample is not even in both sphere sets
+        so = float(og["sdf"][r, j])
+        sd = float(dev_sdf[r, j])
+        o_band = abs(so) < th
+        d_band = abs(sd) < th          # the device's own value: fp32 wherever it can matter (inside the widened band)
+        if o_band != d_band:
+            margin = abs(abs(so) - th)
+            flips.append(dict(ray=int(r), depth_index=int(j), set="kept", device=bool(dev_kept[r, j]), oracle=bool(og["kept"][r, j]),
+                              threshold="|sdf|<th", value=so, device_value=sd, margin=margin, explained=margin <= TOL_SDF))
+        else:
+            dd = float(og["de_do"][r, j])
+            margin = abs(dd - 1e-2) / 1e-2
+            flips.append(dict(ray=int(r), depth_index=int(j), set="kept", device=bool(dev_kept[r, j]), oracle=bool(og["kept"][r, j]),
+                              threshold="de_do>1e-2", value=dd, margin=margin, explained=margin <= TOL_DEDO_REL))
+    return flips
+
+
+def device_linearisation(batch, t_obj_cam, code, depths=None):
+    """One GN iteration of a 1-object, trace-enabled batch from the given state -> (trace dict of iteration 0, status)."""
+    batch.set_start_state([t_obj_cam], [code], None if depths is None else [depths])
+    batch.set_iterations(1)
+    batch.run()
+    _, _, _, status = batch.results()
+    return batch.trace(0), int(status[0])
+
+
+def rel_max(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def state_difference(t_a, c_a, t_b, c_b):
+    """Max-norm distance of two optimiser states: rotation/scale block (absolute), translation (relative to |t|), code (absolute)."""
+    t_a, t_b = np.asarray(t_a, np.float64), np.asarray(t_b, np.float64)
+    return dict(rot=float(np.abs(t_a[:3, :3] - t_b[:3, :3]).max()),
+                trans=float(np.linalg.norm(t_a[:3, 3] - t_b[:3, 3]) / max(np.linalg.norm(t_b[:3, 3]), 1e-30)),
+                code=float(np.abs(np.asarray(c_a, np.float64)[:len(c_b)] - np.asarray(c_b, np.float64)).max()))
+
+
+def as_device_grids(og):
+    """An oracle linearisation presented the way Batch.debug_samples presents the device's (CPU tests use the oracle as the 'device')."""
+    deds = np.where(og["kept"], np.float32(1.0), np.float32(0.0)).astype(np.float32)
+    deds[~og["in_sphere"]] = np.nan
+    return og["in_sphere"], og["sdf"], deds
+
+
+def first_differing_iteration(dev_vk, g):
+    """Index of the first iteration whose (V, K) differ from the reference's recorded ones, or None."""
+    for e, (v, k) in enumerate(dev_vk):
+        if (int(v), int(k)) != (int(g["it_V"][e]), int(g["it_K"][e])):
+            return e
+    return None
+
+
+def flip_tolerances(drift, depth_diff_obj):
+    """Round-off margins of the three thresholds when the two linearisations start from states `drift` apart (max-norm, object units) and
+    sample depths that differ by depth_diff_obj (object units): a sample moves by about that much in object space, its sdf likewise
+    (|grad sdf| ~ 1); de_do's relative sensitivity to an sdf shift is ~ 1 / (2 th (1 - o)) with 1 - o ~ 1e-2 where de_do ~ 1e-2."""
+    slack = 4.0 * drift + 2.0 * depth_diff_obj
+    return {"norm<1": TOL_NORM + slack, "|sdf|<th": TOL_SDF + slack, "de_do>1e-2": TOL_DEDO_REL + slack * 5e3}

@@ -69,3 +69,50 @@ def test_cpp_embed_call_surface(tmp_path):
     v, f = eng.extract_mesh(code[0], 16)
     assert np.array_equal(res["mesh_vertices"].reshape(nv, 3), v) and np.array_equal(res["mesh_faces"].reshape(nf, 3), f)
     eng.close()
+
+
+@pytest.mark.gpu
+def test_cpp_embed_monocular_sequence_with_32d_codes(tmp_path):
+    """The monocular call pattern of src/LocalMapping_util.cc:391-428 with the 32-D chairs decoder: 5-argument call with a zero 64-float
+    shape code, the 180-degree-yaw-flipped second call, `loss` read from both results unconditionally and compared, t_cam_obj as a 4x4,
+    code_len read as int, the code cast into a fixed-size 32-vector, zero-padded to 64 floats and handed to extract_mesh_from_code.
+    Every value C++ reads must equal what the direct C-ABI path returns for the same inputs, bit for bit."""
+    _build()
+    from dsp_slam_amd import synth, engine as E
+    from oracle import dsp_oracle as O
+    ddir = fixtures.materialize_decoder_dir("chairs32", str(tmp_path / "chairs_32"))
+    cfg = {"data_type": "Redwood", "DeepSDF_DIR": ddir, "voxels_dim": 16,
+           "optimizer": {"code_len": 32, "num_depth_samples": 50, "cut_off_threshold": 0.01,
+                         "joint_optim": dict(k1=10.0, k2=100.0, k3=2.5, k4=0.0, b1=0.2, b2=0.02, num_iterations=5, learning_rate=1.0, scale_damping=100.0)}}
+    (tmp_path / "cfg.json").write_text(json.dumps(cfg))
+    obj = synth.make_object(21, n_surface=220, n_background=60, code_len=32, half=synth.CHAIR_HALF)
+    np.savez(tmp_path / "in.npz", t_cam_obj=obj["t_cam_obj_init"], pts=obj["pts"], rays=obj["rays"], depth=obj["depth"])
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), PYTHONUNBUFFERED="1")
+    out = subprocess.run([HARNESS, os.path.join(ROOT, "dsp_slam_amd"), str(tmp_path / "cfg.json"), str(tmp_path / "in.npz"), "mono"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = {}
+    for line in out.stdout.splitlines():
+        k, *v = line.split() or [""]
+        if k in ("mono_loss", "mono_pick", "mono_t_cam_obj", "mono_code", "code_len", "mesh_shape", "mesh_vertices"):
+            res[k] = np.array([float(x) for x in v], np.float32)
+    assert res["code_len"][0] == 32 and res["mono_code"].shape == (32,)
+    dec = O.fold_decoder(fixtures.load_decoder_npz(fixtures.fixture_path("chairs32")), fixtures.fixture_specs("chairs32"))
+    eng = E.Engine(dec.layers, dec.latent_in, dec.code_len, device=0)
+    prm = E.params_from_configs(cfg)
+    flip = obj["t_cam_obj_init"].copy()
+    flip[:, 0] *= -1
+    flip[:, 2] *= -1
+    zero = np.zeros(64, np.float32)
+    ta, ca, la, sa = eng.reconstruct_batch(prm, [obj["t_cam_obj_init"]], [obj["pts"]], [obj["rays"]], [obj["depth"]], [zero])
+    tb, cb, lb, sb = eng.reconstruct_batch(prm, [flip], [obj["pts"]], [obj["rays"]], [obj["depth"]], [zero])
+    assert sa[0] == 0 and sb[0] == 0
+    assert res["mono_loss"][0] == la[0] and res["mono_loss"][1] == lb[0]
+    pick = 1 if la[0] > lb[0] else 0
+    assert int(res["mono_pick"][0]) == pick
+    t, c = (tb, cb) if pick else (ta, ca)
+    assert np.array_equal(res["mono_t_cam_obj"].reshape(4, 4), t[0]) and np.array_equal(res["mono_code"], c[0][:32])
+    nv = int(res["mesh_shape"][0])
+    v, f = eng.extract_mesh(c[0], 16)
+    assert nv == v.shape[0] and np.array_equal(res["mesh_vertices"].reshape(nv, 3), v)
+    eng.close()

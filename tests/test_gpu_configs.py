@@ -399,4 +399,40 @@ def test_c_abi_gather_over_rccl(eng, oracle_decoder):
     eng2 = E.Engine(oracle_decoder.layers, oracle_decoder.latent_in, oracle_decoder.code_len, device=0)
     with pytest.raises(Exception):
         E.gather_results_c([eng, eng2], [packed, packed])
+    with pytest.raises(Exception):
+        E.gather_results_c([eng, eng], [packed, packed])          # the same handle twice
     eng2.close()
+    # ... and straight from a device-resident batch (no host bounce in front of the collective): dsp_gather_batch_results
+    bt = eng.batch(prm, [o["t_cam_obj_init"] for o in objs], [o["pts"] for o in objs], [o["rays"] for o in objs], [o["depth"] for o in objs])
+    with pytest.raises(Exception):
+        E.gather_batches_c([bt])                                  # not run yet
+    bt.run()
+    assert np.array_equal(E.gather_batches_c([bt]), D.pack_results(*bt.results()))
+    bt.close()
+
+
+def test_device_resident_gather_through_torch_distributed(eng):
+    """distributed.gather_results_device (what bench.py's step does under torch.distributed.run): the library copies each batch's packed
+    rows device-to-device into a torch tensor, ONE dist.gather over RCCL, one copy to the host.  One rank here (one GPU per box); the
+    2- and 3-rank logic incl. an empty shard runs on gloo in tests/test_sharding_gloo.py."""
+    import os
+    import torch
+    import torch.distributed as dist
+    prm = E.gn_params(num_iterations=2)
+    objs = synth.make_batch(5, first_seed=60, n_surface=100, n_background=25)
+    mk = lambda ol: eng.batch(prm, [o["t_cam_obj_init"] for o in ol], [o["pts"] for o in ol], [o["rays"] for o in ol], [o["depth"] for o in ol])  # noqa: E731
+    b1, b2 = mk(objs[:2]), mk(objs[2:])
+    b1.run(); b2.run()
+    want = np.concatenate([D.pack_results(*b1.results()), D.pack_results(*b2.results())], 0)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29547")
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        got = D.gather_results_device([b1, b2], [(0, 5)], dist, torch.device("cuda", 0))
+    finally:
+        if own:
+            dist.destroy_process_group()
+    assert np.array_equal(got, want)
+    b1.close(); b2.close()

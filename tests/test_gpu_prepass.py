@@ -62,11 +62,12 @@ from dsp_slam_amd import synth
 TRACE_KEYS = ("H", "b", "dx", "V", "K", "set_sums", "t_obj_cam", "code")
 
 
-def _run_traced(eng, prm, args, mode, delta=-1.0, passes=0, reuse=-1, audit=True, iters=None):
+def _run_traced(eng, prm, args, mode, delta=-1.0, passes=0, reuse=-1, audit=True, iters=None, guard=True):
     b = eng.batch(prm, *args, trace=True)
     b.set_prepass(mode, delta)
     b.set_ray_passes(passes)
     b.set_mask_reuse(reuse)
+    b.set_prepass_guard(guard)
     if mode:
         b.set_prepass_audit(audit)
     b.run()
@@ -167,8 +168,8 @@ def test_margin_is_calibrated_per_decoder(eng, oracle_decoder):
     floor with f16 (its error is 5x below it) and 5x its measured error with bf16; a decoder whose hidden activations are 30x larger gets a proportionally wider band
     instead of misclassified samples -- and still gives prepass-on == prepass-off."""
     for dt, floor in ((L.PREPASS_F16, 5e-4), (L.PREPASS_BF16, 3e-3)):
-        err, delta = eng.prepass_calibration(dt)
-        assert 0 < err < floor / 4 and abs(delta - max(floor, 5 * err)) < 1e-7
+        err, delta = eng.prepass_calibration(dt)          # the zero-code entry of the table
+        assert 0 < err < 0.1 and abs(delta - max(floor, 5 * err)) < 1e-7
     # scale the last hidden layer's output by 30 and the final layer's weights by 1/30: same function, 30x the activations of layer 7
     layers = [(w.copy(), b.copy()) for w, b in oracle_decoder.layers]
     w7, b7 = layers[7]
@@ -185,3 +186,118 @@ def test_margin_is_calibrated_per_decoder(eng, oracle_decoder):
     _assert_identical(run, ref, "rescaled decoder")
     assert run[2]["prepass_misclassified"] == 0 and abs(run[2]["prepass_delta"] - d1) < 1e-9
     big.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# safe WITHOUT the audit: code-aware margins + the always-on guard
+# ---------------------------------------------------------------------------------------------------
+def _args(objs, codes=None):
+    a = [[o["t_cam_obj_init"] for o in objs], [o["pts"] for o in objs], [o["rays"] for o in objs], [o["depth"] for o in objs]]
+    if codes is not None:
+        a.append(codes)
+    return tuple(a)
+
+
+def test_margin_table_follows_the_code_magnitude(eng):
+    """dsp_create measures the prepass error with codes drawn at |z|_inf = 0, 0.15, 0.5, 1, 2: the margins are monotone in the
+    magnitude, never below the floor, and the error really does grow with the code (which is why a code-blind margin is unsafe)."""
+    for dt, floor in ((L.PREPASS_F16, 5e-4), (L.PREPASS_BF16, 3e-3)):
+        t = eng.prepass_calibration_table(dt)
+        assert list(t["mags"]) == [0.0, 0.15000000596046448, 0.5, 1.0, 2.0]
+        assert np.all(np.diff(t["delta"]) >= 0) and t["delta"][0] >= floor and t["delta"][-1] <= 0.5
+        assert np.all(t["delta"] >= np.minimum(0.5, 5 * np.maximum.accumulate(t["max_err"])) - 1e-9)
+        assert t["max_err"][-1] > t["max_err"][0]
+        assert t["guard_err"] == 0.0
+        print("dtype %d: max_err %s delta %s" % (dt, t["max_err"], t["delta"]))
+
+
+@pytest.mark.parametrize("mag", [0.5, 1.0, 2.0])
+def test_warm_start_codes_are_exact_without_the_audit(eng, mag):
+    """The C++ caller warm-starts with arbitrary codes (LocalMapping_util.cc:391-392).  With codes whose entries reach +-mag the prepass
+    error is far above the zero-code margin; the per-object margin follows the code, so prepass-on still reproduces prepass-off bit for
+    bit -- checked WITHOUT the audit switch (a production run) -- and the guard, which compares every re-decoded sample, stays quiet."""
+    prm = E.gn_params(num_iterations=3)
+    objs = synth.make_batch(3, first_seed=960, n_surface=300, n_background=80)
+    rng = np.random.default_rng(int(mag * 10))
+    codes = [(rng.uniform(-mag, mag, size=64)).astype(np.float32) for _ in objs]
+    codes[1][:] = 0.0
+    codes[1][:3] = mag * np.array([1.0, -1.0, 0.5], np.float32)       # a code the decoder was fitted on, at this magnitude
+    ref = _run_traced(eng, prm, _args(objs, codes), L.PREPASS_OFF)
+    for mode in (L.PREPASS_F16, L.PREPASS_BF16):
+        run = _run_traced(eng, prm, _args(objs, codes), mode, audit=False)
+        _assert_identical(run, ref, "warm start |z|=%g mode %d" % (mag, mode))
+        st = run[2]
+        assert st["prepass_guard_trips"] == 0 and st["prepass_guard_rerun"] == 0, st
+        assert st["prepass_audited"] == 0                       # the audit really was off
+        assert st["prepass_guard_max_err"] > 0                  # ... and the guard really compared samples
+        parity_log(kind="prepass_guard", case="warm start |z|_inf = %g" % mag, dtype=["off", "f16", "bf16"][mode],
+                   guard_max_err=st["prepass_guard_max_err"], delta_zero_code=st["prepass_delta"], trips=int(st["prepass_guard_trips"]), identical=True)
+
+
+def test_reference_goldens_are_exact_without_the_audit(eng):
+    for name in ("golden_recon_small.npz", "golden_recon_redwood.npz", "golden_recon_cfg2.npz"):
+        g = golden(name)
+        prm = E.params_from_configs(json.loads(str(g["cfg_json"])))
+        args = [[g["in_t_cam_obj_init"]], [g["in_pts"]], [g["in_rays"]], [g["in_depth"]]]
+        if "in_code" in g.files:
+            args.append([g["in_code"]])
+        ref = _run_traced(eng, prm, tuple(args), L.PREPASS_OFF)
+        run = _run_traced(eng, prm, tuple(args), L.PREPASS_F16, audit=False)
+        _assert_identical(run, ref, name)
+        assert run[2]["prepass_guard_trips"] == 0 and run[2]["prepass_guard_rerun"] == 0
+        # the guard's cost: the 1/64 sample of the classified samples that the fp32 kernel re-decodes
+        off = _run_traced(eng, prm, tuple(args), L.PREPASS_F16, audit=False, guard=False)
+        _assert_identical(off, ref, name + " (guard off)")
+        extra = run[2]["n_fwd_points"] / off[2]["n_fwd_points"] - 1.0
+        assert 0.0 < extra < 0.25, extra
+        parity_log(kind="prepass_guard", case=name, dtype="f16", guard_max_err=run[2]["prepass_guard_max_err"], delta_zero_code=run[2]["prepass_delta"],
+                   trips=0, identical=True, extra_fp32_points=extra)
+
+
+def test_chairs32_and_rescaled_decoders_are_exact_without_the_audit(chairs32_decoder, oracle_decoder):
+    prm = E.gn_params(k1=10.0, k3=2.5, k4=0.0, b2=0.02, s_damp=100.0, num_iterations=4)
+    objs = synth.make_batch(2, first_seed=940, n_surface=300, n_background=80, code_len=32, half=synth.CHAIR_HALF)
+    ch = E.Engine(chairs32_decoder.layers, chairs32_decoder.latent_in, chairs32_decoder.code_len, device=0)
+    ref = _run_traced(ch, prm, _args(objs), L.PREPASS_OFF)
+    run = _run_traced(ch, prm, _args(objs), L.PREPASS_F16, audit=False)
+    _assert_identical(run, ref, "chairs32")
+    assert run[2]["prepass_guard_trips"] == 0
+    ch.close()
+    layers = [(w.copy(), b.copy()) for w, b in oracle_decoder.layers]
+    layers[7] = (layers[7][0] * 30.0, layers[7][1] * 30.0)          # same function, 30x the activations of the last hidden layer
+    layers[8] = (layers[8][0] / 30.0, layers[8][1])
+    big = E.Engine(layers, oracle_decoder.latent_in, oracle_decoder.code_len, device=0)
+    objs = synth.make_batch(2, first_seed=930, n_surface=300, n_background=80)
+    ref = _run_traced(big, E.gn_params(num_iterations=3), _args(objs), L.PREPASS_OFF)
+    run = _run_traced(big, E.gn_params(num_iterations=3), _args(objs), L.PREPASS_F16, audit=False)
+    _assert_identical(run, ref, "rescaled decoder")
+    assert run[2]["prepass_guard_trips"] == 0
+    big.close()
+
+
+def test_guard_fires_on_a_margin_that_is_too_small_and_the_rerun_is_exact(oracle_decoder):
+    """A margin below the decoder's real prepass error (here forced: 2e-5 with bf16, whose error is ~1e-3): the guard sees re-decoded
+    samples that are off by more than half the margin, the batch is run again with the prepass off, and the caller gets exactly the
+    prepass-off results with prepass_guard_rerun = 1; the handle's calibrated margins are raised to 4x the error seen.  The same run
+    with the guard switched off returns DIFFERENT results (so the guard is what saved it), as the audit confirms."""
+    own = E.Engine(oracle_decoder.layers, oracle_decoder.latent_in, oracle_decoder.code_len, device=0)      # its margins get raised: not shared
+    prm = E.gn_params(num_iterations=3)
+    objs = synth.make_batch(4, first_seed=970, n_surface=1000, n_background=250)
+    ref = _run_traced(own, prm, _args(objs), L.PREPASS_OFF)
+    before = own.prepass_calibration_table(L.PREPASS_BF16)
+    run = _run_traced(own, prm, _args(objs), L.PREPASS_BF16, delta=2e-5, audit=False)
+    st = run[2]
+    assert st["prepass_guard_trips"] > 0 and st["prepass_guard_objects"] >= 1 and st["prepass_guard_rerun"] == 1, st
+    assert st["prepass_guard_max_err"] >= 1e-5
+    _assert_identical(run, ref, "guarded run with a margin that is too small")
+    after = own.prepass_calibration_table(L.PREPASS_BF16)
+    assert after["guard_err"] == pytest.approx(st["prepass_guard_max_err"]) and np.all(after["delta"] >= before["delta"])
+    assert np.all(after["delta"] >= min(0.5, 4 * after["guard_err"]) - 1e-9)
+    # unguarded, the same margin silently changes set membership
+    bad = _run_traced(own, prm, _args(objs), L.PREPASS_BF16, delta=2e-5, audit=True, guard=False)
+    assert bad[2]["prepass_misclassified"] > 0 and bad[2]["prepass_guard_rerun"] == 0
+    same = all(np.array_equal(ta[k], tc[k]) for ta, tc in zip(bad[1], ref[1]) for k in TRACE_KEYS)
+    assert not same, "an unguarded run with misclassified samples should not reproduce prepass-off"
+    parity_log(kind="prepass_guard", case="forced margin 2e-5 (bf16)", dtype="bf16", guard_max_err=st["prepass_guard_max_err"],
+               delta_zero_code=2e-5, trips=int(st["prepass_guard_trips"]), identical=True, rerun=True)
+    own.close()

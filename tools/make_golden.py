@@ -54,11 +54,19 @@ class Recorder(object):
     def __enter__(self):
         ro, rl = self.ropt, self.rloss
         self.saved = dict(sdf=ro.compute_sdf_loss, rend=ro.compute_render_loss, rot=ro.compute_rotation_loss_sim3,
-                          exp=ro.exp_sim3, dec=rl.decode_sdf, inv=torch.inverse, mv=torch.mv)
+                          exp=ro.exp_sim3, dec=rl.decode_sdf, inv=torch.inverse, mv=torch.mv, lin=torch.linspace)
         rec = self
+        rec.pending_depths = None
+
+        def w_lin(*a, **k):          # the depth samples of the iteration about to start (optimizer.py:125)
+            out = rec.saved["lin"](*a, **k)
+            rec.pending_depths = out.clone().numpy()
+            return out
 
         def w_sdf(decoder, pts, t_obj_cam, z):
             rec.cur = dict(t_obj_cam=t_obj_cam.clone().numpy(), code=z.clone().cpu().numpy())
+            if rec.pending_depths is not None:
+                rec.cur["depths"] = rec.pending_depths
             rec.iters.append(rec.cur)
             out = rec.saved["sdf"](decoder, pts, t_obj_cam, z)
             rec.cur["res_sdf_absmax"] = float(out[2].abs().max())
@@ -91,18 +99,18 @@ class Recorder(object):
             return out
 
         ro.compute_sdf_loss, ro.compute_render_loss, rl.decode_sdf = w_sdf, w_rend, w_dec
-        torch.inverse, torch.mv = w_inv, w_mv
+        torch.inverse, torch.mv, torch.linspace = w_inv, w_mv, w_lin
         return self
 
     def __exit__(self, *exc):
         ro, rl = self.ropt, self.rloss
         ro.compute_sdf_loss, ro.compute_render_loss = self.saved["sdf"], self.saved["rend"]
         rl.decode_sdf = self.saved["dec"]
-        torch.inverse, torch.mv = self.saved["inv"], self.saved["mv"]
+        torch.inverse, torch.mv, torch.linspace = self.saved["inv"], self.saved["mv"], self.saved["lin"]
 
     def pack(self, prefix=""):
         out = {}
-        keys = ["t_obj_cam", "code", "H", "b", "dx"]
+        keys = ["t_obj_cam", "code", "H", "b", "dx", "depths"]
         full = [it for it in self.iters if "dx" in it]
         for k in keys:
             if full:
