@@ -201,8 +201,8 @@ int dsp_batch_set_ray_pass_bounds(dsp_batch* b, const int32_t* bounds, int n_pas
  * prepass on, every candidate sample is first decoded by an f16 (or bf16) MFMA kernel at 16x the fp32 matrix rate; samples with
  * |sdf_lp| >= cut_off + delta are classified by that value alone, rays stop behind their first certainly-solid sample, and only the
  * samples inside the widened band are decoded by the fp32 kernel (one launch per iteration).  delta must exceed the largest
- * |sdf_lp - sdf_fp32| of the decoder.  The default is calibrated PER DECODER at dsp_create: 5x the largest difference over 16 384 seeded
- * unit-ball points x 4 codes, not below 5e-4 (f16) / 3e-3 (bf16) -- dsp_prepass_calibration reports both numbers, the audit below
+ * |sdf_lp - sdf_fp32| of the decoder.  The default is calibrated PER DECODER at dsp_create: 6x the largest difference over 32 768 seeded
+ * unit-ball points x 2 codes per code magnitude (dsp_prepass_calibration_table), not below 5e-4 (f16) / 3e-3 (bf16) -- dsp_prepass_calibration reports both numbers, the audit below
  * measures the error on the actual workload; results are then identical, bit for bit, to prepass off.
  * mode: -1 automatic (f16 when the decoder geometry is supported), DSP_PREPASS_OFF / _F16 / _BF16; delta < 0 = default. */
 int dsp_batch_set_prepass(dsp_batch* b, int mode, float delta);
@@ -211,7 +211,7 @@ int dsp_batch_set_prepass(dsp_batch* b, int mode, float delta);
 int dsp_prepass_calibration(dsp_handle* h, int dtype, float* max_err, float* delta);
 /* The whole calibration: the prepass error grows with the hidden activations, hence with the code, so dsp_create measures it with codes
  * drawn uniformly in +-mag on every entry for mag in {0, 0.15, 0.5, 1, 2} (5 entries each: mags, largest error, margin = max(floor,
- * 5 x largest error up to that magnitude), capped at 0.5).  Every object's margin follows the largest entry of its CURRENT code,
+ * 6 x largest error up to that magnitude), capped at 0.5).  Every object's margin follows the largest entry of its CURRENT code,
  * piecewise linearly through this table, re-evaluated after every Gauss-Newton step.  guard_err: largest error a guard trip on this
  * handle has reported (the margins returned are already raised to 4 x that).  Any pointer may be NULL. */
 int dsp_prepass_calibration_table(dsp_handle* h, int dtype, float* mags, float* max_err, float* delta, float* guard_err);

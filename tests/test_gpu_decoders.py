@@ -68,14 +68,24 @@ def test_chairs32_reconstruction_vs_reference_golden(eng32, chairs32_decoder):
     for ta, tc in zip(out[0][1], out[1][1]):
         for k in ("H", "b", "dx", "V", "K", "set_sums"):
             assert np.array_equal(ta[k], tc[k]), k
-    assert st["prepass_misclassified"] == 0 and 4.0 * st["prepass_max_err"] <= st["prepass_delta"]
+    assert st["prepass_misclassified"] == 0 and 3.0 * st["prepass_max_err"] <= st["prepass_delta"]
     # code entries beyond the decoder's 32 never move
     assert all(np.all(tr["code"][0][32:] == 0) and np.all(tr["dx"][0][39:] == 0) for tr in traces)
     # first iteration against the reference's own trace (39 x 39 system)
     # (one sample of this object sits on the unit sphere: the reference's float32 LAPACK inverse of T_co puts it inside, the
     # device's fp64-then-rounded inverse -- like the oracle's -- outside: 9711 vs 9712 in-sphere samples)
     assert abs(int(traces[0]["V"][0]) - int(g["it_V"][0])) <= 1 and abs(int(traces[0]["K"][0]) - int(g["it_K"][0])) <= 1
-    assert rel(traces[0]["H"][0][:39, :39], g["it_H"][0]) < (1e-4 if traces[0]["K"][0] == g["it_K"][0] else 4.0 / g["it_K"][0])
+    # ... so the comparison with the reference's own numbers is made at ITS state: camera->object matrix, code and depth samples of
+    # every recorded iteration injected bit for bit (dsp_batch_set_start_state) -- identical sets, H / b to 1e-4 (39 x 39 system)
+    bi = eng32.batch(prm, [g["in_t_cam_obj_init"]], [g["in_pts"]], [g["in_rays"]], [g["in_depth"]], trace=True)
+    for e in range(g["it_H"].shape[0]):
+        bi.set_start_state([g["it_t_obj_cam"][e]], [g["it_code"][e]], [g["it_depths"][e]])
+        bi.set_iterations(1)
+        bi.run()
+        ti = bi.trace(0)
+        assert (int(ti["V"][0]), int(ti["K"][0])) == (int(g["it_V"][e]), int(g["it_K"][e])), e
+        assert rel(ti["H"][0][:39, :39], g["it_H"][e]) < 1e-4 and rel(ti["b"][0][:39], g["it_b"][e]) < 3e-4, e
+    bi.close()
     # every iteration re-linearised by the oracle from the device state
     strict, per = 0, []
     for tr in traces:

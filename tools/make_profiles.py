@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""profiles/r02_*.md and profiles/pmc_traffic.json from the outputs of tools/run_profiles_r02.sh (gpurun_out/<tag>/), with the
+"""profiles/<tag>_*.md and profiles/pmc_traffic.json from the outputs of tools/run_profiles.sh (gpurun_out/<tag>/), with the
 derived numbers (TFLOP/s, matrix-pipe busy, clocks, bytes per point) computed here rather than by hand.
 
-    python tools/make_profiles_r02.py [gpurun_out/r02]
+    python tools/make_profiles.py [gpurun_out/r03 [tag]]
 """
 import json
 import os
@@ -10,7 +10,9 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r02")
+SRC = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r03")
+TAG = sys.argv[2] if len(sys.argv) > 2 else os.path.basename(os.path.normpath(SRC))     # file prefix under profiles/ (r03, r03b, ...)
+ROUND = TAG[1:3].lstrip("0") or "?"
 DST = os.path.join(ROOT, "profiles")
 F_FWD = 3671040.0
 PEAK32, PEAK16 = 157.3, 2500.0
@@ -62,15 +64,14 @@ def main():
         r, p = d["roofline"], d.get("prepass")
         return "| %s | %.1f | %.1f | %.3f | %.3f | %s |" % (label, d["value"], d["ms_per_step"], r["frac"], r["jac_kernel_frac"],
                                                          "%.0f (%.3f)" % (p["achieved"], p["frac"]) if p else "-")
-    lines = ["# Round 2 -- bench lines as printed on an MI355X (one gpurun call, `tools/run_profiles_r02.sh`; this file by `tools/make_profiles_r02.py`)",
-             "", "`python bench.py --steps 5 --warmup 1 [--config ...] [--prepass off]`  (state at the end of round 2; the lines of the first round-2 profile",
-             "run -- 110.2 objects/s, before the instruction-stream work on the decoder kernels -- are in the git history of this file)", "",
+    lines = ["# Round %s -- bench lines" % ROUND + " as printed on an MI355X (one gpurun call, `tools/run_profiles.sh`; this file by `tools/make_profiles.py`)",
+             "", "`python bench.py --steps 5 --warmup 1 [--config ...] [--prepass off]`", "",
              "| config | objects/s | ms per step | fp32 forward kernel frac of 157.3 TFLOP/s | jacobian kernels frac | prepass kernel TFLOP/s (frac of 2500) |", "|---|---|---|---|---|---|",
              row("cfg2x64", b), row("cfg2x64, prepass off", boff), row("cfg4", b4), row("cfg5", b5), ""]
     for title, d in (("cfg2x64 (the headline configuration), f16 prepass", b), ("cfg2x64, --prepass off (round 1 behaviour)", boff),
                      ("cfg4: 128 objects per GPU through shard_objects", b4), ("cfg5: 4000-point objects, Redwood hyper-parameters, cars + chairs32 decoders", b5)):
         lines += ["## " + title, "", "```json", json.dumps(d), "```", ""]
-    open(os.path.join(DST, "r02_bench_lines.md"), "w").write("\n".join(lines))
+    open(os.path.join(DST, TAG + "_bench_lines.md"), "w").write("\n".join(lines))
 
     # ---- kernel stats ------------------------------------------------------------------------------------------------------------
     st = stats_rows("kernel_stats.md")
@@ -84,7 +85,7 @@ def main():
     text = ["# Round 2 -- rocprofv3 kernel stats of the bench command", "",
             "`cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --latency-runs 1`",
             "(64 cfg2 objects per step, f16 prepass on; 6 steps incl. the warm-up + the two latency probes).  Table by `tools/rocpd_stats.py`, this file by",
-            "`tools/make_profiles_r02.py`.  The bench line of the same build, un-profiled: `profiles/r02_bench_lines.md` (%.1f objects/s, %.1f ms per step)." % (b["value"], b["ms_per_step"]),
+            "`tools/make_profiles.py`.  The bench line of the same build, un-profiled: `profiles/" + TAG + "_bench_lines.md` (%.1f objects/s, %.1f ms per step)." % (b["value"], b["ms_per_step"]),
             "", table_only("kernel_stats.md"), "", "Reading (per step of 64 objects x 10 iterations):", "",
             "* `mlp_kernel<1>` (fp32 forward over the samples the prepass could not classify, relu masks exported): 10 launches, **%.2f ms average**"
             % (k1["avg_us"] / 1e3),
@@ -101,7 +102,7 @@ def main():
             % (lp["alg_flop_per_launch"] / 1e12, lp["achieved"] / 1e3, lp["frac"]),
             "* everything else (sampling, band selection, occupancy scan, compaction, Gram, solve, tile lists): %.1f ms per step = %.1f %%."
             % (by["other"], 100 * by["other"] / b["ms_per_step"]), ""]
-    open(os.path.join(DST, "r02_kernel_stats.md"), "w").write("\n".join(text))
+    open(os.path.join(DST, TAG + "_kernel_stats.md"), "w").write("\n".join(text))
 
     # ---- PMC ---------------------------------------------------------------------------------------------------------------------
     mf, dm = pmc("pmc_mfma.md")
@@ -129,7 +130,7 @@ def main():
            "Four separate `--pmc` passes (no `--stats`, no tracing; one counter group per run) over",
            "`python bench.py --steps 1 --warmup 1 --no-cpu-baseline --latency-runs 1` -- **64 objects per GPU, the bench configuration** (round 1's pass was",
            "taken at 32).  2 steps = %d launches of the fp32 forward kernel `mlp_kernel<1>`, 200 of the prepass kernel (+ ~60 from the latency probes)." % n1,
-           "Tables by `tools/rocpd_pmc.py` (kernels matching `mlp_`), this file by `tools/make_profiles_r02.py`.", "",
+           "Tables by `tools/rocpd_pmc.py` (kernels matching `mlp_`), this file by `tools/make_profiles.py`.", "",
            "## FETCH_SIZE (KiB)", "", table_only("pmc_fetch.md"), "", "## WRITE_SIZE (KiB)", "", table_only("pmc_write.md"), "",
            "## MFMA / busy counters", "", table_only("pmc_mfma.md"), "", "## LDS / wait counters", "", table_only("pmc_lds.md"), "", "## Reading", "",
            "**`mlp_kernel<1>` -- fp32 forward decoder over the unclassified band (%d launches, %.1f ms in the counter run)**" % (n1, dm[K1][1]), "",
@@ -163,12 +164,12 @@ def main():
            % (wr[(K0, "WRITE_SIZE")][1], wr[(K0, "WRITE_SIZE")][1] * 1024 / k0_pts),
            "* LDS: %d bank conflicts (A fragments are read as lane-linear `ds_read_b128`)." % ld[(K0, "SQ_LDS_BANK_CONFLICT")][1], "",
            "**Jacobian kernels**: `mlp_kernel<3>` (backward only) %.1f %% matrix-pipe busy, `mlp_kernel<2>` (forward + backward) %.1f %%." % (100 * busy(K2R), 100 * busy(K2)), ""]
-    open(os.path.join(DST, "r02_pmc.md"), "w").write("\n".join(txt))
+    open(os.path.join(DST, TAG + "_pmc.md"), "w").write("\n".join(txt))
     traffic = {
         "fwd_fetch_bytes_per_point": round(k1_fetch / k1_pts, 1),
         "lp_fetch_bytes_per_point": round(k0_fetch / k0_pts, 1),
-        "source": "profiles/r02_pmc.md",
-        "note": ("rocprofv3 --pmc FETCH_SIZE pass at the bench configuration, 64 objects per GPU (profiles/r02_pmc.md): %.2f KB of L2-fabric reads per point "
+        "source": "profiles/" + TAG + "_pmc.md",
+        "note": ("rocprofv3 --pmc FETCH_SIZE pass at the bench configuration, 64 objects per GPU (profiles/" + TAG + "_pmc.md): %.2f KB of L2-fabric reads per point "
                  "the fp32 forward kernel decodes (x2 gfx950 correction applied) = Infinity-Cache-served re-reads of the 6.8 MB fp32 weight stream, %.0f GB/s = "
                  "%.1f %% of the HBM peak; algorithmic 20 B/point.  Prepass kernel: %.0f B/point (its 3.6 MB f16 stream fits the 4 MiB L2)"
                  % (k1_fetch / k1_pts / 1e3, k1_fetch / (df[K1][1] * 1e-3) / 1e9, 100 * k1_fetch / (df[K1][1] * 1e-3) / 8e12, k0_fetch / k0_pts)),
@@ -186,7 +187,7 @@ def main():
     book = sum(v["total_ms"] for k, v in ls.items() if not any(x in k for x in ("mlp_", "k_solve", "__amd", "k_init_state", "k_finalize", "k_code_bias")))
     ltxt = ["# Round 2 -- single-detection latency path, rocprofv3 kernel stats", "",
             "`cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -- python tools/gpu_small_loop.py <M> <Bg> <reps>`: a resident batch of ONE object",
-            "re-run `reps`+1 times (10 joint Gauss-Newton iterations each); tables by `tools/rocpd_stats.py`, this file by `tools/make_profiles_r02.py`.",
+            "re-run `reps`+1 times (10 joint Gauss-Newton iterations each); tables by `tools/rocpd_stats.py`, this file by `tools/make_profiles.py`.",
             "Automatic kernel choice (no setters).", "",
             "## Real-KITTI-size detection: 250 surface points + 200 background rays (450 rays x 50 samples), %d runs -- %.2f ms of kernels per run under the profiler"
             % (runs, per_run),
@@ -203,8 +204,8 @@ def main():
             % (1e3 * book / solve["calls"], book / runs), "",
             "## cfg2-size object: 2000 surface points + 500 background rays (2500 rays) -- %.2f ms p50 in `bench.py`" % b["latency_ms_p50"], "",
             table_only("latency_cfg2_kernel_stats.md"), ""]
-    open(os.path.join(DST, "r02_latency_kernel_stats.md"), "w").write("\n".join(ltxt))
-    print("wrote profiles/r02_{bench_lines,kernel_stats,pmc,latency_kernel_stats}.md and pmc_traffic.json")
+    open(os.path.join(DST, TAG + "_latency_kernel_stats.md"), "w").write("\n".join(ltxt))
+    print("wrote profiles/%s_{bench_lines,kernel_stats,pmc,latency_kernel_stats}.md and pmc_traffic.json" % TAG)
     print("K1 busy %.1f%% clk %.2f; K2 %.1f%%; K2r %.1f%%; K0 busy %.1f%% clk %.2f" % (100 * busy(K1), clk(K1), 100 * busy(K2), 100 * busy(K2R), 100 * busy(K0), clk(K0)))
     print("K1 fetch B/pt %.0f  K0 fetch B/pt %.0f write B/pt %.0f" % (k1_fetch / k1_pts, k0_fetch / k0_pts, wr[(K0, "WRITE_SIZE")][1] * 1024 / k0_pts))
 

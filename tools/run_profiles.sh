@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round-2 profile sequence on the GPU box (one gpurun call): bench line, rocprofv3 kernel stats of the same command, PMC passes
-# (each in its own run, --pmc only), latency-sized kernel stats.  Outputs under gpurun_out/r02/ ; copy what is to be judged into profiles/.
+# Profile sequence on the GPU box (one gpurun call): bench line, rocprofv3 kernel stats of the same command, PMC passes
+# (each in its own run, --pmc only), latency-sized kernel stats.  Outputs under gpurun_out/<tag>/ ; copy what is to be judged into profiles/.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-r02}
