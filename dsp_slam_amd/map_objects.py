@@ -27,10 +27,15 @@ def read_map_objects(path):
 
 
 def write_map_objects(path, objects):
-    """objects: iterable of dict(id, pose (4,4) or (3,4), code).  Written as the reference does (`fixed`, setprecision(9))."""
+    """objects: iterable of dict(id, pose (4,4) or (3,4), code).  Written as System::SaveMapCurrentFrame does (src/System_util.cc:123-146):
+    `fixed`, setprecision(9); the pose as twelve `<<`-streamed scalars separated by single spaces; the code as an Eigen row vector streamed
+    with Eigen's default IOFormat, which right-aligns every coefficient to the width of the widest one (so values are separated by one OR
+    MORE spaces -- the reason the reference's reader skips empty items, extract_map_objects.py:59-61)."""
     with open(path, "w") as f:
         for o in sorted(objects, key=lambda x: x["id"]):
             f.write("%d\n" % int(o["id"]))
-            p = np.asarray(o["pose"], np.float64)[:3, :4].reshape(-1)
-            f.write(" ".join("%.9f" % v for v in p) + "\n")
-            f.write(" ".join("%.9f" % v for v in np.asarray(o["code"], np.float64).reshape(-1)) + "\n")
+            p = np.asarray(o["pose"], np.float32)[:3, :4].reshape(-1)        # Eigen::Matrix4f / Vector<float,64>: float32 values
+            f.write(" ".join("%.9f" % float(v) for v in p) + "\n")
+            items = ["%.9f" % float(v) for v in np.asarray(o["code"], np.float32).reshape(-1)]
+            width = max(len(x) for x in items) if items else 0
+            f.write(" ".join(x.rjust(width) for x in items) + "\n")

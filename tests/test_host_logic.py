@@ -129,9 +129,28 @@ def test_map_objects_roundtrip(tmp_path):
     by_id = {o["id"]: o for o in objs}
     for o in back:
         assert np.allclose(o["pose"], by_id[o["id"]]["pose"], atol=1e-9) and np.allclose(o["code"], by_id[o["id"]]["code"], atol=1e-8)
-    # the reference's own reader logic (extract_map_objects.py:46-63) accepts the file
-    N = int(len(lines) / 3)
-    assert N == 3 and np.asarray([float(x) for x in lines[1].strip().split(" ")]).reshape(3, 4).shape == (3, 4)
+
+
+def test_map_objects_reader_equals_the_references_parse_loop(tmp_path):
+    """Pinned against the reference itself: tools/make_golden_map.py ran the UNMODIFIED extract_map_objects.py (its `__main__` parse
+    loop, lines 46-63) on a MapObjects.txt in System_util.cc's format -- Eigen's column-aligned code line included -- and recorded the ids,
+    the 4x4 poses it saved and the codes it handed to the mesh extractor.  Our reader must return the same values, bit for bit, from the
+    same bytes; and our writer must reproduce those bytes from the values."""
+    from conftest import golden
+    from dsp_slam_amd.map_objects import read_map_objects, write_map_objects
+    g = golden("golden_map_objects.npz")
+    p = str(tmp_path / "MapObjects.txt")
+    with open(p, "wb") as f:
+        f.write(g["text"].tobytes())
+    assert b"  " in g["text"].tobytes()        # the code line really is column-aligned (several spaces between some values)
+    back = read_map_objects(p)
+    assert [o["id"] for o in back] == list(g["ids"])
+    for o, pose, code in zip(back, g["poses"], g["codes"]):
+        assert o["pose"].dtype == pose.dtype and np.array_equal(o["pose"], pose)
+        assert o["code"].dtype == code.dtype == np.float32 and np.array_equal(o["code"], code)
+    p2 = str(tmp_path / "again.txt")
+    write_map_objects(p2, back)
+    assert open(p2, "rb").read() == g["text"].tobytes()
 
 
 def test_ply_writer_layout_and_roundtrip(mirror, tmp_path):
