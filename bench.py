@@ -172,9 +172,14 @@ def main():
 
     gathered = [None]
 
+    k1_all = {"ms": 0.0, "n": 0}      # every launch of the fp32 forward kernel in this process (warm-up and the prepass-off leg included)
+
     def step():
         for bt in batches:
             bt.run()
+            st = bt.stats()
+            k1_all["ms"] += st["ms_mlp_fwd"]
+            k1_all["n"] += st["n_mlp_fwd_launches"]
         if dist is not None:     # the single collective of the path: results device -> RCCL gather over xGMI -> rank 0's host, no host bounce
             gathered[0] = D.gather_results_device(batches, shards, dist, device=torch.device("cuda", local_rank))
         else:
@@ -278,6 +283,9 @@ def main():
             "traffic": pmc.get("fwd_fetch_bytes_per_point", 0.0) * fwd_pts / max(n_fwd, 1) or None,
             "traffic_note": pmc.get("note", "no PMC pass recorded (profiles/pmc_traffic.json missing)"),
             "avg_launch_ms": round(fwd_ms / max(n_fwd, 1), 4),
+            # what `rocprofv3 --kernel-trace --stats` of THIS command reports for the kernel: it also sees the warm-up step and, when the
+            # prepass-off leg runs, that leg's (ten shorter per iteration) launches -- profiles/rNN_kernel_stats.md must agree with this
+            "rocprof_check": {"launches_in_this_process": k1_all["n"], "avg_launch_ms_over_all_of_them": round(k1_all["ms"] / max(k1_all["n"], 1), 4)},
             "alg_flop_per_launch": round(fwd_pts * F_FWD / max(n_fwd, 1)),
             "fwd_points_evaluated_over_insphere": round(fwd_pts / max(insphere_pts, 1.0), 4),
             "render_rows_kept_over_fwd_points": round(ren_rows / max(fwd_pts, 1.0), 4),
@@ -303,6 +311,13 @@ def main():
             "alg_flop_per_launch": round(lp_pts * F_FWD / max(n_lp, 1)),
             "points_over_insphere": round(lp_pts / max(insphere_pts, 1.0), 4),
             "delta": acc.get("prepass_delta"),
+            # what actually bounds this kernel: LDS bandwidth.  One v_mfma_f32_32x32x16 (32 cycles) needs one 1 KiB A fragment per wave from LDS
+            # = 128 B/clk/CU for the four waves = the CU's whole LDS read bandwidth, and the LDS-DMA refill of the ring writes another quarter
+            # of that.  Per 128-point tile: 232 chunks x 16 KiB x (4 waves reading + 1 DMA write) = 18.1 MiB through the LDS
+            "lds_roofline": {"bound": "lds", "bytes_per_tile": 232 * 16384 * 5, "achieved": round(lp_pts / 128.0 * 232 * 16384 * 5 / (lp_ms * 1e-3) / 1e12, 2) if lp_ms > 0 else None,
+                             "peak": round(128 * 256 * 2.4e9 / 1e12, 1), "unit": "TB/s",
+                             "frac": round(lp_pts / 128.0 * 232 * 16384 * 5 / (lp_ms * 1e-3) / (128 * 256 * 2.4e9), 4) if lp_ms > 0 else None,
+                             "note": "peak at the nominal 2.4 GHz; the chip holds ~1.73 GHz under this kernel (tools/gpu_power_probe.py, profiles/r03_power_probe.md), at which it moves ~0.9 of the LDS bandwidth"},
             "traffic": pmc.get("lp_fetch_bytes_per_point", 0.0) * lp_pts / max(n_lp, 1) or None,
         }
 

@@ -89,7 +89,8 @@ Q4 normalize_rotation(Q4 q) {   // se3quat.h:286-291
     return {q.x / n, q.y / n, q.z / n, q.w / n};
 }
 
-Pose load(const double* p) { return {{p[0], p[1], p[2]}, {p[3], p[4], p[5], p[6]}}; }
+// the 7-vector constructor of SE3Quat normalises the rotation (sign flipped to w >= 0, unit norm): se3quat.h:86-92
+Pose load(const double* p) { return {{p[0], p[1], p[2]}, normalize_rotation({p[3], p[4], p[5], p[6]})}; }
 void store(const Pose& s, double* p) {
     p[0] = s.t.x; p[1] = s.t.y; p[2] = s.t.z;
     p[3] = s.q.x; p[4] = s.q.y; p[5] = s.q.z; p[6] = s.q.w;

@@ -11,8 +11,10 @@ import numpy as np
 from . import _lib as L
 
 INV_SIGMA_OBJECT = 1e3                                      # src/Optimizer_util.cc:82,448
-TH_HUBER_OBJECT_JOINT_BA = float(np.sqrt(0.10 * 1e3))       # :83       Optimizer::JointBundleAdjustment (global)
-TH_HUBER_OBJECT_LOCAL_BA = float(np.sqrt(1e3))              # :449-450  Optimizer::LocalJointBundleAdjustment
+# `const float th = sqrt(...)`: the reference keeps the thresholds as float32 (the sqrt itself runs in double on the double-promoted
+# product 0.10 * invSigmaObject with a float invSigmaObject, then narrows)
+TH_HUBER_OBJECT_JOINT_BA = float(np.float32(np.sqrt(0.10 * float(np.float32(1e3)))))       # :83       Optimizer::JointBundleAdjustment (global)
+TH_HUBER_OBJECT_LOCAL_BA = float(np.float32(np.sqrt(float(np.float32(1e3)))))              # :449-450  Optimizer::LocalJointBundleAdjustment
 VERTEX_EXPMAP, VERTEX_OBJECT = 0, 1
 
 

@@ -82,8 +82,8 @@ def main():
     lp = b["prepass"]
     others = sum(v["total_ms"] for k, v in st.items() if k not in (K1, K2, K2R, K0) and "mlp_" not in k)
     n_steps = 6.0
-    text = ["# Round 2 -- rocprofv3 kernel stats of the bench command", "",
-            "`cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --latency-runs 1`",
+    text = ["# Round %s -- rocprofv3 kernel stats of the bench command" % ROUND, "",
+            "`cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --latency-runs 1 --no-prepass-off`",
             "(64 cfg2 objects per step, f16 prepass on; 6 steps incl. the warm-up + the two latency probes).  Table by `tools/rocpd_stats.py`, this file by",
             "`tools/make_profiles.py`.  The bench line of the same build, un-profiled: `profiles/" + TAG + "_bench_lines.md` (%.1f objects/s, %.1f ms per step)." % (b["value"], b["ms_per_step"]),
             "", table_only("kernel_stats.md"), "", "Reading (per step of 64 objects x 10 iterations):", "",
@@ -102,6 +102,18 @@ def main():
             % (lp["alg_flop_per_launch"] / 1e12, lp["achieved"] / 1e3, lp["frac"]),
             "* everything else (sampling, band selection, occupancy scan, compaction, Gram, solve, tile lists): %.1f ms per step = %.1f %%."
             % (by["other"], 100 * by["other"] / b["ms_per_step"]), ""]
+    # the command exactly as the driver runs it (default flags): its JSON line, printed under the profiler, carries roofline.rocprof_check
+    if os.path.exists(os.path.join(SRC, "kernel_stats_full.md")):
+        full = stats_rows("kernel_stats_full.md")
+        js = [ln for ln in read("bench_under_rocprof_full.txt").splitlines() if ln.startswith('{"metric"')]
+        if js and K1 in full:
+            chk = json.loads(js[-1])["roofline"]["rocprof_check"]
+            text += ["## The default command (`python bench.py --steps 5 --warmup 1 --no-cpu-baseline --latency-runs 1`: prepass-off leg included), same profiler", "",
+                     "rocprofv3: `mlp_kernel<1>` **%d calls, %.3f ms average**; the JSON line of that very process (`roofline.rocprof_check`, HIP events on the library's stream): "
+                     "%d launches, %.3f ms average -- difference %.2f %%.  (The average mixes the headline leg's one launch per iteration with the prepass-off leg's ten shorter ones;"
+                     % (full[K1]["calls"], full[K1]["avg_us"] / 1e3, chk["launches_in_this_process"], chk["avg_launch_ms_over_all_of_them"],
+                        100.0 * abs(full[K1]["avg_us"] / 1e3 - chk["avg_launch_ms_over_all_of_them"]) / chk["avg_launch_ms_over_all_of_them"]),
+                     "the table above profiles the headline leg alone.)", "", table_only("kernel_stats_full.md"), ""]
     open(os.path.join(DST, TAG + "_kernel_stats.md"), "w").write("\n".join(text))
 
     # ---- PMC ---------------------------------------------------------------------------------------------------------------------
@@ -126,7 +138,7 @@ def main():
     k0_fetch = fe[(K0, "FETCH_SIZE")][1] * 1024 * 2
     wave1 = mf[(K1, "SQ_WAVE_CYCLES")][1]
     wave0 = ld[(K0, "SQ_ACTIVE_INST_ANY")][1] + 0.0
-    txt = ["# Round 2 -- rocprofv3 PMC passes at the bench configuration", "",
+    txt = ["# Round %s -- rocprofv3 PMC passes" % ROUND + " at the bench configuration", "",
            "Four separate `--pmc` passes (no `--stats`, no tracing; one counter group per run) over",
            "`python bench.py --steps 1 --warmup 1 --no-cpu-baseline --latency-runs 1` -- **64 objects per GPU, the bench configuration** (round 1's pass was",
            "taken at 32).  2 steps = %d launches of the fp32 forward kernel `mlp_kernel<1>`, 200 of the prepass kernel (+ ~60 from the latency probes)." % n1,
@@ -185,7 +197,7 @@ def main():
     lpk = [v for k, v in ls.items() if "mlp_lp_kernel" in k][0]
     solve = [v for k, v in ls.items() if "k_solve" in k][0]
     book = sum(v["total_ms"] for k, v in ls.items() if not any(x in k for x in ("mlp_", "k_solve", "__amd", "k_init_state", "k_finalize", "k_code_bias")))
-    ltxt = ["# Round 2 -- single-detection latency path, rocprofv3 kernel stats", "",
+    ltxt = ["# Round %s -- single-detection latency path, rocprofv3 kernel stats" % ROUND, "",
             "`cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -- python tools/gpu_small_loop.py <M> <Bg> <reps>`: a resident batch of ONE object",
             "re-run `reps`+1 times (10 joint Gauss-Newton iterations each); tables by `tools/rocpd_stats.py`, this file by `tools/make_profiles.py`.",
             "Automatic kernel choice (no setters).", "",
