@@ -70,7 +70,7 @@ def parity_log(**record):
 
 @pytest.fixture(scope="session")
 def chairs32_decoder():
-    """The second fixture decoder: 32-D codes, fitted to a different (taller) shape family (tools/make_decoder_fixture.py
+    """The second fixture decoder: 32-D codes, fitted to a different (taller) shape family (tools/fit_decoder_gpu.py
     --name chairs32 --code-len 32 --half 0.36 0.55 0.36); oracle form."""
     from dsp_slam_amd import fixtures
     from oracle import dsp_oracle

@@ -22,6 +22,38 @@ def main():
         last[(r["kind"], r.get("case", ""), r.get("dtype", ""))] = r
     print("# Parity report -- measured on MI355X by `pytest -m gpu` (tests/conftest.py:parity_log)\n")
     print("Every number is |device - reference| (or oracle) as the test measured it, next to the bound it was held to.\n")
+    ars = [r for (k, _, _d), r in last.items() if k == "at_reference_states"]
+    if ars:
+        print("## Device linearised at the REFERENCE'S OWN recorded states (pose, code and depth samples injected bit for bit), compared with the reference's recorded H / b / dx / V / K directly\n")
+        print("Every iteration of every recorded run (tests/test_gpu_forensics.py::test_linearisation_at_reference_states).  strict = V and K identical to the reference's, H and b within 1e-4.\n")
+        print("| golden | iterations | strict | iterations with named flips | max rel dH | max rel db | max rel d(dx) | K per iteration |")
+        print("|---|---|---|---|---|---|---|---|")
+        for r in sorted(ars, key=lambda r: r["case"]):
+            print("| %s | %d | %d | %d | %.2e | %.2e | %.2e | %s |" % (r["case"], r["n"], r["strict"], sum(1 for f in r["flips"] if f), max(r["rel_H"]), max(r["rel_b"]),
+                                                                   max(r["rel_dx"]), r["K"]))
+        print("\n(rel d(dx) is dominated by the three rotation-prior entries of b: k4 = 1e7 times a residual that is a difference of two numbers ~1, i.e. float32 ulp noise in the reference itself; the test bounds dx through |H^-1| with that term.)\n")
+    chf = [r for (k, _, _d), r in last.items() if k == "chained_forensic"]
+    if chf:
+        print("## Chained run beside the reference's recorded trajectory: every step's difference decomposed\n")
+        print("local = device step vs oracle step FROM THE DEVICE'S OWN STATE (asserted: identical sets or named flips, dx to 1e-4 through |H^-1|); propagated = oracle step from the device's state vs the "
+              "reference's recorded step = the MAP's response to the state difference that came in.  Per-case tables with the named samples: profiles/r03_forensics_*.md.\n")
+        print("| golden | first iteration whose sets differ from the recorded ones | max local rel d(dx) | max propagated rel d(dx) | incoming state diff at that iteration | samples named (explained) | final rot / scale / trans / code | reference's own 1-ulp spread |")
+        print("|---|---|---|---|---|---|---|---|")
+        for r in sorted(chf, key=lambda r: r["case"]):
+            f = r["first_flip_iteration"]
+            m, sp = r["final"], r["reference_spread"]
+            print("| %s | %s | %.2e | %.2e | %s | %d (%d) | %.1e / %.1e / %.1e / %.1e | %.1e / %.1e / %.1e / %.1e |" % (
+                r["case"], "none" if f is None else f, max(r["local_rel_dx"]), max(r["propagated_rel_dx"]), "-" if f is None else "%.1e" % r["incoming_state_diff"][f],
+                r["flips_named"], r["flips_explained"], m["rot"], m["scale"], m["trans"], m["code"], sp["rot"], sp["scale"], sp["trans"], sp["code"]))
+        print()
+    pg = [r for (k, _, _d), r in last.items() if k == "prepass_guard"]
+    if pg:
+        print("## Prepass WITHOUT the audit: always-on guard (every re-decoded sample compared with the prepass value it replaces)\n")
+        print("| case | dtype | largest abs(sdf_lp - sdf_fp32) the guard saw | margin of a zero code | guard trips | re-run with prepass off | bit-identical to prepass off |")
+        print("|---|---|---|---|---|---|---|")
+        for r in sorted(pg, key=lambda r: (r["case"], r["dtype"])):
+            print("| %s | %s | %.3g | %.3g | %d | %s | %s |" % (r["case"], r["dtype"], r["guard_max_err"], r["delta_zero_code"], r["trips"], r.get("rerun", False), r["identical"]))
+        print()
     e2e = [r for (k, _, _d), r in last.items() if k == "end_to_end"]
     if e2e:
         print("## Chained GN run vs the reference's final result (golden files recorded from the unmodified reference)\n")

@@ -168,7 +168,7 @@ def main():
            "  512 rows and the xyz k-steps carry split-precision products).",
            "* Matrix pipe busy: **%.1f %%** (first round-2 profile: 53.8 %%); shader clock averaged over launches of very different length %.2f GHz (the long"
            % (100 * busy(K0), clk(K0)),
-           "  ones run at 1.7-1.8 GHz: `tools/gpu_prepass_probe.py`) -- the chip clocks down under 16-bit MFMA load, so part of every cycle saved comes back",
+           "  ones run at 1.7-1.8 GHz: `tools/probes/gpu_prepass_probe.py`) -- the chip clocks down under 16-bit MFMA load, so part of every cycle saved comes back",
            "  as clock, not throughput (MI355X_MICROARCH.md, DVFS).",
            "* Fabric reads: %.4g KiB x 2 = %.1f GB over %.1f M points = **%.0f B per point**: the 3.6 MB f16 weight stream fits the 4 MiB L2."
            % (fe[(K0, "FETCH_SIZE")][1], k0_fetch / 1e9, k0_pts / 1e6, k0_fetch / k0_pts),

@@ -2,7 +2,7 @@
 """Development aid: throughput of the automatic (adaptive) ray-pass mode for several batch sizes."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from dsp_slam_amd import fixtures, synth, engine as E
 from dsp_slam_amd.deep_sdf.deep_sdf_decoder import fold_weight_norm

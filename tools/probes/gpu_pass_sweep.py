@@ -2,7 +2,7 @@
 """Development aid: throughput / latency versus the number of front-to-back ray passes."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from dsp_slam_amd import fixtures, synth, engine as E
 from dsp_slam_amd.deep_sdf.deep_sdf_decoder import fold_weight_norm
@@ -10,7 +10,7 @@ layers = fold_weight_norm(fixtures.load_decoder_npz(fixtures.fixture_path("cars"
 eng = E.Engine(layers, [4], 64, device=0)
 prm = E.gn_params()
 SWEEPS = ((32, (1, 3, 5, 7, 10, 13, 17, 25)), (1, (1, 2, 3, 4, 5, 7, 10)), (4, (2, 3, 5, 7, 10)))
-if len(sys.argv) > 2:      # python tools/gpu_pass_sweep.py <objects> <passes,passes,...>
+if len(sys.argv) > 2:      # python tools/probes/gpu_pass_sweep.py <objects> <passes,passes,...>
     SWEEPS = ((int(sys.argv[1]), tuple(int(x) for x in sys.argv[2].split(","))),)
 for B, sweep in SWEEPS:
     objs = synth.make_batch(B, first_seed=1, n_surface=2000, n_background=500)

@@ -2,7 +2,7 @@
 """Development aid: throughput of the low-precision prepass kernel alone (dsp_decode_sdf_prepass on resident points)."""
 import os, sys, time, ctypes as C
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from dsp_slam_amd import fixtures, engine as E, _lib as L
 from dsp_slam_amd.deep_sdf.deep_sdf_decoder import fold_weight_norm

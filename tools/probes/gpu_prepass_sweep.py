@@ -2,7 +2,7 @@
 """Development aid: step time of the bench workload (N cfg2 objects, 10 iterations) by prepass mode and pass count."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from dsp_slam_amd import fixtures, synth, engine as E, _lib as L
 from dsp_slam_amd.deep_sdf.deep_sdf_decoder import fold_weight_norm

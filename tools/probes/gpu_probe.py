@@ -2,7 +2,7 @@
 """Quick on-GPU sanity + timing probe (development aid): decoder parity on a few sizes, one cfg2 batch."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import dsp_oracle as O
 from dsp_slam_amd import fixtures, synth, engine as E

@@ -3,7 +3,7 @@
 (16-point tiles, rows split over waves) forms; joint optimisation and pose-only."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from dsp_slam_amd import fixtures, synth, engine as E
 from dsp_slam_amd.deep_sdf.deep_sdf_decoder import fold_weight_norm
