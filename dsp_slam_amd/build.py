@@ -175,5 +175,26 @@ def build_locked(force=False, verbose=False):
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
+def build_variant(name, flags, verbose=False):
+    """Development aid for A/B measurements inside one gpurun call: the same sources compiled with extra hipcc flags (e.g. -DLP_ABL_NOBAR)
+    into lib/libdspgn_<name>.so (own object directory; same ISA checks).  Select it at run time with DSPGN_LIB=<path> (dsp_slam_amd/_lib.py)."""
+    global OBJ_DIR, LIB_PATH
+    saved = (OBJ_DIR, LIB_PATH, dict(EXTRA_FLAGS))
+    try:
+        OBJ_DIR = os.path.join(LIB_DIR, "obj_" + name)
+        LIB_PATH = os.path.join(LIB_DIR, "libdspgn_%s.so" % name)
+        for src in SOURCES:
+            EXTRA_FLAGS[src] = EXTRA_FLAGS.get(src, []) + list(flags)
+        return build(force=True, verbose=verbose)
+    finally:
+        OBJ_DIR, LIB_PATH = saved[0], saved[1]
+        EXTRA_FLAGS.clear()
+        EXTRA_FLAGS.update(saved[2])
+
+
 if __name__ == "__main__":
+    if "--variant" in sys.argv:        # python -m dsp_slam_amd.build --variant NAME -DFLAG ...
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:], verbose=False))
+        sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True))

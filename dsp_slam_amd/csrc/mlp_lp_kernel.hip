@@ -83,6 +83,7 @@ struct LpRing {            // weight-stream state, all wave-uniform
     const char* isrc;      // ... inside the chunk being issued
     unsigned ring0, idst;  // LDS byte addresses: ring start + this wave's quarter; destination of the chunk being issued
     char* ring_ptr;
+    unsigned ring_lane;    // LDS byte address of the ring start + lane * 16: base of this lane's A-fragment reads
 };
 
 __device__ __forceinline__ void lp_issue_next(LpRing& rg) {
@@ -167,8 +168,14 @@ __device__ __forceinline__ void lp_pass(const LpPass pd, u32x4 (&in)[32], u32x4 
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int nx_slot = (rg.rd_slot + 1 == LP_NBUF) ? 0 : rg.rd_slot + 1;
-            const char* cbp = rg.ring_ptr + rg.rd_slot * CHUNK_BYTES + lane * 16;
-            const char* nbp = rg.ring_ptr + nx_slot * CHUNK_BYTES + lane * 16;
+            // This lane's LDS byte address inside the chunk being read and inside the next one, each as ONE opaque 32-bit register: every
+            // A-fragment read below is then `ds_read_b128 v, base offset:imm`.  Left to itself hipcc materialises a separate address for
+            // every (slot, k-step, row tile), parks them in AGPRs and pays a v_accvgpr_read (often two) per ds_read -- 1.0-1.9 extra
+            // instructions per MFMA in a one-wave-per-SIMD kernel where every issued instruction costs matrix-pipe time.
+            typedef const __attribute__((address_space(3))) char* lds_cptr;
+            unsigned cb_a = rg.ring_lane + (unsigned)rg.rd_slot * CHUNK_BYTES, nb_a = rg.ring_lane + (unsigned)nx_slot * CHUNK_BYTES;
+            asm volatile("" : "+v"(cb_a), "+v"(nb_a));
+            const lds_cptr cbp = (lds_cptr)(size_t)cb_a, nbp = (lds_cptr)(size_t)nb_a;
 #pragma unroll
             for (int sl = 0; sl < LP_KSTEPS_PER_CHUNK; ++sl) {
                 const int s = LP_KSTEPS_PER_CHUNK * c + sl;
@@ -189,17 +196,17 @@ __device__ __forceinline__ void lp_pass(const LpPass pd, u32x4 (&in)[32], u32x4 
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         const int sp = sl + 2 + q;
-                        const char* src = (sp < LP_KSTEPS_PER_CHUNK) ? cbp + sp * LP_KSTEP_BYTES : nbp + (sp - LP_KSTEPS_PER_CHUNK) * LP_KSTEP_BYTES;
-                        abuf[sp % 4][0] = *reinterpret_cast<const u32x4*>(src);
-                        abuf[sp % 4][1] = *reinterpret_cast<const u32x4*>(src + 1024);
+                        const lds_cptr src = (sp < LP_KSTEPS_PER_CHUNK) ? cbp + sp * LP_KSTEP_BYTES : nbp + (sp - LP_KSTEPS_PER_CHUNK) * LP_KSTEP_BYTES;
+                        abuf[sp % 4][0] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(src);
+                        abuf[sp % 4][1] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(src + 1024);
                     }
                 }
 #else
                 const int sp = sl + LP_PREFETCH;
-                const char* src = (sp < LP_KSTEPS_PER_CHUNK) ? cbp + sp * LP_KSTEP_BYTES : nbp + (sp - LP_KSTEPS_PER_CHUNK) * LP_KSTEP_BYTES;
+                const lds_cptr src = (sp < LP_KSTEPS_PER_CHUNK) ? cbp + sp * LP_KSTEP_BYTES : nbp + (sp - LP_KSTEPS_PER_CHUNK) * LP_KSTEP_BYTES;
 #if !defined(LP_ABL_NOLDS)
-                abuf[sp % 4][0] = *reinterpret_cast<const u32x4*>(src);
-                abuf[sp % 4][1] = *reinterpret_cast<const u32x4*>(src + 1024);
+                abuf[sp % 4][0] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(src);
+                abuf[sp % 4][1] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(src + 1024);
 #endif
 #endif
                 const u32x4 a0 = abuf[sl % 4][0], a1 = abuf[sl % 4][1];
@@ -266,6 +273,7 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpArgs a) {
     rg.ring0 = lds_addr(ring_ptr) + wave * 4096;
     rg.idst = rg.ring0;
     rg.ring_ptr = ring_ptr;
+    rg.ring_lane = lds_addr(ring_ptr) + lane * 16;
 #pragma unroll
     for (int i = 0; i < LP_NBUF - 1; ++i) {
         glds_quarter(rg.isrc, rg.lane_off, rg.idst);

@@ -45,6 +45,23 @@ def _worker(rank, world, port, out_path, n_obj=N_OBJ):
     a, b = shards[rank]
     local = _solve(objs[a:b]) if b > a else np.zeros((0, D.RESULT_WIDTH), np.float32)    # an empty shard still joins the gather
     full = D.gather_results(local, shards, dist)
+    # the device-resident form bench.py uses (gather_results_device): the library copies each batch's packed rows to the address the
+    # collective sends from.  Here the "batches" are host stand-ins that do that copy with memmove into a CPU tensor (gloo); on the GPU
+    # box engine.Batch.results_packed_to_device does it device-to-device (tests/test_gpu_configs.py).  Two batches per rank where the
+    # shard has two or more objects: their rows must land back to back.
+    import ctypes
+
+    class HostBatch(object):
+        def __init__(self, rows):
+            self.rows, self.n = np.ascontiguousarray(rows, np.float32), rows.shape[0]
+
+        def results_packed_to_device(self, dst_ptr):
+            ctypes.memmove(int(dst_ptr), self.rows.ctypes.data, self.rows.nbytes)
+
+    k = local.shape[0] // 2
+    batches = [HostBatch(local[:k]), HostBatch(local[k:])] if local.shape[0] >= 2 else [HostBatch(local)]
+    full_dev = D.gather_results_device(batches, shards, dist, torch.device("cpu"))
+    assert (full_dev is None) == (full is None) and (full is None or np.array_equal(full_dev, full))
     dist.barrier()
     if rank == 0:
         np.save(out_path, full)
