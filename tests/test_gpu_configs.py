@@ -3,6 +3,7 @@ batch, cfg4 = objects sharded over ranks + gather, cfg5 = 4000-point objects, Re
 mixed batch) plus size-independent properties at full size: run-to-run determinism, batch-permutation equivariance,
 shard/gather == unsharded."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -438,3 +439,19 @@ def test_device_resident_gather_through_torch_distributed(eng):
             dist.destroy_process_group()
     assert np.array_equal(got, want)
     b1.close(); b2.close()
+
+
+def test_build_info_of_the_library_that_ran(eng):
+    """Which compiler produced the code object these tests just executed, and which HIP runtime executed it: the decoder kernels rely on
+    codegen properties checked at build time (dsp_slam_amd/build.py: check_isa), so a library rebuilt by a different hipcc on the GPU box
+    must be visible in the test record, not silent."""
+    import ctypes as C
+    from dsp_slam_amd import _lib as L
+    lib = L.load()
+    info = lib.dsp_build_info().decode()
+    rt, drv = C.c_int32(0), C.c_int32(0)
+    assert lib.dsp_runtime_versions(C.byref(rt), C.byref(drv)) == 0
+    assert "ISA assumptions checked at build time" in info and "clang" in info and rt.value > 0
+    assert lib.dsp_device_count() >= 1
+    print("\n%s\nHIP runtime %d, driver %d, library %s" % (info, rt.value, drv.value, L.lib_path()))
+    parity_log(kind="build_info", case="libdspgn", info=info, hip_runtime=rt.value, hip_driver=drv.value, lib=os.path.basename(L.lib_path()))

@@ -22,6 +22,8 @@ def main():
         last[(r["kind"], r.get("case", ""), r.get("dtype", ""))] = r
     print("# Parity report -- measured on MI355X by `pytest -m gpu` (tests/conftest.py:parity_log)\n")
     print("Every number is |device - reference| (or oracle) as the test measured it, next to the bound it was held to.\n")
+    for r in [r for (k, _, _d), r in last.items() if k == "build_info"]:
+        print("Library that ran: `%s` -- %s; HIP runtime %s, driver %s.\n" % (r["lib"], r["info"], r["hip_runtime"], r["hip_driver"]))
     ars = [r for (k, _, _d), r in last.items() if k == "at_reference_states"]
     if ars:
         print("## Device linearised at the REFERENCE'S OWN recorded states (pose, code and depth samples injected bit for bit), compared with the reference's recorded H / b / dx / V / K directly\n")
