@@ -311,16 +311,34 @@ def main():
             "alg_flop_per_launch": round(lp_pts * F_FWD / max(n_lp, 1)),
             "points_over_insphere": round(lp_pts / max(insphere_pts, 1.0), 4),
             "delta": acc.get("prepass_delta"),
-            # what actually bounds this kernel: LDS bandwidth.  One v_mfma_f32_32x32x16 (32 cycles) needs one 1 KiB A fragment per wave from LDS
-            # = 128 B/clk/CU for the four waves = the CU's whole LDS read bandwidth, and the LDS-DMA refill of the ring writes another quarter
-            # of that.  Per 128-point tile: 232 chunks x 16 KiB x (4 waves reading + 1 DMA write) = 18.1 MiB through the LDS
-            "lds_roofline": {"bound": "lds", "bytes_per_tile": 232 * 16384 * 5, "achieved": round(lp_pts / 128.0 * 232 * 16384 * 5 / (lp_ms * 1e-3) / 1e12, 2) if lp_ms > 0 else None,
-                             "peak": round(128 * 256 * 2.4e9 / 1e12, 1), "unit": "TB/s",
-                             "frac": round(lp_pts / 128.0 * 232 * 16384 * 5 / (lp_ms * 1e-3) / (128 * 256 * 2.4e9), 4) if lp_ms > 0 else None,
-                             "note": "peak at the nominal 2.4 GHz; the chip holds ~1.73 GHz under this kernel (tools/gpu_power_probe.py, profiles/r03_power_probe.md), at which it moves ~0.9 of the LDS bandwidth"},
             "traffic": pmc.get("lp_fetch_bytes_per_point", 0.0) * lp_pts / max(n_lp, 1) or None,
         }
 
+    if mode and world == 1:
+        # the clock the chip grants under this kernel (dense 16-bit MFMA): shader cycles / wall ticks of workgroup 0 of a bare prepass decode
+        try:
+            import ctypes as C
+            from dsp_slam_amd import _lib as L
+            lib = L.load()
+            lib.dsp_debug_last_clocks.restype = C.c_int
+            lib.dsp_debug_last_clocks.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+            rngp = np.random.default_rng(0)
+            ppts = rngp.uniform(-0.6, 0.6, size=(128 * 256 * 24, 3)).astype(np.float32)
+            pcode = np.zeros(64, np.float32)
+            mhz = []
+            for _ in range(6):
+                eng.decode_sdf_prepass(pcode, ppts, 1 if mode == 1 else 2)
+                clk = (C.c_uint64 * 4)()
+                L.check(lib.dsp_debug_last_clocks(eng._h, clk), eng._h, "clk")
+                mhz.append((clk[2] - clk[0]) / ((clk[3] - clk[1]) / 100e6) / 1e6)
+            clk_mhz = float(np.median(mhz[1:]))
+            result["prepass"]["sustained_clock_mhz"] = round(clk_mhz)
+            result["prepass"]["frac_of_peak_at_sustained_clock"] = round(lp_tflops / (PEAK_16BIT_MFMA_TFLOPS * clk_mhz / 2400.0), 4)
+            result["prepass"]["clock_note"] = ("the chip holds this clock under dense 16-bit MFMA while drawing LESS socket power than under the fp32 kernel at 2.37 GHz "
+                                               "(profiles/r03_power_probe.md); LDS array 37 % busy, 3 non-MFMA instructions per MFMA: neither LDS- nor issue-bound (DESIGN.md K0)")
+        except Exception as e:
+            result["prepass"]["sustained_clock_mhz"] = None
+            result["prepass"]["clock_note"] = "clock probe failed: %r" % (e,)
     if mode:
         result["prepass"]["guard"] = {"trips": acc.get("prepass_guard_trips", 0.0), "reruns": acc.get("prepass_guard_rerun", 0.0),
                                       "max_err_seen": acc.get("prepass_guard_max_err", 0.0),
