@@ -134,7 +134,10 @@ int dsp_compute_sdf_loss(dsp_handle* h, const float* pts_cam, int64_t n, const f
 /* compute_render_loss(decoder, ray_directions, depth_obs, t_obj_cam, sampled_ray_depth, latent_vector, th)
  * -- reconstruct/loss.py:46-152.  *k_out = number of rows K, or -1 when the reference returns None
  * (< 10 in-sphere samples).  Outputs need capacity n_rays * n_depths rows; row order = the reference's
- * (ray-major, depth-minor).  v_out / m_out (optional) receive the ragged set sizes V and m. */
+ * (ray-major, depth-minor).  v_out / m_out (optional) receive the ragged set sizes V and m.  m (samples with |sdf| < th) is
+ * INFORMATIONAL: with early ray termination or the prepass on, samples behind a ray's first solid sample are not decoded (their
+ * transmittance is exactly 0, so they cannot reach K, the rows or the results), and they are not counted in m either -- it can be smaller
+ * than the reference's m.  V and K are the reference's. */
 int dsp_compute_render_loss(dsp_handle* h, const float* rays, int64_t n_rays, const float* depth_obs,
                             const float* t_obj_cam, const float* sampled_depth, int32_t n_depths, const float* code,
                             float th, int64_t* k_out, float* jac_pose, float* jac_code, float* res, int64_t* v_out,

@@ -4,11 +4,11 @@
     and depth samples injected bit for bit (dsp_batch_set_start_state) -- for EVERY iteration of every recorded run, and H, b, dx, V, K are
     compared with what the unmodified reference recorded (tests/golden/golden_recon_*.npz: it_*), not with the oracle.  Every iteration
     must be strict (identical sets, 1e-4) unless every differing sample is NAMED and lies within round-off of the threshold it crossed.
-(b) test_chained_run_follows_the_reference_until_a_named_flip: the chained device run is laid beside the reference's recorded trajectory
-    iteration by iteration.  Either it selects the reference's sets all the way, and then the final pose / code agree to 1e-4 -- or there
-    is a FIRST iteration whose sets differ, up to which the two states agree to round-off, and the samples that switched sets there are
-    listed with their distance to the threshold (`|‖p‖-1|`, `||sdf|-th|`, `|de_do-1e-2|`).  Nothing is attributed to "chaos" without a
-    named sample.
+(b) test_chained_divergence_is_the_maps_own: the chained device run is laid beside the reference's recorded trajectory iteration by
+    iteration and every step's difference is decomposed into the device's LOCAL error (device step vs oracle step from the device's own
+    state: asserted, identical sets or named samples, dx to 1e-4) and the PROPAGATED part (the map's own response to the state
+    difference that came in: reported).  Where the device's sets first depart from the recorded ones, the samples that switched are
+    listed with their distance to the threshold (`|‖p‖-1|`, `||sdf|-th|`, `|de_do-1e-2|`).
 Reports go to gpurun_out/parity/ (parity_log) and gpurun_out/forensics_<case>.md; tools/make_parity_report.py collects them.
 """
 import json
@@ -96,8 +96,10 @@ def test_linearisation_at_reference_states(eng, oracle_decoder, name):
             report += ["", "iteration %d:" % e] + ["* " + _fmt_flip(f) for f in flips] + [""]
         else:
             strict += 1
-            assert rh < 1e-4, (e, rh)
-            assert rb < 2e-4, (e, rb)
+            # measured on MI355X (profiles/parity_r03.md): rel dH <= 9.2e-6, rel db <= 3.7e-5 over all 35 recorded iterations; the bounds
+            # leave a factor of three, so a 10x regression of the per-step agreement fails here
+            assert rh < 3e-5, (e, rh)
+            assert rb < 1.2e-4, (e, rb)
             assert np.all(np.abs(tr["b"][0][3:6] - b_ref[3:6]) <= _rot_prior_bound(h_ref, k4) + 2e-4 * np.abs(b_ref).max())
             # dx = H^-1 b inherits what is accepted on b through |H^-1| (near convergence b, hence dx, is a difference of large terms)
             tol_b = np.full(71, 2e-4 * np.abs(b_ref[mask]).max())
