@@ -30,7 +30,11 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef __bf16 b8 __attribute__((ext_vector_type(8)));
 typedef __bf16 b2 __attribute__((ext_vector_type(2)));
 
-constexpr int LP_PREFETCH = 2;     // A fragments are read this many k-steps ahead of their MFMAs (4 rotating buffers)
+#ifndef LP_PREFETCH_K
+#define LP_PREFETCH_K 2
+#endif
+constexpr int LP_PREFETCH = LP_PREFETCH_K;     // A fragments are read this many k-steps ahead of their MFMAs (4 rotating buffers: <= 3)
+static_assert(LP_PREFETCH >= 1 && LP_PREFETCH <= 3, "the A-fragment buffers rotate over 4 slots");
 constexpr int LP_KSTEP_BYTES = 2048;   // two 1 KiB A fragments (row tiles 2g, 2g+1) per k-step
 constexpr int LP_NCH = 4;              // chunks per output group of a hidden layer: 32 k-steps = 512 slab rows
 constexpr int LP_NOG = 8;              // 64-row output groups per layer
