@@ -342,7 +342,7 @@ def main():
     if mode:
         result["prepass"]["guard"] = {"trips": acc.get("prepass_guard_trips", 0.0), "reruns": acc.get("prepass_guard_rerun", 0.0),
                                       "max_err_seen": acc.get("prepass_guard_max_err", 0.0),
-                                      "note": "always on: the fp32 kernel re-decodes the widened band + 1/64 of the classified samples and compares"}
+                                      "note": "always on: the fp32 kernel compares every sample it re-decodes (the whole widened band + 1/8 of the ring beyond it + 1/512 of the rest) with the prepass value"}
     if off_run is not None:
         o_el, o_ranks, o_acc, o_steps = off_run
         o_tf = o_acc["n_fwd_points"] * F_FWD / (o_acc["ms_mlp_fwd"] * 1e-3) / 1e12 if o_acc["ms_mlp_fwd"] > 0 else 0.0

@@ -192,7 +192,8 @@ void launch_surface(const ObjConst* oc, const ObjState* st, const float* pts, fl
 void launch_build_tiles(const ObjConst* oc, const ObjState* st, int B, int mode, int4* tiles, int* n_tiles, double* counters, int add_v, int tile_pts,
                         int cnt_slot, hipStream_t s);   // mode 3 = mode 1 with the band samples (P) in place of the kept render rows (K)   // cnt_slot: counter the point count of a mode 0 / 2 list is added to
 // th = cut_off; the widened band of object b is |sdf_lp| < th + st[b].lp_delta.  guard_salt: samples OUTSIDE the band whose id hash
-// (xor salt) is 0 mod 64 are selected too, so that the fp32 kernel re-decodes them and prepass_guard compares (0 = no guard samples)
+// (xor salt) selects them (1/8 of the ring just beyond the band, 1/512 farther out) are listed too, so that the fp32 kernel re-decodes them
+// and prepass_guard compares (0 = no guard samples)
 void launch_band_select(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff, const float* ssdf, float th,
                         unsigned guard_salt, int* pcnt, int* poff, int* plist, int maxR, int B, hipStream_t s);
 // fused per-object forms (latency path): front = sample_count + scan + sample_write + surface; band = count + scan + write;

@@ -366,11 +366,20 @@ __global__ void k_pass_update(const ObjConst* oc, const ObjState* st, const unsi
 // 0, so nothing there can reach the result.  What is left for the fp32 kernel: the samples IN FRONT of a ray's first
 // certainly-solid sample whose |sdf_lp| < th + delta.  Their exact values then replace the low-precision ones in ssdf; the
 // classified samples keep sdf_lp (any value beyond +-th gives the same occupancy bit for bit).
-// Guard samples: a 1/64 sample (id hash xor a per-launch salt) of the samples the prepass CLASSIFIED -- beyond the widened band, up to
-// and including the ray's first certainly-solid sample -- joins the list, so that the fp32 kernel re-decodes it and prepass_guard
-// (mlp_common.h) compares the two values.  Its exact value then replaces the prepass value: the same occupancy, bit for bit, whenever
-// the classification was right.  salt == 0: no guard samples.
-__device__ __forceinline__ bool guard_pick(unsigned id, unsigned salt) { return salt != 0u && ((id_hash(id) ^ salt) & 63u) == 0u; }
+// Guard samples: a sample of the samples the prepass CLASSIFIED -- beyond the widened band, up to and including the ray's first
+// certainly-solid sample -- joins the list, so that the fp32 kernel re-decodes it and prepass_guard (mlp_common.h) compares the two
+// values.  Its exact value then replaces the prepass value: the same occupancy, bit for bit, whenever the classification was right.
+// Stratified by where an error would matter: 1/8 of the RING th + delta <= |sdf_lp| < th + 2 delta (an error between delta and 2 delta
+// misclassifies exactly these), 1/512 of everything farther out (there only a gross failure -- overflow, a broken weight stream --
+// can misclassify, and a gross failure hits many samples).  Together with the band itself, where EVERY sample is compared, that is
+// ~0.3 % of the in-sphere samples on the bench workload.  The id hash is xor-ed with a per-launch salt; salt == 0: no guard samples.
+__device__ __forceinline__ bool guard_pick(unsigned id, unsigned salt, bool ring) {
+#if defined(GUARD_UNIFORM_64)      // A/B aid: the round-3 first form, a uniform 1/64 sample
+    return salt != 0u && ((id_hash(id) ^ salt) & 63u) == 0u;
+#else
+    return salt != 0u && ((id_hash(id) ^ salt) & (ring ? 7u : 511u)) == 0u;
+#endif
+}
 
 __device__ __forceinline__ void band_count_ray(const ObjConst& c, const ObjState& s, const unsigned long long* raymask, const int* rayoff,
                                                const float* ssdf, float th, unsigned salt, int* pcnt, int r) {
@@ -384,7 +393,7 @@ __device__ __forceinline__ void band_count_ray(const ObjConst& c, const ObjState
             const int j = __ffsll((long long)mask) - 1;
             mask &= mask - 1;
             const float v = sd[i];
-            const bool pick = v != 1.0f && guard_pick(((unsigned)r << 6) | (unsigned)j, salt);
+            const bool pick = v != 1.0f && guard_pick(((unsigned)r << 6) | (unsigned)j, salt, fabsf(v) < thd + s.lp_delta);
             n += (fabsf(v) < thd || pick) ? 1 : 0;
             if (v <= -thd) break;
         }
@@ -404,7 +413,7 @@ __device__ __forceinline__ void band_write_ray(const ObjConst& c, const ObjState
         const int j = __ffsll((long long)mask) - 1;
         mask &= mask - 1;
         const float v = ssdf[base + i];
-        const bool pick = v != 1.0f && guard_pick(((unsigned)r << 6) | (unsigned)j, salt);
+        const bool pick = v != 1.0f && guard_pick(((unsigned)r << 6) | (unsigned)j, salt, fabsf(v) < thd + s.lp_delta);
         if (fabsf(v) < thd || pick) *dst++ = base + i;
         if (v <= -thd) break;
     }
@@ -753,18 +762,19 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_front_fused(const ObjConst* o
 // k_band_count + k_scan_rays(2) + k_band_write: one THREAD per ray, the ray's <= 64 sample values as independent loads (the
 // front-to-back walk of band_count_ray becomes mask arithmetic: first certainly-solid sample = lowest set bit)
 __device__ __forceinline__ unsigned long long band_select_thread(const ObjConst& c, const unsigned long long* raymask, const int* rayoff,
-                                                                 const float* ssdf, float thd, unsigned salt, int r, int& base) {
+                                                                 const float* ssdf, float thd, float delta, unsigned salt, int r, int& base) {
     const int gr = c.ray_off + r;
     const unsigned long long rmask = raymask[gr];
     const int cnt = __popcll(rmask);
     base = c.samp_off + rayoff[gr];
-    unsigned long long solid = 0ull, band = 0ull, decoded = 0ull;
+    unsigned long long solid = 0ull, band = 0ull, decoded = 0ull, ring = 0ull;
 #pragma unroll
     for (int k = 0; k < 64; ++k) {
         const float v = ssdf[k < cnt ? base + k : c.samp_off];
         if (k < cnt && v <= -thd) solid |= 1ull << k;
         if (k < cnt && fabsf(v) < thd) band |= 1ull << k;
         if (k < cnt && v != 1.0f) decoded |= 1ull << k;
+        if (k < cnt && fabsf(v) < thd + delta) ring |= 1ull << k;
     }
     const int first = solid ? __ffsll((long long)solid) - 1 : 64;     // samples behind the first certainly-solid one are skipped
     if (salt) {       // guard samples (band_count_ray): classified samples up to and including the first certainly-solid one
@@ -772,7 +782,7 @@ __device__ __forceinline__ unsigned long long band_select_thread(const ObjConst&
         for (int k = 0; m; ++k) {
             const int j = __ffsll((long long)m) - 1;
             m &= m - 1;
-            if (guard_pick(((unsigned)r << 6) | (unsigned)j, salt)) pick |= 1ull << k;
+            if (guard_pick(((unsigned)r << 6) | (unsigned)j, salt, (ring >> k) & 1ull)) pick |= 1ull << k;
         }
         band |= pick & decoded;
         return first >= 63 ? band : band & ((2ull << first) - 1ull);
@@ -789,13 +799,13 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_band_fused(const ObjConst* oc
     const bool good = st[b].status == DSP_STATUS_GOOD;
     const float thd = th + st[b].lp_delta;
     int base;
-    for (int r = threadIdx.x; r < c.n_rays; r += FUSED_THREADS) pcnt[c.ray_off + r] = good ? __popcll(band_select_thread(c, raymask, rayoff, ssdf, thd, salt, r, base)) : 0;
+    for (int r = threadIdx.x; r < c.n_rays; r += FUSED_THREADS) pcnt[c.ray_off + r] = good ? __popcll(band_select_thread(c, raymask, rayoff, ssdf, thd, st[b].lp_delta, salt, r, base)) : 0;
     __syncthreads();
     scan_rays_block<FUSED_THREADS>(c, st, b, pcnt, poff, 2, part);
     __syncthreads();
     if (good) {
         for (int r = threadIdx.x; r < c.n_rays; r += FUSED_THREADS) {
-            unsigned long long sel = band_select_thread(c, raymask, rayoff, ssdf, thd, salt, r, base);
+            unsigned long long sel = band_select_thread(c, raymask, rayoff, ssdf, thd, st[b].lp_delta, salt, r, base);
             int pos = poff[c.ray_off + r];
             while (sel) {
                 const int idx = base + __ffsll((long long)sel) - 1;

@@ -92,7 +92,7 @@ __device__ __forceinline__ float relu1(float x) {
 
 // Always-on guard of the low-precision pre-classification (DESIGN.md "Prepass").  The prepass is exact as long as
 // |sdf_lp - sdf_fp32| < lp_delta for every sample it classifies.  The fp32 kernels re-decode every sample the prepass left inside the
-// widened band, plus a 1/64 sample of the ones it classified (k_band_*: guard samples), and each of those still holds its prepass value
+// widened band, plus a stratified sample of the ones it classified (k_band_*: guard samples), and each of those still holds its prepass value
 // where the fp32 value is about to be stored: compare them.  A difference of half the object's margin or more is a TRIP (counted per
 // wave, per object): the host then re-runs the batch with the prepass off (batch_run) -- results never depend on a margin that the
 // workload itself has shown to be thin.  The largest difference seen is kept as well (dsp_stats.prepass_guard_max_err).

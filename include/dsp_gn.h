@@ -86,8 +86,8 @@ typedef struct dsp_stats {
     float prepass_max_err;       /* audit only: max |sdf_lp - sdf_fp32| over the audited samples */
     double prepass_misclassified;/* audit only: samples classified against their fp32 value (must be 0) */
     double prepass_audited;      /* audit only: samples compared */
-    /* always-on prepass guard (ABI version 3): every sample the fp32 kernel re-decodes -- the widened band plus a 1/64 sample of the
-     * classified ones -- is compared with the prepass value it replaces */
+    /* always-on prepass guard (ABI version 3): every sample the fp32 kernel re-decodes -- the widened band plus a stratified sample of
+     * the classified ones -- is compared with the prepass value it replaces */
     double prepass_guard_trips;  /* waves that saw |sdf_lp - sdf_fp32| >= half the object's margin (0 in a healthy run) */
     double prepass_guard_objects;/* objects with at least one trip */
     float prepass_guard_max_err; /* largest |sdf_lp - sdf_fp32| over the compared samples */
@@ -220,9 +220,10 @@ int dsp_prepass_calibration(dsp_handle* h, int dtype, float* max_err, float* del
 int dsp_prepass_calibration_table(dsp_handle* h, int dtype, float* mags, float* max_err, float* delta, float* guard_err);
 /* Audit: every run also decodes all in-sphere samples in fp32 and fills dsp_stats.prepass_max_err / _misclassified / _audited. */
 int dsp_batch_set_prepass_audit(dsp_batch* b, int on);
-/* The guard is ON by default and costs ~1.5 % more fp32 points: with the prepass on, the fp32 kernel also re-decodes a 1/64 sample of
- * the samples the prepass classified (a different one every launch) and compares every sample it decodes with the prepass value it
- * replaces.  A difference of half the object's margin or more trips the guard: dsp_batch_run then runs the batch AGAIN with the
+/* The guard is ON by default and costs ~0.3 % more fp32 points: with the prepass on, the fp32 kernel also re-decodes a sample of the
+ * samples the prepass classified -- 1/8 of the ring th + delta <= |sdf_lp| < th + 2 delta, where an error between delta and 2 delta would
+ * misclassify, 1/512 of everything farther out; a different sample every launch -- and compares EVERY sample it decodes (the whole
+ * widened band included) with the prepass value it replaces.  A difference of half the object's margin or more trips the guard: dsp_batch_run then runs the batch AGAIN with the
  * prepass off and returns those results (dsp_stats.prepass_guard_rerun = 1), and the handle's margins are raised to 4 x the error
  * seen.  on = 0 turns the guard off (tests: what an unguarded run would have returned). */
 int dsp_batch_set_prepass_guard(dsp_batch* b, int on);

@@ -247,7 +247,7 @@ def test_reference_goldens_are_exact_without_the_audit(eng):
         run = _run_traced(eng, prm, tuple(args), L.PREPASS_F16, audit=False)
         _assert_identical(run, ref, name)
         assert run[2]["prepass_guard_trips"] == 0 and run[2]["prepass_guard_rerun"] == 0
-        # the guard's cost: the 1/64 sample of the classified samples that the fp32 kernel re-decodes
+        # the guard's cost: the stratified sample of the classified samples that the fp32 kernel re-decodes
         off = _run_traced(eng, prm, tuple(args), L.PREPASS_F16, audit=False, guard=False)
         _assert_identical(off, ref, name + " (guard off)")
         # (latency-sized objects send their band samples straight into the jacobian launch: count both kinds of fp32 points)
