@@ -143,7 +143,10 @@ def _run_traced(eng, cfg, obj, code=None):
     return res, traces, oprm
 
 
-E2E_SPREAD_FACTOR = 3.0    # chained runs: bound = this x the largest of the reference's 9 recorded round-off draws (see test_reconstruct_end_to_end)
+# chained runs: bound = this x the largest of the reference's 9 recorded round-off draws (see test_reconstruct_end_to_end).  Measured on
+# MI355X (profiles/parity_r03.md): device / spread <= 0.9 on five of the six goldens, 1.07 on `small` (the device is one more draw: it
+# exceeds the largest of nine exchangeable draws one time in ten per quantity).  Round 2 used 3.0.
+E2E_SPREAD_FACTOR = 1.5
 SDF_ROUNDOFF = 2e-7      # the two decoders agree to ~1e-7 (test_decode_sdf_vs_oracle); this is what propagates
 LAST_LINEARISATION = {}  # what the last compare_linearisation call measured (written to the parity report by its callers)
 
@@ -302,18 +305,13 @@ def end_to_end_differences(g, t44, code):
 def test_reconstruct_end_to_end(eng, name):
     """All iterations chained, against the reference's final pose / code (north_star: 1e-4 relative).
 
-    Tolerance per quantity: 1e-4, or E2E_SPREAD_FACTOR x the REFERENCE'S OWN spread when every element of its inputs moves to
-    an adjacent float32 (golden ulps_*: 8 seeded draws + the original one-direction draw; tools/make_golden_sensitivity.py),
-    whichever is larger.  (The device is one more round-off-sized perturbation of the reference: it exceeds the largest of 9
-    exchangeable draws one time in ten per quantity -- the spread is heavy-tailed, cfg2's code draws range 2.6e-4 .. 3.6e-3 --
-    hence a factor of 3 on the maximum.  An independent CPU fp32 restatement, the oracle, lands at the same distance from the
-    reference: cfg2 |dT| 9.3e-3, |dcode| 5.8e-3, tests/test_oracle_golden.py.  What pins parity at 1e-4 is the per-iteration
-    re-linearisation above, not this chained comparison.)  The 10-iteration map is discontinuous in its ragged sets, so round-off of that size -- which any re-ordering of
-    one float32 sum produces -- is amplified far beyond 1e-4 inside the reference itself (cfg2: 2e-2 on the translation;
-    `small`: one draw in eight flips a set and moves the pose by 3e-2) -- DESIGN.md "Parity".  Rotation (R / scale, entries
-    of magnitude <= 1: absolute), scale (relative), translation (relative to |t|) and code (absolute) are checked separately so
-    that the 18 m translation does not set the scale for the rotation entries.  The measured differences go to the parity
-    report (profiles/parity_rNN.md)."""
+    Tolerance per quantity: 1e-4, or E2E_SPREAD_FACTOR x the REFERENCE'S OWN spread when every element of its inputs moves to an adjacent
+    float32 (golden ulps_*: 8 seeded draws + the original one-direction draw; tools/make_golden_sensitivity.py), whichever is larger.
+    The chained map amplifies round-off (set flips and up to x100 per iteration without flips, measured in the
+    reference itself), so this comparison is a sanity bound; what pins parity is tests/test_gpu_forensics.py -- the device at the
+    reference's own recorded states (identical sets, H / b to 1e-5, all iterations) and the chained run decomposed step by step.
+    Rotation (R / scale: absolute), scale (relative), translation (relative to |t|) and code (absolute) are checked separately so that the
+    18 m translation does not set the scale for the rotation entries.  The measured differences go to profiles/parity_rNN.md."""
     g = golden(name)
     cfg = json.loads(str(g["cfg_json"]))
     prm, oprm = prm_from(cfg)
