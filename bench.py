@@ -109,13 +109,24 @@ def main():
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible)")
+    # Plumbing test only (tests/test_gpu_examples.py): DSP_BENCH_SHARE_GPU=1 puts every rank on device 0 and DSP_BENCH_BACKEND=gloo carries
+    # the gather on host tensors, so that the `torch.distributed.run --nproc-per-node N` launch path (rendezvous, per-rank shards, the
+    # build lock, gather order, max-over-ranks timing) can be exercised on a ONE-GPU box.  Numbers from such a run mean nothing.
+    share_gpu = os.environ.get("DSP_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("DSP_BENCH_BACKEND", "nccl")
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or os.environ.get("DSP_BENCH_FORCE_DIST") == "1":   # the env switch exercises the RCCL path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    coll_device = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
 
     from dsp_slam_amd import fixtures, synth, engine as E, distributed as D
     from dsp_slam_amd.deep_sdf.deep_sdf_decoder import fold_weight_norm
@@ -180,8 +191,10 @@ def main():
             st = bt.stats()
             k1_all["ms"] += st["ms_mlp_fwd"]
             k1_all["n"] += st["n_mlp_fwd_launches"]
-        if dist is not None:     # the single collective of the path: results device -> RCCL gather over xGMI -> rank 0's host, no host bounce
+        if dist is not None and backend == "nccl":     # the single collective of the path: results device -> RCCL gather over xGMI -> rank 0's host, no host bounce
             gathered[0] = D.gather_results_device(batches, shards, dist, device=torch.device("cuda", local_rank))
+        elif dist is not None:                         # plumbing test on gloo: host rows
+            gathered[0] = D.gather_results(np.concatenate([D.pack_results(*bt.results()) for bt in batches], 0), shards, dist)
         else:
             gathered[0] = np.concatenate([D.pack_results(*bt.results()) for bt in batches], 0)
 
@@ -212,7 +225,7 @@ def main():
         elapsed = time.perf_counter() - t0
         per_rank = [own]
         if dist is not None:
-            tt = torch.tensor([elapsed, own], dtype=torch.float64, device="cuda")
+            tt = torch.tensor([elapsed, own], dtype=torch.float64, device=coll_device)
             allt = [torch.empty_like(tt) for _ in range(world)]
             dist.all_gather(allt, tt)
             elapsed = max(float(x[0].item()) for x in allt)
@@ -270,7 +283,7 @@ def main():
             "name": args.config,
             "objects_per_gpu": B,
             "objects_good": n_good,
-            "parallelism": "object-sharded x%d, one RCCL gather of results per step" % world,
+            "parallelism": "object-sharded x%d, one RCCL gather of results per step" % world + (" [PLUMBING TEST: ranks share GPU 0, %s backend]" % backend if share_gpu else ""),
             "prepass": ["off", "f16", "bf16"][mode] + (" (exact pre-classification of ray samples; results bit-identical to off)" if mode else ""),
         },
         "roofline": {

@@ -35,3 +35,29 @@ def test_multi_gpu_c_abi_example(tmp_path):
     good = int(last[0].split(":")[1].split("good")[0])
     assert good >= 10, out.stdout
     print(out.stdout)
+
+
+@pytest.mark.gpu
+def test_bench_launch_path_with_two_ranks_on_one_gpu(tmp_path):
+    """The driver launches the multi-GPU bench as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...`.  This box has one GPU, so the LAUNCH PATH is exercised with both ranks on device 0 and the
+    gather on gloo (DSP_BENCH_SHARE_GPU / DSP_BENCH_BACKEND: plumbing switches, the numbers mean nothing): rendezvous, RANK / LOCAL_RANK /
+    WORLD_SIZE handling, two engines created concurrently (build lock), per-rank shards, gather order, barrier + max-over-ranks timing, ONE
+    JSON line from rank 0 with n_gpus = 2 and both ranks' times."""
+    import json
+    import socket
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, DSP_BENCH_SHARE_GPU="1", DSP_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--objects-per-gpu", "3", "--no-prepass-off"]
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and len(d["ms_per_step_by_rank"]) == 2 and d["value"] > 0
+    assert d["config"]["objects_good"] >= 2 and "PLUMBING TEST" in d["config"]["parallelism"]
