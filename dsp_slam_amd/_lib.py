@@ -82,6 +82,7 @@ SYMBOLS = [
     ("dsp_batch_set_ray_pass_bounds", C.c_int, [_VP, c_i32p, C.c_int]),
     ("dsp_batch_set_mask_reuse", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_set_fused_bookkeeping", C.c_int, [_VP, C.c_int]),
+    ("dsp_batch_set_tail_split", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_set_speculative_band", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_set_prepass", C.c_int, [_VP, C.c_int, C.c_float]),
     ("dsp_prepass_calibration", C.c_int, [_VP, C.c_int, c_f32p, c_f32p]),

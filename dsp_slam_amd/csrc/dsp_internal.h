@@ -194,6 +194,7 @@ void launch_build_tiles(const ObjConst* oc, const ObjState* st, int B, int mode,
 // th = cut_off; the widened band of object b is |sdf_lp| < th + st[b].lp_delta.  guard_salt: samples OUTSIDE the band whose id hash
 // (xor salt) selects them (1/8 of the ring just beyond the band, 1/512 farther out) are listed too, so that the fp32 kernel re-decodes them
 // and prepass_guard compares (0 = no guard samples)
+void launch_tail_tiles(const int4* tiles, int* n_tiles, int4* tiles16, int* n_tiles16, int n_cu, hipStream_t s);   // see k_tail_tiles
 void launch_band_select(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff, const float* ssdf, float th,
                         unsigned guard_salt, int* pcnt, int* poff, int* plist, int maxR, int B, hipStream_t s);
 // fused per-object forms (latency path): front = sample_count + scan + sample_write + surface; band = count + scan + write;

@@ -564,6 +564,32 @@ __global__ __launch_bounds__(256) void k_build_tiles(const ObjConst* oc, const O
     }
 }
 
+// Tail split of a forward tile list (latency-sized batches): a launch of T 64-point tiles on n_cu CUs takes ceil(T / n_cu) rounds of
+// one tile time each, and the last round is often nearly empty (one cfg2 object: 312 band tiles = one full round + 56).  When that
+// remainder is at most half a round, its tiles are re-listed as 16-point tiles for the latency-form kernel (mlp_split_kernel<false>,
+// ~0.3 of a 64-point tile's time, bit-identical results), which runs them in a launch of its own: the 64-point launch loses its
+// last round.  tiles16 needs 4 * (n_cu / 2) entries.
+__global__ __launch_bounds__(256) void k_tail_tiles(const int4* tiles, int* n_tiles, int4* tiles16, int* n_tiles16, int n_cu) {
+    const int T = n_tiles[0];
+    int tail = 0;
+    if (T > n_cu && T <= 8 * n_cu) {
+        const int r = T % n_cu;
+        if (r > 0 && r <= n_cu / 2) tail = r;
+    }
+    __syncthreads();                 // every thread has read T before thread 0 rewrites it
+    for (int i = threadIdx.x; i < tail; i += 256) {
+        const int4 td = tiles[T - tail + i];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            // a quarter beyond the tile's points is an empty tile: it keeps the tile's FIRST point as its (unused) address -- lanes without
+            // a point still read list entry td.x, and entries behind the tile's last point are not valid indices
+            const int n = max(0, min(SPLIT_TILE_PTS, td.y - SPLIT_TILE_PTS * q));
+            tiles16[4 * i + q] = make_int4(n > 0 ? td.x + SPLIT_TILE_PTS * q : td.x, n, td.z, td.w);
+        }
+    }
+    if (threadIdx.x == 0) { n_tiles[0] = T - tail; n_tiles16[0] = 4 * tail; }
+}
+
 // ------------------------------------------------------------------------------------------------
 // per-ray occupancy / transmittance scan  (loss.py:84-141)
 // ------------------------------------------------------------------------------------------------
@@ -1445,6 +1471,9 @@ void launch_surface(const ObjConst* oc, const ObjState* st, const float* pts, fl
 void launch_build_tiles(const ObjConst* oc, const ObjState* st, int B, int mode, int4* tiles, int* n_tiles, double* counters, int add_v, int tile_pts,
                         int cnt_slot, hipStream_t s) {
     hipLaunchKernelGGL(k_build_tiles, dim3(1), dim3(256), 0, s, oc, st, B, mode, tiles, n_tiles, counters, add_v, tile_pts, cnt_slot);
+}
+void launch_tail_tiles(const int4* tiles, int* n_tiles, int4* tiles16, int* n_tiles16, int n_cu, hipStream_t s) {
+    hipLaunchKernelGGL(k_tail_tiles, dim3(1), dim3(256), 0, s, tiles, n_tiles, tiles16, n_tiles16, n_cu);
 }
 void launch_render_scan(const ObjConst* oc, ObjState* st, const unsigned long long* m, const int* off, const float* ssdf, const float* depth,
                         float* sdeds, float* ray_res, int* kcnt, int* mcnt, int D, float th, int maxR, int B, hipStream_t s) {

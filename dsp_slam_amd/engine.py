@@ -132,6 +132,10 @@ class Batch(object):
         """-1 = automatic, 0 = band samples get a forward launch of their own, 1 = they go straight into the jacobian launch (latency path)."""
         L.check(L.load().dsp_batch_set_speculative_band(self._h, int(mode)), self.engine._h, "dsp_batch_set_speculative_band")
 
+    def set_tail_split(self, mode):
+        """-1 = automatic, 0 = off, 1 = the last partial round of the fp32 forward launch runs as 16-point latency-form tiles."""
+        L.check(L.load().dsp_batch_set_tail_split(self._h, int(mode)), self.engine._h, "dsp_batch_set_tail_split")
+
     def set_fused_bookkeeping(self, mode):
         """-1 = automatic, 0 = per-ray bookkeeping as separate launches (throughput form), 1 = fused per object (latency form)."""
         L.check(L.load().dsp_batch_set_fused_bookkeeping(self._h, int(mode)), self.engine._h, "dsp_batch_set_fused_bookkeeping")

@@ -239,6 +239,11 @@ int dsp_batch_set_mask_reuse(dsp_batch* b, int mode);
  * results.  -1 = automatic (on while the 16-point tiles fit a round or two over the CUs and mask reuse is off), 0 = off, 1 = on
  * (ignored while mask reuse is on). */
 int dsp_batch_set_split_rows(dsp_batch* b, int mode);
+/* Small batches: a forward launch of T 64-point tiles takes ceil(T / CUs) rounds and its last round is often nearly empty (one
+ * 2000-point object: 312 band tiles on 256 CUs).  With the tail split on, a remainder of at most half a round runs as 16-point
+ * latency-form tiles in a launch of its own (~0.3 of a 64-point tile's time).  -1 = automatic (on where the 64-point forward kernel runs
+ * without mask export), 0 = off, 1 = on where applicable.  Results are identical for every setting. */
+int dsp_batch_set_tail_split(dsp_batch* b, int mode);
 /* Per-ray bookkeeping (sampling + compaction, band selection, occupancy scan + row compaction) either as one thread block per 256 rays
  * with separate scan launches (throughput form) or fused per object (latency form: 3 launches instead of 11 per iteration).  -1 = automatic
  * (fused for batches of <= 16 objects), 0 = off, 1 = on.  Results are identical for every setting. */

@@ -320,6 +320,35 @@ def test_split_kernel_is_exact(eng, oracle_decoder):
     assert np.abs(t[0] - gp["out"]).max() / np.abs(gp["out"]).max() < 1e-4
 
 
+def test_tail_split_is_exact(eng):
+    """The last, mostly empty round of a 64-point forward launch handed to the latency-form kernel as 16-point tiles (k_tail_tiles):
+    one cfg2-size object (a few hundred band tiles on 256 CUs: one full round + a remainder) and a two-object batch, with the prepass on
+    and off -- every bit of every iteration equals the run without the split, and the forward launches get shorter."""
+    prm = E.gn_params(num_iterations=5)
+    for objs in ([synth.make_object(1, n_surface=2000, n_background=500)], synth.make_batch(2, first_seed=985, n_surface=1500, n_background=400)):
+        args = ([o["t_cam_obj_init"] for o in objs], [o["pts"] for o in objs], [o["rays"] for o in objs], [o["depth"] for o in objs])
+        for prepass in (1, 0):
+            out = {}
+            for tail in (0, 1):
+                b = eng.batch(prm, *args, trace=True)
+                b.set_prepass(prepass)
+                b.set_mask_reuse(0)
+                b.set_split_rows(-1)
+                b.set_tail_split(tail)
+                b.run()
+                b.run()
+                out[tail] = (b.results(), [b.trace(e) for e in range(5)], b.stats())
+                b.close()
+            for a, c in zip(out[1][0], out[0][0]):
+                assert np.array_equal(a, c)
+            for ta, tc in zip(out[1][1], out[0][1]):
+                for k in ("H", "b", "dx", "V", "K", "set_sums"):
+                    assert np.array_equal(ta[k], tc[k]), k
+            assert out[1][2]["n_fwd_points"] == out[0][2]["n_fwd_points"]
+            print("tail split, %d object(s), prepass %d: fp32 forward launches %.3f ms -> %.3f ms per run" % (
+                len(objs), prepass, out[0][2]["ms_mlp_fwd"], out[1][2]["ms_mlp_fwd"]))
+
+
 def test_fused_bookkeeping_is_exact(eng):
     """The per-object fused bookkeeping kernels (latency form) and the per-ray launches (throughput form) call the same device
     functions: every bit of every iteration must agree, with and without the prepass, including an object that fails."""
