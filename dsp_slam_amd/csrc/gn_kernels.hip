@@ -394,7 +394,7 @@ __device__ __forceinline__ void band_count_ray(const ObjConst& c, const ObjState
             mask &= mask - 1;
             const float v = sd[i];
             const bool pick = v != 1.0f && guard_pick(((unsigned)r << 6) | (unsigned)j, salt, fabsf(v) < thd + s.lp_delta);
-            n += (fabsf(v) < thd || pick) ? 1 : 0;
+            n += (!(fabsf(v) >= thd) || pick) ? 1 : 0;      // `!(>=)`, not `<`: a NaN prepass value belongs to the band (the fp32 kernel decides)
             if (v <= -thd) break;
         }
     }
@@ -414,7 +414,7 @@ __device__ __forceinline__ void band_write_ray(const ObjConst& c, const ObjState
         mask &= mask - 1;
         const float v = ssdf[base + i];
         const bool pick = v != 1.0f && guard_pick(((unsigned)r << 6) | (unsigned)j, salt, fabsf(v) < thd + s.lp_delta);
-        if (fabsf(v) < thd || pick) *dst++ = base + i;
+        if (!(fabsf(v) >= thd) || pick) *dst++ = base + i;
         if (v <= -thd) break;
     }
 }
@@ -798,7 +798,7 @@ __device__ __forceinline__ unsigned long long band_select_thread(const ObjConst&
     for (int k = 0; k < 64; ++k) {
         const float v = ssdf[k < cnt ? base + k : c.samp_off];
         if (k < cnt && v <= -thd) solid |= 1ull << k;
-        if (k < cnt && fabsf(v) < thd) band |= 1ull << k;
+        if (k < cnt && !(fabsf(v) >= thd)) band |= 1ull << k;      // NaN -> band
         if (k < cnt && v != 1.0f) decoded |= 1ull << k;
         if (k < cnt && fabsf(v) < thd + delta) ring |= 1ull << k;
     }

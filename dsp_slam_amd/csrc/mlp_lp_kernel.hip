@@ -359,7 +359,10 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpArgs a) {
         }
         lp_pass<BF, LP_NCH, true>(a.pass[a.n_pass - 1], X, Y, acc, abuf, rg, xb, bias_of(a.pass[a.n_pass - 1]), wl, lane, hh, part);
         part += __shfl_xor(part, 32);
-        const float y = tanhf(part + a.b_last);
+        float y = tanhf(part + a.b_last);
+        // exactly 1.0f is the optimiser's "never decoded" placeholder (gn_kernels.hip: sample_write_ray): a prepass value never takes it.
+        // (tanh saturates to 1.0f above ~9 -- or after an f16 overflow upstream.)  NaN stays NaN: the band kernels send it to the fp32 kernel.
+        if (y >= 1.0f) y = 0x1.fffffep-1f;
         if (valid && hh == 0) a.out_sdf[a.index ? src : pidx + td.w] = y;
         // stores and LDS-DMA share vmcnt and may retire out of order: drain before counting again
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
