@@ -192,7 +192,7 @@ __device__ __forceinline__ void lp_pass(const LpPass pd, u32x4 (&in)[32], u32x4 
                     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(GLDS_PER_CHUNK * (LP_NBUF - 3)) : "memory");
 #endif
                 }
-#if defined(LP_PAIR_READS)   // measured: no gain here (121.6 vs 121.2 ms per step) and 20 more spilled registers
+#if defined(LP_PAIR_READS)   // measured (round 3, no spills in either form): 0.5248 vs 0.5284 of peak -- no gain; the kernel is clock-governed, not issue-bound
                 // A fragments of two k-steps per group, one lgkmcnt wait per group (mlp_common.h: every instruction between MFMAs costs)
                 if ((sl & 1) == 0) {
                     __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0), vmcnt / expcnt untouched
