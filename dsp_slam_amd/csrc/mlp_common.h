@@ -97,6 +97,23 @@ __device__ __forceinline__ float relu1(float x) {
 // wave, per object): the host then re-runs the batch with the prepass off (batch_run) -- results never depend on a margin that the
 // workload itself has shown to be thin.  The largest difference seen is kept as well (dsp_stats.prepass_guard_max_err).
 // `active`: this lane stores a sample's fp32 sdf; old_lp: what the slot held (1.0f = never decoded by the prepass: no comparison).
+// tol: half the object's margin, 0.5f * float(guard word 0 of the object) -- passed in so that a caller can fetch it early
+__device__ __forceinline__ void prepass_guard_tol(const MlpArgs& a, int obj, bool active, float old_lp, float y, float tol) {
+    float err = 0.f;
+    if (active && old_lp != 1.0f) {
+        err = fabsf(old_lp - y);
+        if (!(err < 1.0f)) err = 1.0f;                  // NaN / inf prepass value
+    }
+    float m = err;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    if (m > 0.f && (threadIdx.x & 63) == 0) {
+        unsigned* w = a.guard + (size_t)obj * a.guard_stride;
+        atomicMax(w + 2, __float_as_uint(m));
+        if (!(m < tol)) atomicAdd(w + 1, 1u);
+    }
+}
+
 __device__ __forceinline__ void prepass_guard(const MlpArgs& a, int obj, bool active, float old_lp, float y) {
     float err = 0.f;
     if (active && old_lp != 1.0f) {

@@ -111,6 +111,13 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
         const int pidx = td.x + (valid ? local : 0);
         const int src = (MODE <= 1 && a.index) ? a.index[pidx] : pidx;
         float4 pt = a.pts[src];
+        // prepass guard (mlp_common.h): the value this tile's result will replace is fetched NOW, with the point, so that its latency
+        // hides behind the tile instead of stalling its last instructions (one register per lane for the tile's lifetime)
+        float old_lp = 1.0f, guard_tol = 0.f;
+        if (MODE <= 1 && a.guard) {
+            if (valid && g == 0) old_lp = a.out_sdf[a.index ? src : pidx + td.w];
+            guard_tol = 0.5f * __uint_as_float(a.guard[(size_t)td.z * a.guard_stride]);     // tile-uniform: the object's margin / 2
+        }
         if (!valid) pt = make_float4(0.f, 0.f, 0.f, 0.f);
         // The shape code is the same for every point of the tile, so its contribution to layer 0 and to the latent_in
         // layer is a per-object bias vector (k_code_bias): stage both into LDS.  What is left of layer 0 is three
@@ -373,7 +380,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
                 part += __shfl_xor(part, 32);
                 y = tanhf(part + a.b_last);
                 if (!BWD) {
-                    if (a.guard) prepass_guard(a, td.z, valid && g == 0, (valid && g == 0) ? a.out_sdf[a.index ? src : pidx + td.w] : 1.0f, y);
+                    if (a.guard) prepass_guard_tol(a, td.z, valid && g == 0, old_lp, y, guard_tol);
                     if (valid && g == 0) a.out_sdf[a.index ? src : pidx + td.w] = y;
                     if (MODE == 1 && valid && y > -a.th && y < a.th) {
                         // a candidate row of the render term (loss.py:88): export this lane's 64 mask words (8 layers x 8
