@@ -24,22 +24,43 @@ from dsp_slam_amd import engine as E
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["golden_recon_small.npz", "golden_recon_cfg1.npz", "golden_recon_redwood.npz", "golden_recon_freiburg.npz", "golden_recon_cfg2.npz"]
+# the last two run on the 32-D chairs decoder; cfg5 is BASELINE configs[4] at full size (4000 surface points + 500 background rays,
+# Redwood hyper-parameters) -- and a fixture on which the reference's OWN 1-ulp spread is below 1e-4 (9.3e-5 pose / 4.4e-5 code)
+CASES = ["golden_recon_small.npz", "golden_recon_cfg1.npz", "golden_recon_redwood.npz", "golden_recon_freiburg.npz", "golden_recon_cfg2.npz",
+         "golden_recon_chairs32.npz", "golden_recon_cfg5.npz"]
+
+
+class _Engines(object):
+    """The engine + oracle decoder a golden was recorded with (64-D cars or 32-D chairs), created on first use."""
+
+    def __init__(self, decoders):
+        self.decoders, self.engines = decoders, {}
+
+    def __call__(self, code_len):
+        if code_len not in self.engines:
+            d = self.decoders[code_len]
+            self.engines[code_len] = E.Engine(d.layers, d.latent_in, d.code_len, device=0)
+        return self.engines[code_len], self.decoders[code_len]
+
+    def close(self):
+        for e in self.engines.values():
+            e.close()
 
 
 @pytest.fixture(scope="module")
-def eng(oracle_decoder):
-    e = E.Engine(oracle_decoder.layers, oracle_decoder.latent_in, oracle_decoder.code_len, device=0)
-    yield e
-    e.close()
+def eng(oracle_decoder, chairs32_decoder):
+    es = _Engines({64: oracle_decoder, 32: chairs32_decoder})
+    yield es
+    es.close()
 
 
-def _setup(eng, g):
+def _setup(engines, g):
     cfg = json.loads(str(g["cfg_json"]))
     prm, oprm = E.params_from_configs(cfg), O.GNParams.from_configs(cfg)
+    e, dec = engines(cfg["optimizer"]["code_len"])
     code0 = [g["in_code"]] if "in_code" in g.files else None
-    b = eng.batch(prm, [g["in_t_cam_obj_init"]], [g["in_pts"]], [g["in_rays"]], [g["in_depth"]], code0, trace=True)
-    return cfg, prm, oprm, b
+    b = e.batch(prm, [g["in_t_cam_obj_init"]], [g["in_pts"]], [g["in_rays"]], [g["in_depth"]], code0, trace=True)
+    return cfg, prm, oprm, b, dec
 
 
 def _rot_prior_bound(h_ref, k4):
@@ -62,20 +83,22 @@ def _fmt_flip(f):
 
 
 @pytest.mark.parametrize("name", CASES)
-def test_linearisation_at_reference_states(eng, oracle_decoder, name):
+def test_linearisation_at_reference_states(eng, name):
     g = golden(name)
-    cfg, prm, oprm, b = _setup(eng, g)
+    cfg, prm, oprm, b, oracle_decoder = _setup(eng, g)
     k4 = cfg["optimizer"]["joint_optim"]["k4"]
     n_it = g["it_H"].shape[0]
     n_rays, n_d = g["in_rays"].shape[0], oprm.num_depth_samples
     obj = dict(pts=g["in_pts"], rays=g["in_rays"], depth=g["in_depth"])
     rows, strict, report = [], 0, ["## %s: device linearised at the reference's recorded states (injected bit for bit)" % name, "",
                                    "| it | V dev/ref | K dev/ref | rel dH | rel db | rel ddx | flips |", "|---|---|---|---|---|---|---|"]
-    mask = np.ones(71, bool)
+    n_unk = 7 + oprm.code_len                # 71, or 39 with the 32-D decoder (the device carries 64 code slots; the unused ones are pinned)
+    mask = np.ones(n_unk, bool)
     mask[3:6] = False
     for e in range(n_it):
         tr, status = F.device_linearisation(b, g["it_t_obj_cam"][e], g["it_code"][e], g["it_depths"][e])
         assert status == 0
+        tr = dict(tr, H=tr["H"][:, :n_unk, :n_unk], b=tr["b"][:, :n_unk], dx=tr["dx"][:, :n_unk])
         # the state really is the reference's, bit for bit
         assert np.array_equal(tr["t_obj_cam"][0], g["it_t_obj_cam"][e]) and np.array_equal(tr["code"][0][:g["it_code"].shape[1]], g["it_code"][e])
         assert np.array_equal(tr["depths"][0][:n_d], g["it_depths"][e])
@@ -102,7 +125,7 @@ def test_linearisation_at_reference_states(eng, oracle_decoder, name):
             assert rb < 1.2e-4, (e, rb)
             assert np.all(np.abs(tr["b"][0][3:6] - b_ref[3:6]) <= _rot_prior_bound(h_ref, k4) + 2e-4 * np.abs(b_ref).max())
             # dx = H^-1 b inherits what is accepted on b through |H^-1| (near convergence b, hence dx, is a difference of large terms)
-            tol_b = np.full(71, 2e-4 * np.abs(b_ref[mask]).max())
+            tol_b = np.full(n_unk, 2e-4 * np.abs(b_ref[mask]).max())
             tol_b[3:6] += _rot_prior_bound(h_ref, k4)
             tol_dx = np.abs(np.linalg.inv(h_ref.astype(np.float64))) @ tol_b + 1e-4 * np.abs(dx_ref).max()
             assert np.all(np.abs(tr["dx"][0] - dx_ref) <= tol_dx), (e, np.abs(tr["dx"][0] - dx_ref).max(), tol_dx.max())
@@ -116,7 +139,7 @@ def test_linearisation_at_reference_states(eng, oracle_decoder, name):
 
 
 @pytest.mark.parametrize("name", CASES)
-def test_chained_divergence_is_the_maps_own(eng, oracle_decoder, name):
+def test_chained_divergence_is_the_maps_own(eng, name):
     """The chained device run beside the reference's recorded trajectory, with the difference of every step DECOMPOSED:
 
         state_dev(e+1) - state_ref(e+1)  =  [ step_dev(state_dev(e)) - step_oracle(state_dev(e)) ]        local: the device's own error
@@ -128,7 +151,7 @@ def test_chained_divergence_is_the_maps_own(eng, oracle_decoder, name):
     the inputs does to the unmodified reference (golden ulps_*: the yardstick of the final bound), including set flips, which are
     named where the device's sets first depart from the recorded ones."""
     g = golden(name)
-    cfg, prm, oprm, b = _setup(eng, g)
+    cfg, prm, oprm, b, oracle_decoder = _setup(eng, g)
     k4 = cfg["optimizer"]["joint_optim"]["k4"]
     n_it = g["it_H"].shape[0]
     n_rays, n_d = g["in_rays"].shape[0], oprm.num_depth_samples
@@ -139,13 +162,15 @@ def test_chained_divergence_is_the_maps_own(eng, oracle_decoder, name):
     report = ["## %s: chained device run beside the reference's recorded trajectory" % name, "",
               "| it | incoming state diff (rot / trans / code) | V dev/ref | K dev/ref | local: rel d(dx) dev vs oracle at the device's state | propagated: rel d(dx) oracle(dev state) vs reference | local flips |",
               "|---|---|---|---|---|---|---|"]
+    n_unk = 7 + oprm.code_len
+    traces = [dict(tr, H=tr["H"][:, :n_unk, :n_unk], b=tr["b"][:, :n_unk], dx=tr["dx"][:, :n_unk]) for tr in traces]
     local, prop, drift_in, first = [], [], [], None
     for e, tr in enumerate(traces):
         sd = F.state_difference(tr["t_obj_cam"][0], tr["code"][0], g["it_t_obj_cam"][e], g["it_code"][e])
         drift_in.append(max(sd.values()))
         if first is None and (int(tr["V"][0]), int(tr["K"][0])) != (int(g["it_V"][e]), int(g["it_K"][e])):
             first = e
-        ot = F.oracle_linearisation(oracle_decoder, oprm, g["in_pts"], g["in_rays"], g["in_depth"], tr["t_obj_cam"][0], tr["code"][0], tr["depths"][0][:n_d])
+        ot = F.oracle_linearisation(oracle_decoder, oprm, g["in_pts"], g["in_rays"], g["in_depth"], tr["t_obj_cam"][0], tr["code"][0][:oprm.code_len], tr["depths"][0][:n_d])
         same = int(tr["set_sums"][0][0]) == ot["vsum"] and int(tr["set_sums"][0][1]) == ot["ksum"]
         flips = []
         if not same:      # the device and the oracle disagree at the SAME state and depths: name the samples (tight margins: nothing drifted)
@@ -161,7 +186,7 @@ def test_chained_divergence_is_the_maps_own(eng, oracle_decoder, name):
         local.append(loc)
         prop.append(pro)
         if same:
-            tol_b = np.full(71, 1e-4 * np.abs(ot["b"]).max())
+            tol_b = np.full(n_unk, 1e-4 * np.abs(ot["b"]).max())
             tol_b[3:6] += _rot_prior_bound(ot["H"], k4)
             tol_dx = np.abs(np.linalg.inv(ot["H"].astype(np.float64))) @ tol_b + 1e-4 * np.abs(ot["dx"]).max()
             assert F.rel_max(tr["H"][0], ot["H"]) < 1e-4, (e, F.rel_max(tr["H"][0], ot["H"]))
@@ -194,6 +219,8 @@ def test_chained_divergence_is_the_maps_own(eng, oracle_decoder, name):
     b.close()
     if first is not None and drift_in[first] <= 2e-5:
         assert named and all(f["explained"] for f in named), "\n".join(_fmt_flip(f) for f in named)
-    bound = {q: max(1e-4 if first is None else 5e-3, P.E2E_SPREAD_FACTOR * sens[q]) for q in sens}
+    # Where the REFERENCE is stable in a quantity (its own 1-ulp spread below 1e-4: Freiburg, cfg1's pose, all of full-size cfg5) the chained
+    # device result must be within north_star's 1e-4 of it, flip or no flip; elsewhere the reference's own spread is the yardstick.
+    bound = {q: (1e-4 if sens[q] < 1e-4 else max(1e-4 if first is None else 5e-3, P.E2E_SPREAD_FACTOR * sens[q])) for q in sens}
     for q in ("rot", "scale", "trans", "code"):
         assert m[q] <= bound[q], (q, m[q], sens[q])

@@ -314,6 +314,17 @@ def main():
                             grad=gj.reshape(n, 35).numpy(), sdf=sdf)
         obj = synth.make_object(21, n_surface=220, n_background=60, code_len=32, half=synth.CHAIR_HALF)
         recon("golden_recon_chairs32.npz", obj, cfg_ch, dec=dec_ch)
+    # ---- C3. BASELINE configs[4] at full size: 4000 surface points + 500 background rays, the 32-D chairs decoder, Redwood hyper-parameters
+    if want("cfg5"):
+        ch_dir = fixtures.materialize_decoder_dir("chairs32", os.path.join(tmp, "chairs_32b"))
+        cfg_ch = make_cfg(ch_dir, REDWOOD, "Redwood", code_len=32)
+        with open(os.path.join(tmp, "cfg_ch5.json"), "w") as f:
+            json.dump(cfg_ch, f)
+        dec_ch = get_decoder(get_configs(os.path.join(tmp, "cfg_ch5.json")))
+        for p_ in dec_ch.parameters():
+            p_.requires_grad_(False)
+        obj = synth.make_object(31, n_surface=4000, n_background=500, code_len=32, half=synth.CHAIR_HALF)
+        recon("golden_recon_cfg5.npz", obj, cfg_ch, dec=dec_ch)
 
     # ---- D. pose-only optimiser --------------------------------------------------------------
     if want("pose"):
