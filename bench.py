@@ -179,6 +179,7 @@ def main():
     for e, ol in groups:
         bt = e.batch(prm, [o["t_cam_obj_init"] for o in ol], [o["pts"] for o in ol], [o["rays"] for o in ol], [o["depth"] for o in ol])
         bt.set_prepass(PREPASS[args.prepass])
+        bt.set_kernel_timing(1)        # the roofline below is computed from HIP events around every decoder launch
         batches.append(bt)
 
     gathered = [None]
@@ -245,6 +246,46 @@ def main():
     n_good = int(sum(int((bt.results()[3] == 0).sum()) for bt in batches))
     n_total = sum(b - a for a, b in shards)
 
+    # what every rank measured on its own GPU, gathered so that an imbalance in a multi-GPU run is explainable from the line alone:
+    # fp32 forward / jacobian / prepass rates (HIP events on the library's stream), the shader clock the chip granted under the
+    # prepass kernel, and what the prepass guard saw
+    def rank_clock_mhz():
+        try:
+            import ctypes as C
+            from dsp_slam_amd import _lib as L
+            lib = L.load()
+            lib.dsp_debug_last_clocks.restype = C.c_int
+            lib.dsp_debug_last_clocks.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+            rngp = np.random.default_rng(0)
+            ppts = rngp.uniform(-0.6, 0.6, size=(128 * 256 * 24, 3)).astype(np.float32)
+            pcode = np.zeros(64, np.float32)
+            mhz = []
+            for _ in range(6):
+                eng.decode_sdf_prepass(pcode, ppts, 1 if int(acc.get("prepass_mode", 0)) == 1 else 2)
+                clk = (C.c_uint64 * 4)()
+                L.check(lib.dsp_debug_last_clocks(eng._h, clk), eng._h, "clk")
+                mhz.append((clk[2] - clk[0]) / ((clk[3] - clk[1]) / 100e6) / 1e6)
+            return float(np.median(mhz[1:]))
+        except Exception as e:
+            sys.stderr.write("clock probe failed: %r\n" % (e,))
+            return 0.0
+
+    def rate(pts, flop, ms):
+        return pts * flop / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+
+    my_clock = rank_clock_mhz() if int(acc.get("prepass_mode", 0)) else 0.0
+    mine_rec = [rate(acc["n_fwd_points"], F_FWD, acc["ms_mlp_fwd"]),
+                (acc["n_jac_points"] * F_JAC + acc["n_render_rows"] * (F_JAC - F_FWD)) / (acc["ms_mlp_jac"] * 1e-3) / 1e12 if acc["ms_mlp_jac"] > 0 else 0.0,
+                rate(acc["n_prepass_points"], F_FWD, acc["ms_mlp_prepass"]), my_clock, acc.get("prepass_guard_trips", 0.0),
+                acc.get("prepass_guard_rerun", 0.0), acc.get("prepass_guard_max_err", 0.0), float(n_good)]
+    all_recs = [mine_rec]
+    if dist is not None:
+        tt = torch.tensor(mine_rec, dtype=torch.float64, device=coll_device)
+        allt = [torch.empty_like(tt) for _ in range(world)]
+        dist.all_gather(allt, tt)
+        all_recs = [[float(v) for v in x.tolist()] for x in allt]
+        n_good = int(sum(r[7] for r in all_recs))
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -265,7 +306,8 @@ def main():
     jac_tflops = jac_flop / (jac_ms * 1e-3) / 1e12 if jac_ms > 0 else 0.0
     mode = int(acc.get("prepass_mode", 0))
     result = {
-        "metric": "objects/sec (2000 pts, 64-D code, 10 GN iters)",
+        "metric": {"cfg2x64": "objects/sec (2000 pts, 64-D code, 10 GN iters)", "cfg4": "objects/sec (2000 pts, 64-D code, 10 GN iters; 1024-object job sharded over the GPUs)",
+                   "cfg5": "objects/sec (4000 pts, 64-D + 32-D codes on two decoders, 5 GN iters, Redwood hyper-parameters)"}[args.config],
         "value": round(value, 3),
         "unit": "objects/s",
         "n_gpus": world,
@@ -273,6 +315,9 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "ms_per_step_by_rank": [round(x / args.steps * 1e3, 3) for x in per_rank_s],
+        "by_rank": [{"rank": r, "fwd_fp32_frac": round(x[0] / PEAK_FP32_MFMA_TFLOPS, 4), "jac_fp32_frac": round(x[1] / PEAK_FP32_MFMA_TFLOPS, 4),
+                     "prepass_tflops": round(x[2], 1), "prepass_clock_mhz": round(x[3]), "guard_trips": x[4], "guard_reruns": x[5],
+                     "guard_max_err": x[6], "objects_good": int(x[7])} for r, x in enumerate(all_recs)],
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -283,6 +328,8 @@ def main():
             "name": args.config,
             "objects_per_gpu": B,
             "objects_good": n_good,
+            "timed_region": "inputs are resident in HBM before the timed step (dsp_batch_create uploaded them: ~4 MB per 64 objects, ~0.1 ms over PCIe, NOT "
+                            "in the step); the step = every GN iteration on the device + the read-back of the 82-float result rows + the gather",
             "parallelism": "object-sharded x%d, one RCCL gather of results per step" % world + (" [PLUMBING TEST: ranks share GPU 0, %s backend]" % backend if share_gpu else ""),
             "prepass": ["off", "f16", "bf16"][mode] + (" (exact pre-classification of ray samples; results bit-identical to off)" if mode else ""),
         },
@@ -327,31 +374,16 @@ def main():
             "traffic": pmc.get("lp_fetch_bytes_per_point", 0.0) * lp_pts / max(n_lp, 1) or None,
         }
 
-    if mode and world == 1:
-        # the clock the chip grants under this kernel (dense 16-bit MFMA): shader cycles / wall ticks of workgroup 0 of a bare prepass decode
-        try:
-            import ctypes as C
-            from dsp_slam_amd import _lib as L
-            lib = L.load()
-            lib.dsp_debug_last_clocks.restype = C.c_int
-            lib.dsp_debug_last_clocks.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
-            rngp = np.random.default_rng(0)
-            ppts = rngp.uniform(-0.6, 0.6, size=(128 * 256 * 24, 3)).astype(np.float32)
-            pcode = np.zeros(64, np.float32)
-            mhz = []
-            for _ in range(6):
-                eng.decode_sdf_prepass(pcode, ppts, 1 if mode == 1 else 2)
-                clk = (C.c_uint64 * 4)()
-                L.check(lib.dsp_debug_last_clocks(eng._h, clk), eng._h, "clk")
-                mhz.append((clk[2] - clk[0]) / ((clk[3] - clk[1]) / 100e6) / 1e6)
-            clk_mhz = float(np.median(mhz[1:]))
+    if mode:
+        # the clock the chip grants under this kernel (dense 16-bit MFMA): shader cycles / wall ticks of workgroup 0 of a bare prepass decode (rank 0's)
+        clk_mhz = all_recs[0][3]
+        if clk_mhz > 0:
             result["prepass"]["sustained_clock_mhz"] = round(clk_mhz)
             result["prepass"]["frac_of_peak_at_sustained_clock"] = round(lp_tflops / (PEAK_16BIT_MFMA_TFLOPS * clk_mhz / 2400.0), 4)
             result["prepass"]["clock_note"] = ("the chip holds this clock under dense 16-bit MFMA while drawing LESS socket power than under the fp32 kernel at 2.37 GHz "
-                                               "(profiles/r03_power_probe.md); LDS array 37 % busy, 3 non-MFMA instructions per MFMA: neither LDS- nor issue-bound (DESIGN.md K0)")
-        except Exception as e:
+                                               "(profiles/r03_power_probe.md); DESIGN.md K0")
+        else:
             result["prepass"]["sustained_clock_mhz"] = None
-            result["prepass"]["clock_note"] = "clock probe failed: %r" % (e,)
     if mode:
         result["prepass"]["guard"] = {"trips": acc.get("prepass_guard_trips", 0.0), "reruns": acc.get("prepass_guard_rerun", 0.0),
                                       "max_err_seen": acc.get("prepass_guard_max_err", 0.0),
@@ -396,6 +428,18 @@ def main():
             lat.append((time.perf_counter() - t1) * 1e3)
         one.close()
         result["latency_kitti_size_ms_p50"] = round(statistics.median(lat), 3)
+        # the call SLAM really makes (Optimizer.reconstruct_object -> dsp_reconstruct_batch: build the batch from host buffers, run, drop): same detection
+        args1 = ([k["t_cam_obj_init"]], [k["pts"]], [k["rays"]], [k["depth"]])
+        eng.reconstruct_batch(prm, *args1)
+        lat = []
+        for _ in range(max(args.latency_runs, 1)):
+            t1 = time.perf_counter()
+            eng.reconstruct_batch(prm, *args1)
+            lat.append((time.perf_counter() - t1) * 1e3)
+        result["latency_one_shot_ms_p50"] = round(statistics.median(lat), 3)
+        result["latency_note"] = ("ms per object, p50 over %d runs, host wall clock around run + results: latency_ms_p50 = one cfg2 object (2000 + 500 rays), resident batch; "
+                                  "latency_kitti_size_ms_p50 = one detection of the reference's real size (250 LiDAR points + 200 background rays, config_kitti.json:17), "
+                                  "resident batch; latency_one_shot_ms_p50 = the same detection through the one-shot entry point (host buffers in, PCIe both ways)" % max(args.latency_runs, 1))
         # sdf-only workload: Optimizer.estimate_pose_cam_obj on the same objects -- 5 Gauss-Newton iterations of the
         # surface term alone, through the one-shot entry point (host buffers in, so this figure includes upload and download)
         try:

@@ -94,6 +94,9 @@ SYMBOLS = [
     ("dsp_batch_set_depth_schedule", C.c_int, [_VP, c_f32p, C.c_int32]),
     ("dsp_batch_debug_samples", C.c_int, [_VP, C.c_int32, C.POINTER(C.c_uint64), c_f32p, c_f32p, C.c_int64]),
     ("dsp_batch_set_split_rows", C.c_int, [_VP, C.c_int]),
+    ("dsp_batch_set_solver", C.c_int, [_VP, C.c_int]),
+    ("dsp_batch_set_kernel_timing", C.c_int, [_VP, C.c_int]),
+    ("dsp_prepass_reset_guard", C.c_int, [_VP]),
     ("dsp_batch_enable_trace", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_trace", C.c_int, [_VP, C.c_int32, c_f32p, c_f32p, c_f32p, c_i64p, c_i64p, c_i64p, c_f32p, c_f32p, C.POINTER(C.c_uint32), c_f32p]),
     ("dsp_batch_destroy", None, [_VP]),

@@ -95,7 +95,7 @@ def check_isa(verbose=False):
         ins = [t for t in ins if t]
         for i, t in enumerate(ins):
             if any(x.rstrip(",") == "m0" for x in t):
-                if not (t[0] == "s_mov_b32" and t[1].rstrip(",") == "m0" and ins[i + 1][0] == "s_nop"):
+                if not (t[0] == "s_mov_b32" and t[1].rstrip(",") == "m0" and i + 1 < len(ins) and ins[i + 1][0] == "s_nop"):
                     raise IsaCheckError("%s: M0 is touched outside the LDS-DMA helpers: `%s`" % (src, " ".join(t)))
                 report["m0_writes"] += 1
         loads = sum(1 for t in ins if t[0] == "global_load_lds_dwordx4")

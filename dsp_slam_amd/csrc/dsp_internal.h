@@ -127,6 +127,7 @@ struct LpArgs {
 constexpr int DSP_STATUS_GOOD = 0;
 constexpr int DSP_STATUS_FEW = 1;    // < 10 in-sphere samples (loss.py:73-74)
 constexpr int DSP_STATUS_NAN = 2;    // NaN loss / singular system (optimizer.py:135-136,149-150)
+constexpr int DSP_STATUS_SKIP = 3;   // internal: not part of this (partial re-)run; never leaves the library (k_init_state run_mask, k_finalize)
 constexpr int MAX_DEPTH_SAMPLES = 64;
 constexpr int TRACE_STRIDE = 5344;   // 71*71 H | 71 b | 71 dx | 16 t_oc | 64 code | V m K | vsum lo,hi | ksum lo,hi | pad | 64 depths
 
@@ -182,15 +183,17 @@ hipError_t mlp_split_prepare_device();
 hipError_t launch_mlp_split(bool bwd, const MlpArgs& args, int n_blocks, hipStream_t stream);   // 16-point tiles; forward (+ backward)
 hipError_t mlp_lp_prepare_device();
 hipError_t launch_mlp_lp(bool bf16, const LpArgs& args, int n_blocks, hipStream_t stream);   // 128-point tiles, forward only
+// run_mask (optional, B bytes): objects with a zero byte are left out of the run (status DSP_STATUS_SKIP, state and result row untouched);
+// summary: the run's counter words, zeroed here (summary_words of them)
 void launch_init_state(ObjState* st, const float* t, const float* codes, const float* scale, const float* depths /*optional B x 64*/, int B, int D, int pose_only,
-                       const LpDeltaTab& lp, hipStream_t s);
+                       const LpDeltaTab& lp, const unsigned char* run_mask, unsigned* summary, int summary_words, hipStream_t s);
 void launch_sample_count(const ObjConst* oc, ObjState* st, const float* rays, unsigned long long* m, int* c, int D, int maxR, int B, hipStream_t s);
 void launch_scan_rays(const ObjConst* oc, ObjState* st, const int* cnt, int* off, int which, int B, hipStream_t s);
 void launch_sample_write(const ObjConst* oc, const ObjState* st, const float* rays, const unsigned long long* m, const int* off, float4* spts,
                          float* ssdf, unsigned char* alive, int D, int maxR, int B, hipStream_t s);
 void launch_surface(const ObjConst* oc, const ObjState* st, const float* pts, float4* jpts, float2* jaux, int maxM, int B, hipStream_t s);
-void launch_build_tiles(const ObjConst* oc, const ObjState* st, int B, int mode, int4* tiles, int* n_tiles, double* counters, int add_v, int tile_pts,
-                        int cnt_slot, hipStream_t s);   // mode 3 = mode 1 with the band samples (P) in place of the kept render rows (K)   // cnt_slot: counter the point count of a mode 0 / 2 list is added to
+void launch_build_tiles(const ObjConst* oc, ObjState* st, int B, int mode, int4* tiles, int* n_tiles, double* counters, int add_v, int tile_pts,
+                        int cnt_slot, hipStream_t s, int apply_few = 0);   // mode 3 = mode 1 with the band samples (P) in place of the kept render rows (K)   // cnt_slot: counter the point count of a mode 0 / 2 list is added to
 // th = cut_off; the widened band of object b is |sdf_lp| < th + st[b].lp_delta.  guard_salt: samples OUTSIDE the band whose id hash
 // (xor salt) selects them (1/8 of the ring just beyond the band, 1/512 farther out) are listed too, so that the fp32 kernel re-decodes them
 // and prepass_guard compares (0 = no guard samples)
@@ -206,6 +209,15 @@ void launch_band_fused(const ObjConst* oc, ObjState* st, const unsigned long lon
 void launch_render_tail_fused(const ObjConst* oc, ObjState* st, const int* raycnt, const int* rayoff, const float4* spts, const float* sdeds,
                               const float* ray_res, const int* kcnt, int* koff, const int* mcnt, float4* jpts, float2* jaux, const int* srow, int* jrow,
                               int B, hipStream_t s);
+// wave-per-ray forms of the three fused stages (one wave per ray, 16 rays per workgroup, whole chip): list segments from running counters
+// (ObjState::V / ::P) instead of scans; kept rows stay in ray-major order.  See gn_kernels.hip.
+void launch_front_wave(const ObjConst* oc, ObjState* st, const float* rays, const float* pts, unsigned long long* raymask, int* raycnt, int* rayoff,
+                       float4* spts, float* ssdf, unsigned char* alive, float4* jpts, float2* jaux, int D, int maxR, int maxM, int B, hipStream_t s);
+void launch_band_wave(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff, const float* ssdf, float th, unsigned guard_salt,
+                      int* plist, const float4* spts, float4* jpts, int* srow, int maxR, int B, hipStream_t s);   // jpts / srow: speculative band rows (or null)
+void launch_render_tail_wave(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff, const float4* spts, const float* sdeds,
+                             const float* ray_res, const int* kcnt, const int* mcnt, float4* jpts, float2* jaux, const int* srow, int* jrow, int maxR, int B,
+                             hipStream_t s);
 void launch_prepass_audit(const ObjConst* oc, const ObjState* st, const float* ssdf, const float* saudit, float th, unsigned* out,
                           int B, hipStream_t s);
 void launch_render_scan(const ObjConst* oc, ObjState* st, const unsigned long long* m, const int* off, const float* ssdf, const float* depth,
@@ -231,10 +243,11 @@ void launch_gram(const ObjConst* oc, const ObjState* st, const float4* jpts, con
 void launch_jrows(const ObjConst* oc, const ObjState* st, const float4* jpts, const float2* jaux, const float* jgrad, const int* jrow, int term, float* rows,
                   int cap, hipStream_t s);   // jrow (optional): render row i takes its gradient from jgrad row jrow[i]
 void launch_solve(const ObjConst* oc, ObjState* st, const float* partials, double* gsum, int n_slices, const GnParamsDev& prm, int iter,
-                  float* trace, const float* codew, const float* b0, const float* blat, float* cbias, const float* depths_next, int B, hipStream_t s);   // cbias: next iteration's code bias; depths_next: optional B x 64 override of the next iteration's depth samples
+                  float* trace, const float* codew, const float* b0, const float* blat, float* cbias, const float* depths_next, int B, hipStream_t s,
+                  int solver = 0);   // cbias: next iteration's code bias; depths_next: optional B x 64 override of the next iteration's depth samples; solver: 0 LDL^T, 1 Gauss-Jordan (A/B)
 void launch_inlier_filter(const ObjConst* oc, ObjState* st, const float* jgrad, unsigned char* alive, int maxM, int B, hipStream_t s);
 constexpr int DSP_RESULT_WIDTH_DEV = 82;   // == DSP_RESULT_WIDTH (dsp_gn.h): t_cam_obj 16 | code 64 | loss | status
-void launch_finalize(ObjState* st, const float* scale, int B, int pose_only, float* t, float* code, float* loss, int* status, float* packed, hipStream_t s);
+void launch_finalize(ObjState* st, const float* scale, int B, int pose_only, float* packed, unsigned* guard_out /*optional B x 3*/, hipStream_t s);
 
 hipError_t debug_solve_clocks(unsigned long long* out8);
 

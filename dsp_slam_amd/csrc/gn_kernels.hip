@@ -116,10 +116,17 @@ __device__ __forceinline__ float lp_delta_of(float zmax, const LpDeltaTab& t) {
 }
 
 __global__ void k_init_state(ObjState* st, const float* t_cam_obj, const float* codes, const float* scale_in, const float* depths,
-                             int n_obj, int n_depth, int pose_only, LpDeltaTab lp) {
+                             int n_obj, int n_depth, int pose_only, LpDeltaTab lp, const unsigned char* run_mask, unsigned* summary, int summary_words) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    // the run's counters (work counters, audit words, ...; read back once at the end of the run) start from zero: this is the first kernel
+    for (int i = b; i < summary_words; i += gridDim.x * blockDim.x) summary[i] = 0u;
     if (b >= n_obj) return;
     ObjState& s = st[b];
+    if (run_mask && !run_mask[b]) { s.status = DSP_STATUS_SKIP; return; }     // partial re-run (batch_run): this object keeps its results
+    {
+        unsigned* w = reinterpret_cast<unsigned*>(&s);
+        for (int i = 0; i < (int)(sizeof(ObjState) / 4); ++i) w[i] = 0u;
+    }
     double tco[16], toc[16];
     for (int i = 0; i < 16; ++i) tco[i] = (double)t_cam_obj[16 * b + i];
     if (pose_only & 1) {   // optimizer.py:52-55: R *= scale before inverting
@@ -133,7 +140,7 @@ __global__ void k_init_state(ObjState* st, const float* t_cam_obj, const float* 
     pose_only &= 1;
     for (int i = 0; i < 16; ++i) s.t_oc[i] = (float)toc[i];
     for (int i = 0; i < CODE_LEN; ++i) s.code[i] = codes ? codes[CODE_LEN * b + i] : 0.f;
-    s.loss = 0.f; s.V = 0; s.m = 0; s.K = 0; s.n_alive = -1; s.vsum = 0; s.ksum = 0;
+    s.loss = 0.f; s.V = 0; s.m = 0; s.K = 0; s.P = 0; s.n_alive = -1; s.vsum = 0; s.ksum = 0;
     float zmax = 0.f;
     for (int i = 0; i < CODE_LEN; ++i) { const float a = fabsf(s.code[i]); zmax = (a > zmax || a != a) ? a : zmax; }
     s.lp_delta = lp_delta_of(zmax, lp);
@@ -483,8 +490,8 @@ __global__ void k_surface(const ObjConst* oc, const ObjState* st, const float* p
 // ------------------------------------------------------------------------------------------------
 // tile lists for the decoder kernels (single workgroup; counts live on the device)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_build_tiles(const ObjConst* oc, const ObjState* st, int n_obj, int mode, int4* tiles,
-                                                     int* n_tiles, double* counters, int add_v, int tile_pts, int cnt_slot) {
+__global__ __launch_bounds__(256) void k_build_tiles(const ObjConst* oc, ObjState* st, int n_obj, int mode, int4* tiles,
+                                                     int* n_tiles, double* counters, int add_v, int tile_pts, int cnt_slot, int apply_few) {
     // mode 0: forward tiles over the V in-sphere samples; mode 1: jacobian tiles over M surface + K render points;
     // mode 2: forward tiles over the P samples selected for the current front-to-back pass (indexed through plist)
     // One thread per object (rounds of 256): tile counts, a block-wide exclusive scan for the list offsets, then the four waves
@@ -504,9 +511,14 @@ __global__ __launch_bounds__(256) void k_build_tiles(const ObjConst* oc, const O
             if (b < n_obj) {
                 const ObjConst c = oc[b];
                 const ObjState& s = st[b];
-                const bool good = s.status == DSP_STATUS_GOOD;
+                int status = s.status;
+                // wave-per-ray bookkeeping (k_front_wave) counts V with a running counter and leaves the "< 10 in-sphere samples" rule
+                // (loss.py:73-74; k_scan_rays applies it in the other forms) to the first tile list built from that count
+                if ((apply_few & 1) && !jac && status == DSP_STATUS_GOOD && s.V < 10) { status = DSP_STATUS_FEW; st[b].status = DSP_STATUS_FEW; }
+                const bool good = status == DSP_STATUS_GOOD;
                 if (!jac) {
                     n = good ? (mode == 0 ? s.V : s.P) : 0;
+                    if ((apply_few & 2) && mode == 2) st[b].P = 0;      // a front-to-back pass's count (k_scan_rays): consumed; k_band_wave counts from zero
                     off = c.samp_off;
                     cnt += n;
                     if (good) vtot += s.V;
@@ -876,6 +888,198 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_render_tail_fused(const ObjCo
     for (int r = threadIdx.x; r < c.n_rays; r += FUSED_THREADS) render_write_ray(c, st[b], raycnt, rayoff, koff, spts, sdeds, ray_res, jpts, jaux, r, srow, jrow);
 }
 
+// ------------------------------------------------------------------------------------------------
+// wave-per-ray forms of the same three stages (latency path, round 4): the fused kernels above give an object ONE workgroup, i.e. one
+// CU, and a detection's 450 rays x 50 samples then cost 27 + 41 + 22 us per iteration on it.  Here a ray is a wave (lane = depth index,
+// as in k_render_scan), 16 rays a workgroup, and the rays of an object spread over as many CUs as they fill.  What made the fused
+// form need one workgroup per object was the scan over the rays; two of the three scans are not needed at all:
+//   * the in-sphere sample list and the band / speculative-row list are INTERNAL orders -- every consumer goes through rayoff / plist /
+//     srow / jrow, each point's decoder result is independent of the tile it shares (test_decode_is_tile_independent), and the Gram
+//     kernel walks the kept rows in koff order -- so their segments are handed out by one atomicAdd per workgroup (ObjState::V / ::P);
+//   * the kept-row order IS the Gram summation order, so k_render_tail_wave keeps it: every workgroup sums the counts of the rays in
+//     front of its own (<= 2500 integers) instead of waiting for a scan launch.
+// Same per-sample arithmetic, same sets, same H / b / dx bits as the fused and the throughput forms (test_wave_bookkeeping_is_exact).
+// ------------------------------------------------------------------------------------------------
+constexpr int WAVE_RAYS = 16;            // rays (= waves) per workgroup of k_front_wave / k_band_wave
+constexpr int WAVE_THREADS = 64 * WAVE_RAYS;
+
+__device__ __forceinline__ unsigned long long lanes_below(int lane) { return (1ull << lane) - 1ull; }
+
+// per-workgroup segment of `tot` list slots from an object's running counter: s_cnt[w] = wave w's count; returns this wave's first slot
+__device__ __forceinline__ int wave_segment(int* counter, int* s_cnt, int* s_base, int wave, int cnt, int lane) {
+    if (lane == 0) s_cnt[wave] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+#pragma unroll
+        for (int w = 0; w < WAVE_RAYS; ++w) tot += s_cnt[w];
+        *s_base = tot ? atomicAdd(counter, tot) : 0;
+    }
+    __syncthreads();
+    int off = *s_base;
+    for (int w = 0; w < wave; ++w) off += s_cnt[w];
+    return off;
+}
+
+// k_sample_count + k_sample_write + k_surface (the scan is replaced by the running counter ObjState::V, zero at the start of an
+// iteration; the "< 10 samples" rule of loss.py:73-74 is applied by the tile builder that follows, k_build_tiles apply_few)
+__global__ __launch_bounds__(WAVE_THREADS) void k_front_wave(const ObjConst* oc, ObjState* st, const float* __restrict__ rays, const float* pts,
+                                                             unsigned long long* raymask, int* raycnt, int* rayoff, float4* spts, float* ssdf,
+                                                             unsigned char* alive, float4* jpts, float2* jaux, int n_depth, int n_ray_blocks) {
+    __shared__ int s_cnt[WAVE_RAYS], s_base;
+    __shared__ unsigned s_hash[WAVE_RAYS];
+    const int b = blockIdx.y;
+    const ObjConst c = oc[b];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if ((int)blockIdx.x >= n_ray_blocks) {           // the surface points, 1024 per workgroup
+        const int i = ((int)blockIdx.x - n_ray_blocks) * WAVE_THREADS + (int)threadIdx.x;
+        if (i < c.n_pts) surface_point(c, st[b], pts, jpts, jaux, i);
+        return;
+    }
+    if ((int)blockIdx.x * WAVE_RAYS >= c.n_rays) return;       // workgroup-uniform
+    const int r = blockIdx.x * WAVE_RAYS + wave;
+    const bool live = r < c.n_rays && st[b].status == DSP_STATUS_GOOD;
+    bool in = false;
+    float3 p = make_float3(0.f, 0.f, 0.f);
+    if (live && lane < n_depth) {
+        float T[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) T[i] = st[b].t_oc[i];
+        const float dj = st[b].depths[lane];
+        const float* d3 = rays + 3 * (size_t)(c.ray_off + r);
+        p = xform(T, __fmul_rn(d3[0], dj), __fmul_rn(d3[1], dj), __fmul_rn(d3[2], dj));
+        const float n2 = __fadd_rn(__fadd_rn(__fmul_rn(p.x, p.x), __fmul_rn(p.y, p.y)), __fmul_rn(p.z, p.z));
+        in = __fsqrt_rn(n2) < 1.0f;
+    }
+    const unsigned long long mask = __ballot(in);
+    const int cnt = __popcll(mask);
+    unsigned h = in ? id_hash(((unsigned)r << 6) | (unsigned)lane) : 0u;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) h += __shfl_xor(h, d);
+    if (lane == 0) s_hash[wave] = h;
+    const int off = wave_segment(&st[b].V, s_cnt, &s_base, wave, cnt, lane);
+    if (threadIdx.x == 0) {
+        unsigned hs = 0;
+#pragma unroll
+        for (int w = 0; w < WAVE_RAYS; ++w) hs += s_hash[w];
+        if (hs) atomicAdd(&st[b].vsum, hs);
+    }
+    if (r >= c.n_rays) return;
+    const int gr = c.ray_off + r;
+    if (lane == 0) { raymask[gr] = mask; raycnt[gr] = cnt; rayoff[gr] = off; alive[gr] = mask ? 1 : 0; }
+    if (in) {
+        const int k = __popcll(mask & lanes_below(lane));
+        spts[c.samp_off + off + k] = make_float4(p.x, p.y, p.z, __int_as_float((r << 6) | lane));
+        ssdf[c.samp_off + off + k] = 1.0f;       // "not evaluated": free space (see sample_write_ray)
+    }
+}
+
+// k_band_count + k_band_write (+ the speculative band rows of k_band_fused): the selection of band_select_thread with lane = depth
+// index; list slots from the running counter ObjState::P (zero at the start of an iteration)
+__global__ __launch_bounds__(WAVE_THREADS) void k_band_wave(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff,
+                                                            const float* ssdf, float th, unsigned salt, int* plist, const float4* spts, float4* jpts,
+                                                            int* srow) {
+    __shared__ int s_cnt[WAVE_RAYS], s_base;
+    const int b = blockIdx.y;
+    const ObjConst c = oc[b];
+    if ((int)blockIdx.x * WAVE_RAYS >= c.n_rays) return;       // workgroup-uniform
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * WAVE_RAYS + wave;
+    const bool live = r < c.n_rays && st[b].status == DSP_STATUS_GOOD;
+    bool sel = false;
+    int idx = 0;
+    if (live) {
+        const float delta = st[b].lp_delta, thd = th + delta;
+        const int gr = c.ray_off + r;
+        const unsigned long long rmask = raymask[gr];
+        const bool in = (rmask >> lane) & 1ull;
+        idx = c.samp_off + rayoff[gr] + __popcll(rmask & lanes_below(lane));
+        const float v = in ? ssdf[idx] : 1.0f;
+        const bool solid = in && v <= -thd;
+        const bool band = in && !(fabsf(v) >= thd);                 // `!(>=)`: a NaN prepass value belongs to the band
+        const bool decoded = in && v != 1.0f;
+        const bool ring = fabsf(v) < thd + delta;
+        const unsigned long long solidm = __ballot(solid);
+        const int first = solidm ? __ffsll((long long)solidm) - 1 : 64;     // samples behind the first certainly-solid one are skipped
+        // guard samples (band_count_ray): classified samples up to AND INCLUDING the first certainly-solid one
+        const bool pick = decoded && guard_pick(((unsigned)r << 6) | (unsigned)lane, salt, ring);
+        sel = (band || pick) && (salt ? lane <= first : lane < first);
+    }
+    const unsigned long long selm = __ballot(sel);
+    const int off = wave_segment(&st[b].P, s_cnt, &s_base, wave, __popcll(selm), lane);
+    if (sel) {
+        const int pos = off + __popcll(selm & lanes_below(lane));
+        plist[c.samp_off + pos] = idx;
+        if (jpts) {       // speculative band rows: the sample goes straight into the jacobian launch (forward + backward), row jren_off + pos
+            float4 p = spts[idx];
+            p.w = __int_as_float(idx);
+            jpts[c.jren_off + pos] = p;
+            srow[idx] = c.jren_off + pos;
+        }
+    }
+}
+
+// k_scan_rays(1) + k_sum_m + k_render_write behind k_render_scan: 64 rays per workgroup (16 waves x 4); the rows keep ray-major,
+// depth-minor order (the reference's row order = the Gram summation order)
+constexpr int TAIL_RAYS = 64;
+
+__global__ __launch_bounds__(WAVE_THREADS) void k_render_tail_wave(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff,
+                                                                   const float4* spts, const float* sdeds, const float* ray_res, const int* kcnt,
+                                                                   const int* mcnt, float4* jpts, float2* jaux, const int* srow, int* jrow) {
+    __shared__ int part[3][WAVE_RAYS];
+    __shared__ int s_koff[TAIL_RAYS];
+    const int b = blockIdx.y;
+    const ObjConst c = oc[b];
+    const int r0 = blockIdx.x * TAIL_RAYS;
+    if (blockIdx.x != 0 && r0 >= c.n_rays) return;             // workgroup-uniform; workgroup 0 always runs (it owns K and m)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // kept rows in front of this workgroup's first ray; workgroup 0: the object's totals K and m
+    int pre = 0, ktot = 0, mtot = 0;
+    for (int i = tid; i < c.n_rays; i += WAVE_THREADS) {
+        const int kc = kcnt[c.ray_off + i];
+        if (i < r0) pre += kc;
+        if (blockIdx.x == 0) { ktot += kc; mtot += mcnt[c.ray_off + i]; }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { pre += __shfl_xor(pre, d); ktot += __shfl_xor(ktot, d); mtot += __shfl_xor(mtot, d); }
+    if (lane == 0) { part[0][wave] = pre; part[1][wave] = ktot; part[2][wave] = mtot; }
+    if (wave == 0) {       // exclusive scan of this workgroup's 64 per-ray counts
+        const int kc = (r0 + lane < c.n_rays) ? kcnt[c.ray_off + r0 + lane] : 0;
+        int incl = kc;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(incl, d);
+            if (lane >= d) incl += v;
+        }
+        s_koff[lane] = incl - kc;
+    }
+    __syncthreads();
+    pre = 0; ktot = 0; mtot = 0;
+#pragma unroll
+    for (int w = 0; w < WAVE_RAYS; ++w) { pre += part[0][w]; ktot += part[1][w]; mtot += part[2][w]; }
+    if (blockIdx.x == 0 && tid == 0) { st[b].K = ktot; st[b].m = mtot; }
+    if (st[b].status != DSP_STATUS_GOOD) return;
+    for (int q = 0; q < TAIL_RAYS / WAVE_RAYS; ++q) {
+        const int rl = wave * (TAIL_RAYS / WAVE_RAYS) + q, r = r0 + rl;
+        if (r >= c.n_rays) break;                               // wave-uniform
+        const int gr = c.ray_off + r;
+        const unsigned long long rmask = raymask[gr];
+        const bool in = (rmask >> lane) & 1ull;
+        const int sidx = c.samp_off + rayoff[gr] + __popcll(rmask & lanes_below(lane));
+        const float dv = in ? sdeds[sidx] : 0.f;
+        const bool kept = in && dv != 0.f;                      // de_ds is never exactly 0 for a kept sample (k_render_scan)
+        const unsigned long long keptm = __ballot(kept);
+        if (kept) {
+            const int dst = c.jren_off + pre + s_koff[rl] + __popcll(keptm & lanes_below(lane));
+            float4 p = spts[sidx];
+            p.w = __int_as_float(sidx);       // compact sample index: where the forward launch left this sample's sdf and relu masks
+            jpts[dst] = p;
+            jaux[dst] = make_float2(dv, ray_res[gr]);
+            if (jrow) jrow[dst] = srow[sidx]; // speculative band rows: this row's gradient already sits in jgrad row srow[sample]
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_sum_m(const ObjConst* oc, ObjState* st, const int* mcnt) {
     __shared__ int part[256];
     const int b = blockIdx.x;
@@ -1102,12 +1306,25 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const ObjState* st, const f
     gsum[((size_t)b * 2 + term) * (72 * 72) + e] = a;
 }
 
-constexpr int SOLVE_THREADS = 1024;   // 16 waves: the elimination is instruction-issue bound, so it is spread over 12 row groups x 72 columns
+constexpr int SOLVE_THREADS = 1024;   // 16 waves: assembly, trace and the code bias use all of them; the factorisation four (LDL^T) or all (Gauss-Jordan)
+constexpr int NS1 = NSOLVE + 1;       // rows of the augmented system: the unknowns + the right-hand side as row n
+constexpr int LDL_THREADS = 256, LDL_NP = NS1 * (NS1 + 1) / 2, LDL_EPT = (LDL_NP + LDL_THREADS - 1) / LDL_THREADS;   // 2628 packed elements, 11 per thread
 
+// 1 / d to full double precision without the IEEE division sequence (it sits on the factorisation's critical path, once per pivot):
+// v_rcp_f64 (>= 25 bits) + two Newton steps
+__device__ __forceinline__ double fast_recip(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(r, fma(-d, r, 1.0), r);
+    r = fma(r, fma(-d, r, 1.0), r);
+    return r;
+}
+
+// SOLVER 0: LDL^T (round 4).  SOLVER 1: the round-2/3 pivot-free Gauss-Jordan, kept as the A/B reference (dsp_batch_set_solver).
+template <int SOLVER>
 __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, ObjState* st, const double* gsum, GnParamsDev prm, int iter,
                                                          const float* codew, const float* cb0, const float* cblat, float* cbias,
                                                float* trace /*nullable*/, const float* depths_next /*nullable: forensics*/, int n_obj) {
-    __shared__ double A[NSOLVE][NSOLVE + 1];
+    __shared__ double A[NS1][NS1 + 1];          // [H | b] in rows 0..n-1 (b = column n); the LDL^T form also keeps b as ROW n
     const int b = blockIdx.x, tid = threadIdx.x;
     const bool stamp = (b == 0 && tid == 0);
     if (stamp) g_solve_clk[0] = wall_clock64();
@@ -1198,6 +1415,87 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
         }
         __syncthreads();
     }
+    if constexpr (SOLVER == 0) {
+        // 2. H dx = b by LDL^T in fp64.  H = sum w J^T J + positive diagonal is symmetric (bit for bit: the Gram kernel's fmaf chains
+        //    commute) positive definite, so no pivoting is needed (the reference inverts H with fp32 LU, optimizer.py:186).  The
+        //    right-hand side rides along as row n of the augmented matrix [[H, b], [b^T, .]]: after the n elimination steps row n holds
+        //    z = L^-1 b, and dx follows from L^T dx = D^-1 z.
+        //    Right-looking, one step per pivot: a_ij -= c_ik c_jk / d_k with UNSCALED columns c_ik = l_ik d_k.  The lower triangle (2628
+        //    elements of the 72 x 72 augmented matrix, packed column-major) lives in the REGISTERS of four waves, 11 elements per thread;
+        //    an element is final after step j - 1 and is published then, once, to its own LDS cell A[i][j] -- so step k reads column k
+        //    that step k - 1 wrote, writes column k + 1, and ONE barrier per step orders both.  The pivot's reciprocal is published by the
+        //    diagonal's owner with the column.  ~250 cycles per step against ~1800 for the Gauss-Jordan form (16 waves, an fp64 division
+        //    per thread and step): 74 -> ~25 us per k_solve at n = 71 (profiles/r04_latency_kernel_stats.md).
+        __shared__ double rdv[NS1];
+        __shared__ int s_sing;
+        if (tid < n) A[n][tid] = A[tid][n];           // b as row n
+        if (tid == 0) {
+            const double d0 = A[0][0];
+            rdv[0] = fast_recip(d0);
+            s_sing = !(d0 > 0.0) ? 1 : 0;              // also NaN
+        }
+        double v[LDL_EPT];
+        int ei[LDL_EPT], ej[LDL_EPT];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < LDL_EPT; ++q) {
+            const int e = tid + LDL_THREADS * q;
+            ei[q] = 0; ej[q] = -1; v[q] = 0.0;
+            if (tid < LDL_THREADS && e < LDL_NP) {
+                // packed column-major lower triangle: column j starts at j * NS1 - j (j - 1) / 2
+                int j = (int)((2 * NS1 + 1 - sqrtf((float)((2 * NS1 + 1) * (2 * NS1 + 1) - 8 * e))) * 0.5f);
+                j = min(max(j, 0), NS1 - 1);
+                while (j > 0 && j * NS1 - j * (j - 1) / 2 > e) --j;
+                while ((j + 1) * NS1 - (j + 1) * j / 2 <= e) ++j;
+                const int i = j + (e - (j * NS1 - j * (j - 1) / 2));
+                if (i <= n && j <= n && !(i == n && j == n)) { ei[q] = i; ej[q] = j; v[q] = A[i][j]; }
+            }
+        }
+        for (int k = 0; k < n; ++k) {
+            __syncthreads();                              // column k and rdv[k] are published; every read of column k - 1 has retired
+            if (tid < LDL_THREADS) {
+                const double rdk = rdv[k];
+#pragma unroll
+                for (int q = 0; q < LDL_EPT; ++q) {
+                    if (ej[q] > k) {
+                        const double cik = A[ei[q]][k], cjk = A[ej[q]][k];
+                        v[q] = fma(-(cik * rdk), cjk, v[q]);
+                        if (ej[q] == k + 1) {             // final: publish (column k + 1 of the next step)
+                            A[ei[q]][k + 1] = v[q];
+                            if (ei[q] == k + 1) {
+                                rdv[k + 1] = fast_recip(v[q]);
+                                if (!(v[q] > 0.0)) s_sing = 1;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (s_sing) { if (tid == 0) s.status = DSP_STATUS_NAN; return; }      // uniform
+        // back substitution L^T dx = D^-1 z by wave 0, column-oriented from the last unknown up: lane j holds w_j = z_j - sum_{i > j}
+        // c_ij dx_i for j = lane and lane + 64; dx_i = rd_i w_i is final when every i' > i has been folded in.  Rows of c are contiguous
+        // in LDS; the next row is fetched while the current one is folded.
+        if (tid < 64) {
+            const int j0 = tid, j1 = tid + 64;
+            double w0 = j0 < n ? A[n][j0] : 0.0, w1 = j1 < n ? A[n][j1] : 0.0;
+            const double rd0 = j0 < n ? rdv[j0] : 0.0, rd1 = j1 < n ? rdv[j1] : 0.0;
+            double c0 = (n >= 1 && j0 < n - 1) ? A[n - 1][j0] : 0.0, c1 = (n >= 1 && j1 < n - 1) ? A[n - 1][j1] : 0.0;
+            for (int i = n - 1; i >= 0; --i) {
+                const double cc0 = c0, cc1 = c1;
+                if (i >= 1) { c0 = j0 < i - 1 ? A[i - 1][j0] : 0.0; c1 = j1 < i - 1 ? A[i - 1][j1] : 0.0; }
+                const double xi_src = (i < 64) ? rd0 * w0 : rd1 * w1;             // valid in lane i & 63
+                const int src = i & 63;
+                const int lo = __builtin_amdgcn_readlane(__double2loint(xi_src), src), hi = __builtin_amdgcn_readlane(__double2hiint(xi_src), src);
+                const double xi = __hiloint2double(hi, lo);
+                if (tid == src) A[i][n] = xi;                                       // dx_i, where the update below expects it
+                w0 = fma(-cc0, xi, w0);                                             // cc = 0 for j >= i
+                w1 = fma(-cc1, xi, w1);
+            }
+        }
+        if (stamp) { g_solve_clk[2] = wall_clock64(); g_solve_clk[6] = clock64(); }
+        __syncthreads();
+    } else {
     // 2. Gauss-Jordan elimination of [H | b] in fp64.  H = sum w J^T J + positive diagonal is symmetric positive
     //    definite, so no pivoting is needed (the reference inverts H with fp32 LU, optimizer.py:186); eliminating above
     //    and below the diagonal leaves x_i = A[i][n] / A[i][i] with no serial back-substitution.  Column k itself is
@@ -1208,7 +1506,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
     //    (instruction-fetch bound, 100 us), so the loop runs over groups of twelve pivots and ROTATES the register file by one
     //    position per group: the pivot rows of the current group are always a[0], and a[i] is row 12*((kk+i) mod 6) + tr.
     //    (History for one 71x71 solve: [H | b] in LDS with per-element division and one LDS round trip per element, 137 us;
-    //    registers + batched reads on 4 waves, 94 us, instruction-issue bound; 16 waves, this form.)
+    //    registers + batched reads on 4 waves, 94 us, instruction-issue bound; 16 waves, this form: 74 us.)
     const int tr = tid / (NSOLVE + 1), tc = tid % (NSOLVE + 1);     // 12 row groups x 72 columns = 864 working threads
     constexpr int ROW_GROUPS = 12, ROWS_PER_THREAD = (NSOLVE + ROW_GROUPS - 1) / ROW_GROUPS;
     __shared__ double prow[ROW_GROUPS][NSOLVE + 1];
@@ -1277,17 +1575,28 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
     }
     if (stamp) { g_solve_clk[2] = wall_clock64(); g_solve_clk[6] = clock64(); }
     __syncthreads();
+    }
     if (trace) {
         float* tr = trace + ((size_t)iter * n_obj + b) * TRACE_STRIDE;
         for (int e = tid; e < n; e += SOLVE_THREADS) tr[NSOLVE * NSOLVE + NSOLVE + e] = (float)A[e][n];
     }
-    // 3. update (optimizer.py:187-192 / 73-74)
-    if (!prm.pose_only) {
-        if (tid >= 64 && tid < 64 + CODE_LEN) {
-            const int i = tid - 64;
-            s.code[i] = s.code[i] + prm.lr * (float)A[pd + i][n];
-        }
+    // 3. update (optimizer.py:187-192 / 73-74).  Wave 0 carries the pose (one lane: exp map, 4x4 product, the next iteration's derived
+    //    state -- a few us of serial fp64), wave 1 the code, and waves 2.. the next iteration's code bias once the code is in LDS: the
+    //    serial pose work no longer sits in front of the bias loop.
+    __shared__ float zc[CODE_LEN];
+    if (!prm.pose_only && tid >= 64 && tid < 64 + CODE_LEN) {
+        const int i = tid - 64;
+        const float zv = s.code[i] + prm.lr * (float)A[pd + i][n];
+        s.code[i] = zv;
+        zc[i] = zv;
+        // the prepass margin follows the code (this wave holds all CODE_LEN = 64 entries)
+        float zmax = fabsf(zv);
+        bool bad = zv != zv;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { zmax = fmaxf(zmax, __shfl_xor(zmax, d)); bad = bad || __shfl_xor((int)bad, d); }
+        if (i == 0) s.lp_delta = lp_delta_of(bad ? __int_as_float(0x7f800000) : zmax, prm.lp);
     }
+    __syncthreads();
     if (tid == 0) {
         float dx[7], dT[16], nt[16];
         for (int i = 0; i < pd; ++i) dx[i] = (prm.pose_only ? 1.f : prm.lr) * (float)A[i][n];
@@ -1304,6 +1613,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
 #pragma unroll
         for (int i = 0; i < 16; ++i) s.t_oc[i] = nt[i];
         s.vsum = 0; s.ksum = 0;
+        s.V = 0; s.P = 0;          // the wave-per-ray bookkeeping counts into these (k_front_wave, k_band_wave); the scans of the other forms overwrite them
         if (stamp) g_solve_clk[3] = wall_clock64();
         if (!prm.pose_only) {
             derive_iter_state(s, prm.n_depth);
@@ -1315,22 +1625,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
         }
         if (stamp) g_solve_clk[4] = wall_clock64();
     }
-    // 4. the next iteration's per-object code bias (k_code_bias: same k-ordered fmaf chains), while this workgroup holds the new code
-    if (!prm.pose_only && cbias) {
-        __shared__ float zc[CODE_LEN];
-        __syncthreads();
-        if (tid < CODE_LEN) {
-            const float zv = s.code[tid];
-            zc[tid] = zv;
-            // the prepass margin follows the code (wave 0 holds all CODE_LEN = 64 entries)
-            float zmax = fabsf(zv);
-            bool bad = zv != zv;
-#pragma unroll
-            for (int d = 32; d > 0; d >>= 1) { zmax = fmaxf(zmax, __shfl_xor(zmax, d)); bad = bad || __shfl_xor((int)bad, d); }
-            if (tid == 0) s.lp_delta = lp_delta_of(bad ? __int_as_float(0x7f800000) : zmax, prm.lp);
-        }
-        __syncthreads();
-        for (int e = tid; e < 2 * WIDTH; e += SOLVE_THREADS) {
+    // 4. the next iteration's per-object code bias (k_code_bias: same k-ordered fmaf chains), by the waves that are not busy with the pose
+    if (!prm.pose_only && cbias && tid >= 128) {
+        for (int e = tid - 128; e < 2 * WIDTH; e += SOLVE_THREADS - 128) {
             const int which = e / WIDTH, o = e % WIDTH;
             float acc = which == 0 ? cb0[o] : cblat[o];
             const float* w = codew + (size_t)e * CODE_LEN;
@@ -1362,29 +1659,31 @@ __global__ __launch_bounds__(256) void k_count_alive(const ObjConst* oc, ObjStat
     if (threadIdx.x == 0) st[b].n_alive = part[0];
 }
 
-// final result: T_co = inv(T_oc) (optimizer.py:200; 81-84 for pose-only, which also divides the scale out)
-__global__ void k_finalize(ObjState* st, const float* scale_in, int n_obj, int pose_only, float* out_t, float* out_code,
-                           float* out_loss, int* out_status, float* out_packed) {
+// final result: T_co = inv(T_oc) (optimizer.py:200; 81-84 for pose-only, which also divides the scale out), as ONE DSP_RESULT_WIDTH row per
+// object (t_cam_obj 16 | code 64 | loss | status): what dsp_batch_results unpacks and what the multi-GPU gather sends, device-resident.
+// guard_out (optional): the always-on prepass guard's per-object words {lp_delta, trips, max error bits}, packed for the run's ONE read-back.
+__global__ void k_finalize(ObjState* st, const float* scale_in, int n_obj, int pose_only, float* out_packed, unsigned* guard_out) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_obj) return;
     const ObjState& s = st[b];
+    if (s.status == DSP_STATUS_SKIP) return;      // partial re-run: the row of the earlier run stands
     double toc[16], tco[16];
     for (int i = 0; i < 16; ++i) toc[i] = (double)s.t_oc[i];
     if (!inv4(toc, tco)) for (int i = 0; i < 16; ++i) tco[i] = nan("");
+    float* row = out_packed + (size_t)DSP_RESULT_WIDTH_DEV * b;
     for (int i = 0; i < 16; ++i) {
         float v = (float)tco[i];
         if (pose_only && (i % 4) < 3 && i < 12) v = v / scale_in[b];
-        out_t[16 * b + i] = v;
+        row[i] = v;
     }
-    for (int i = 0; i < CODE_LEN; ++i) out_code[CODE_LEN * b + i] = s.code[i];
-    out_loss[b] = s.loss;
-    out_status[b] = s.status;
-    // the same results as one DSP_RESULT_WIDTH row (t_cam_obj 16 | code 64 | loss | status): what the multi-GPU gather sends, device-resident
-    float* row = out_packed + (size_t)DSP_RESULT_WIDTH_DEV * b;
-    for (int i = 0; i < 16; ++i) row[i] = out_t[16 * b + i];
     for (int i = 0; i < CODE_LEN; ++i) row[16 + i] = s.code[i];
     row[80] = s.loss;
     row[81] = (float)s.status;
+    if (guard_out) {
+        guard_out[3 * b + 0] = __float_as_uint(s.lp_delta);
+        guard_out[3 * b + 1] = s.guard_trips;
+        guard_out[3 * b + 2] = s.guard_err;
+    }
 }
 
 // per-object code contribution to layer 0 and to the latent_in layer (one workgroup per object):
@@ -1413,8 +1712,8 @@ void launch_code_bias(const float* codew, const float* b0, const float* blat, co
     hipLaunchKernelGGL(k_code_bias, dim3(n_obj), dim3(256), 0, s, codew, b0, blat, codes, code_stride, out);
 }
 void launch_init_state(ObjState* st, const float* t, const float* codes, const float* scale, const float* depths, int B, int D, int pose_only,
-                       const LpDeltaTab& lp, hipStream_t s) {
-    hipLaunchKernelGGL(k_init_state, dim3((B + 63) / 64), dim3(64), 0, s, st, t, codes, scale, depths, B, D, pose_only, lp);
+                       const LpDeltaTab& lp, const unsigned char* run_mask, unsigned* summary, int summary_words, hipStream_t s) {
+    hipLaunchKernelGGL(k_init_state, dim3((B + 63) / 64), dim3(64), 0, s, st, t, codes, scale, depths, B, D, pose_only, lp, run_mask, summary, summary_words);
 }
 void launch_sample_count(const ObjConst* oc, ObjState* st, const float* rays, unsigned long long* m, int* c, int D, int maxR, int B, hipStream_t s) {
     hipLaunchKernelGGL(k_sample_count, GRID2(maxR, B), dim3(256), 0, s, oc, st, rays, m, c, D);
@@ -1465,12 +1764,29 @@ void launch_render_tail_fused(const ObjConst* oc, ObjState* st, const int* raycn
     hipLaunchKernelGGL(k_render_tail_fused, dim3(B), dim3(FUSED_THREADS), 0, s, oc, st, raycnt, rayoff, spts, sdeds, ray_res, kcnt, koff, mcnt, jpts, jaux,
                        srow, jrow);
 }
+void launch_front_wave(const ObjConst* oc, ObjState* st, const float* rays, const float* pts, unsigned long long* raymask, int* raycnt, int* rayoff,
+                       float4* spts, float* ssdf, unsigned char* alive, float4* jpts, float2* jaux, int D, int maxR, int maxM, int B, hipStream_t s) {
+    const int nrb = std::max(1, (maxR + WAVE_RAYS - 1) / WAVE_RAYS), nsb = (maxM + WAVE_THREADS - 1) / WAVE_THREADS;
+    hipLaunchKernelGGL(k_front_wave, dim3((unsigned)(nrb + nsb), (unsigned)B), dim3(WAVE_THREADS), 0, s, oc, st, rays, pts, raymask, raycnt, rayoff, spts, ssdf, alive,
+                       jpts, jaux, D, nrb);
+}
+void launch_band_wave(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff, const float* ssdf, float th, unsigned guard_salt,
+                      int* plist, const float4* spts, float4* jpts, int* srow, int maxR, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_band_wave, dim3((unsigned)std::max(1, (maxR + WAVE_RAYS - 1) / WAVE_RAYS), (unsigned)B), dim3(WAVE_THREADS), 0, s, oc, st, raymask, rayoff,
+                       ssdf, th, guard_salt, plist, spts, jpts, srow);
+}
+void launch_render_tail_wave(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff, const float4* spts, const float* sdeds,
+                             const float* ray_res, const int* kcnt, const int* mcnt, float4* jpts, float2* jaux, const int* srow, int* jrow, int maxR, int B,
+                             hipStream_t s) {
+    hipLaunchKernelGGL(k_render_tail_wave, dim3((unsigned)std::max(1, (maxR + TAIL_RAYS - 1) / TAIL_RAYS), (unsigned)B), dim3(WAVE_THREADS), 0, s, oc, st, raymask,
+                       rayoff, spts, sdeds, ray_res, kcnt, mcnt, jpts, jaux, srow, jrow);
+}
 void launch_surface(const ObjConst* oc, const ObjState* st, const float* pts, float4* jpts, float2* jaux, int maxM, int B, hipStream_t s) {
     hipLaunchKernelGGL(k_surface, GRID2(maxM, B), dim3(256), 0, s, oc, st, pts, jpts, jaux);
 }
-void launch_build_tiles(const ObjConst* oc, const ObjState* st, int B, int mode, int4* tiles, int* n_tiles, double* counters, int add_v, int tile_pts,
-                        int cnt_slot, hipStream_t s) {
-    hipLaunchKernelGGL(k_build_tiles, dim3(1), dim3(256), 0, s, oc, st, B, mode, tiles, n_tiles, counters, add_v, tile_pts, cnt_slot);
+void launch_build_tiles(const ObjConst* oc, ObjState* st, int B, int mode, int4* tiles, int* n_tiles, double* counters, int add_v, int tile_pts,
+                        int cnt_slot, hipStream_t s, int apply_few) {
+    hipLaunchKernelGGL(k_build_tiles, dim3(1), dim3(256), 0, s, oc, st, B, mode, tiles, n_tiles, counters, add_v, tile_pts, cnt_slot, apply_few);
 }
 void launch_tail_tiles(const int4* tiles, int* n_tiles, int4* tiles16, int* n_tiles16, int n_cu, hipStream_t s) {
     hipLaunchKernelGGL(k_tail_tiles, dim3(1), dim3(256), 0, s, tiles, n_tiles, tiles16, n_tiles16, n_cu);
@@ -1496,16 +1812,20 @@ void launch_jrows(const ObjConst* oc, const ObjState* st, const float4* jpts, co
     hipLaunchKernelGGL(k_jrows, dim3((cap + 255) / 256), dim3(256), 0, s, oc, st, jpts, jaux, jgrad, jrow, term, rows);
 }
 void launch_solve(const ObjConst* oc, ObjState* st, const float* partials, double* gsum, int n_slices, const GnParamsDev& prm, int iter,
-                  float* trace, const float* codew, const float* b0, const float* blat, float* cbias, const float* depths_next, int B, hipStream_t s) {
+                  float* trace, const float* codew, const float* b0, const float* blat, float* cbias, const float* depths_next, int B, hipStream_t s,
+                  int solver) {
     hipLaunchKernelGGL(k_gram_reduce, dim3((72 * 72 + 255) / 256, B, prm.pose_only ? 1 : 2), dim3(256), 0, s, st, partials, n_slices, gsum);
-    hipLaunchKernelGGL(k_solve, dim3(B), dim3(SOLVE_THREADS), 0, s, oc, st, gsum, prm, iter, codew, b0, blat, cbias, trace, depths_next, B);
+    if (solver == 1)
+        hipLaunchKernelGGL(k_solve<1>, dim3(B), dim3(SOLVE_THREADS), 0, s, oc, st, gsum, prm, iter, codew, b0, blat, cbias, trace, depths_next, B);
+    else
+        hipLaunchKernelGGL(k_solve<0>, dim3(B), dim3(SOLVE_THREADS), 0, s, oc, st, gsum, prm, iter, codew, b0, blat, cbias, trace, depths_next, B);
 }
 void launch_inlier_filter(const ObjConst* oc, ObjState* st, const float* jgrad, unsigned char* alive, int maxM, int B, hipStream_t s) {
     hipLaunchKernelGGL(k_inlier_filter, GRID2(maxM, B), dim3(256), 0, s, oc, st, jgrad, alive);
     hipLaunchKernelGGL(k_count_alive, dim3(B), dim3(256), 0, s, oc, st, alive);
 }
-void launch_finalize(ObjState* st, const float* scale, int B, int pose_only, float* t, float* code, float* loss, int* status, float* packed, hipStream_t s) {
-    hipLaunchKernelGGL(k_finalize, dim3((B + 63) / 64), dim3(64), 0, s, st, scale, B, pose_only, t, code, loss, status, packed);
+void launch_finalize(ObjState* st, const float* scale, int B, int pose_only, float* packed, unsigned* guard_out, hipStream_t s) {
+    hipLaunchKernelGGL(k_finalize, dim3((B + 63) / 64), dim3(64), 0, s, st, scale, B, pose_only, packed, guard_out);
 }
 
 hipError_t debug_solve_clocks(unsigned long long* out8) { return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_solve_clk), 64); }

@@ -114,21 +114,9 @@ __device__ __forceinline__ void prepass_guard_tol(const MlpArgs& a, int obj, boo
     }
 }
 
+// the same with the tolerance read here (callers that have no early point to fetch it from)
 __device__ __forceinline__ void prepass_guard(const MlpArgs& a, int obj, bool active, float old_lp, float y) {
-    float err = 0.f;
-    if (active && old_lp != 1.0f) {
-        err = fabsf(old_lp - y);
-        if (!(err < 1.0f)) err = 1.0f;                  // NaN / inf prepass value
-    }
-    float m = err;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
-    if (m > 0.f && (threadIdx.x & 63) == 0) {
-        unsigned* w = a.guard + (size_t)obj * a.guard_stride;
-        const float tol = 0.5f * __uint_as_float(w[0]);
-        atomicMax(w + 2, __float_as_uint(m));
-        if (!(m < tol)) atomicAdd(w + 1, 1u);
-    }
+    prepass_guard_tol(a, obj, active, old_lp, y, 0.5f * __uint_as_float(a.guard[(size_t)obj * a.guard_stride]));
 }
 
 }  // namespace dsp

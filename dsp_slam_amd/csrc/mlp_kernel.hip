@@ -69,11 +69,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
     auto issue_next = [&]() {   // advance to the next chunk of the stream / next ring slot
         issue_pos = (issue_pos + 1 == total_chunks) ? 0 : issue_pos + 1;
         issue_slot = (issue_slot + 1 == NBUF) ? 0 : issue_slot + 1;
-#if defined(ABL_SAMESRC)
-        isrc = wbase;
-#else
         isrc = wbase + (size_t)issue_pos * CHUNK_BYTES;
-#endif
         idst = ring0 + issue_slot * CHUNK_BYTES + wave * 4096;
     };
     auto issue = [&]() {
@@ -255,13 +251,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
                                     // Chunk q+1 has landed for this wave once <= NBUF-3 younger chunks are in flight; the
                                     // barrier publishes every wave's quarter and proves all reads of chunk q-1 retired
                                     // (every wave is inside chunk q), so its slot can be refilled right away.
-#if defined(ABL_NOWAIT)
-                                    asm volatile("s_barrier" ::: "memory");
-#elif defined(ABL_NOBAR)
-                                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GLDS_PER_CHUNK * (NBUF - 3)) : "memory");
-#else
                                     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(GLDS_PER_CHUNK * (NBUF - 3)) : "memory");
-#endif
                                 }
 #if PAIR_READS
                                 // A operands in groups of RG k-steps: one wait (lgkmcnt(0): the group read RG k-steps ago) and RG reads
@@ -280,11 +270,9 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
                                 }
 #else
                                 const int sp = s + PREFETCH;
-#if !defined(ABL_NOLDS)
                                 abuf[sp % 4] = (sp < KSTEPS_PER_CHUNK)
                                                    ? *reinterpret_cast<const f32x4*>(cb + sp * 1024)
                                                    : *reinterpret_cast<const f32x4*>(nb + (sp - KSTEPS_PER_CHUNK) * 1024);
-#endif
 #endif
 #if PAIR_READS
                                 const f32x4 av = abuf[s % (2 * PAIR_READS)];
@@ -293,13 +281,11 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
 #endif
                                 const float b = sin_[16 * c + s];
                                 acc[4 * og + 0] = MFMA16(av.x, b, (c == 0 && s == 0) ? bias4[0] : acc[4 * og + 0]);
-#if !defined(ABL_NOISSUE)
                                 // refill of the slot freed by the barrier above: one DMA piece per k-step, behind an MFMA
                                 if (s == KSTEPS_PER_CHUNK / 2 + 0) { glds_set_dst(idst); glds_piece_m0<0>(isrc, lane_off, idst); };
                                 if (s == KSTEPS_PER_CHUNK / 2 + 1) glds_piece_m0<1>(isrc, lane_off, idst);
                                 if (s == KSTEPS_PER_CHUNK / 2 + 2) glds_piece_m0<2>(isrc, lane_off, idst);
                                 if (s == KSTEPS_PER_CHUNK / 2 + 3) { glds_piece_m0<3>(isrc, lane_off, idst); issue_next(); }
-#endif
                                 acc[4 * og + 1] = MFMA16(av.y, b, (c == 0 && s == 0) ? bias4[1] : acc[4 * og + 1]);
                                 acc[4 * og + 2] = MFMA16(av.z, b, (c == 0 && s == 0) ? bias4[2] : acc[4 * og + 2]);
                                 acc[4 * og + 3] = MFMA16(av.w, b, (c == 0 && s == 0) ? bias4[3] : acc[4 * og + 3]);

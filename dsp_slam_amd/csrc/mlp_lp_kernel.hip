@@ -186,11 +186,7 @@ __device__ __forceinline__ void lp_pass(const LpPass pd, u32x4 (&in)[32], u32x4 
                 if (sl == LP_KSTEPS_PER_CHUNK / 2) {
                     // chunk q+1 has landed for this wave once <= LP_NBUF-3 younger chunks are in flight; the barrier
                     // publishes every wave's quarter and proves all reads of chunk q-1 retired (mlp_kernel.hip)
-#if defined(LP_ABL_NOBAR)
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GLDS_PER_CHUNK * (LP_NBUF - 3)) : "memory");
-#else
                     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(GLDS_PER_CHUNK * (LP_NBUF - 3)) : "memory");
-#endif
                 }
 #if defined(LP_PAIR_READS)   // measured (round 3, no spills in either form): 0.5248 vs 0.5284 of peak -- no gain; the kernel is clock-governed, not issue-bound
                 // A fragments of two k-steps per group, one lgkmcnt wait per group (mlp_common.h: every instruction between MFMAs costs)
@@ -208,28 +204,19 @@ __device__ __forceinline__ void lp_pass(const LpPass pd, u32x4 (&in)[32], u32x4 
 #else
                 const int sp = sl + LP_PREFETCH;
                 const lds_cptr src = (sp < LP_KSTEPS_PER_CHUNK) ? cbp + sp * LP_KSTEP_BYTES : nbp + (sp - LP_KSTEPS_PER_CHUNK) * LP_KSTEP_BYTES;
-#if !defined(LP_ABL_NOLDS)
                 abuf[sp % 4][0] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(src);
                 abuf[sp % 4][1] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(src + 1024);
 #endif
-#endif
                 const u32x4 a0 = abuf[sl % 4][0], a1 = abuf[sl % 4][1];
                 const u32x4 b = in[s];
-#if !defined(LP_ABL_NOMFMA)
                 acc[par][0] = lp_mfma<BF>(a0, b, s == 0 ? bias[0] : acc[par][0]);
-#endif
-#if !defined(LP_ABL_NOISSUE)
                 // refill of the slot freed by the barrier above: one DMA piece per k-step, behind an MFMA
                 if (sl == LP_KSTEPS_PER_CHUNK / 2 + 0) { glds_set_dst(rg.idst); glds_piece_m0<0>(rg.isrc, rg.lane_off, rg.idst); };
                 if (sl == LP_KSTEPS_PER_CHUNK / 2 + 1) glds_piece_m0<1>(rg.isrc, rg.lane_off, rg.idst);
                 if (sl == LP_KSTEPS_PER_CHUNK / 2 + 2) glds_piece_m0<2>(rg.isrc, rg.lane_off, rg.idst);
                 if (sl == LP_KSTEPS_PER_CHUNK / 2 + 3) { glds_piece_m0<3>(rg.isrc, rg.lane_off, rg.idst); lp_issue_next(rg); }
-#endif
-#if !defined(LP_ABL_NOMFMA)
                 acc[par][1] = lp_mfma<BF>(a1, b, s == 0 ? bias[1] : acc[par][1]);
-#endif
                 if (s == LP_KSTEPS_PER_CHUNK * NCH - 2 && g + 1 < LP_NOG) lp_load_rows(bp, g + 1, hh, bias);   // the next group's bias, two k-steps ahead
-#if !defined(LP_ABL_NOEPI)
                 // epilogue of the previous group, two accumulator quads per k-step behind this group's MFMAs
                 if (g > 0) {
                     if (s == 2) lp_epilogue<BF, LAST>(g - 1, 0, 2, acc[par ^ 1], dp, hh, out, part);
@@ -237,7 +224,6 @@ __device__ __forceinline__ void lp_pass(const LpPass pd, u32x4 (&in)[32], u32x4 
                     if (s == 4) lp_epilogue<BF, LAST>(g - 1, 4, 6, acc[par ^ 1], dp, hh, out, part);
                     if (s == 5) lp_epilogue<BF, LAST>(g - 1, 6, 8, acc[par ^ 1], dp, hh, out, part);
                 }
-#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
             rg.rd_slot = nx_slot;

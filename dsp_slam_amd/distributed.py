@@ -78,6 +78,10 @@ def gather_results_device(batches, shards, dist, device, dst=0):
     rank, world = dist.get_rank(), dist.get_world_size()
     n_max = max(b - a for a, b in shards)
     mine = torch.zeros((max(n_max, 1), RESULT_WIDTH), dtype=torch.float32, device=device)
+    # torch.zeros fills on TORCH's current stream; the library copies the rows on its own (non-blocking) stream, which nothing orders
+    # behind that fill -- without this wait a late fill could zero rows the copy has already delivered (zeros read as "status GOOD")
+    if torch.device(device).type == "cuda":
+        torch.cuda.current_stream(device).synchronize()
     row = 0
     for bt in batches:
         bt.results_packed_to_device(mine.data_ptr() + row * RESULT_WIDTH * 4)

@@ -136,8 +136,17 @@ class Batch(object):
         """-1 = automatic, 0 = off, 1 = the last partial round of the fp32 forward launch runs as 16-point latency-form tiles."""
         L.check(L.load().dsp_batch_set_tail_split(self._h, int(mode)), self.engine._h, "dsp_batch_set_tail_split")
 
+    def set_solver(self, mode):
+        """0 = LDL^T (default), 1 = pivot-free Gauss-Jordan (the round-2/3 kernel, kept as the A/B reference)."""
+        L.check(L.load().dsp_batch_set_solver(self._h, int(mode)), self.engine._h, "dsp_batch_set_solver")
+
+    def set_kernel_timing(self, mode):
+        """HIP events around every decoder launch (stats ms_mlp_*): -1 = automatic (batches of more than 16 objects), 0 = off, 1 = on."""
+        L.check(L.load().dsp_batch_set_kernel_timing(self._h, int(mode)), self.engine._h, "dsp_batch_set_kernel_timing")
+
     def set_fused_bookkeeping(self, mode):
-        """-1 = automatic, 0 = per-ray bookkeeping as separate launches (throughput form), 1 = fused per object (latency form)."""
+        """-1 = automatic, 0 = per-ray bookkeeping as separate launches (throughput form), 1 = fused per object (one workgroup each),
+        2 = one wave per ray over the whole chip (latency form, round 4)."""
         L.check(L.load().dsp_batch_set_fused_bookkeeping(self._h, int(mode)), self.engine._h, "dsp_batch_set_fused_bookkeeping")
 
     def set_split_rows(self, mode):
@@ -283,6 +292,10 @@ class Engine(object):
         L.check(L.load().dsp_prepass_calibration_table(self._h, int(dtype), L.ptr(m), L.ptr(e), L.ptr(d), C.byref(g)), self._h,
                 "dsp_prepass_calibration_table")
         return dict(mags=m, max_err=e, delta=d, guard_err=g.value)
+
+    def prepass_reset_guard(self):
+        """Forget what earlier guard trips on this engine left behind: the margins return to the decoder's calibration."""
+        L.check(L.load().dsp_prepass_reset_guard(self._h), self._h, "dsp_prepass_reset_guard")
 
     def decode_sdf_multi(self, codes, pts):
         """(n_codes, 64) codes x one shared (n, 3) point set -> (n_codes, n) sdf, one kernel launch."""

@@ -9,6 +9,7 @@
 // Prints one line per GPU and the gathered result's checksum; exits non-zero unless the sharded result equals, bit for bit, the result
 // of all objects on one GPU (objects are independent: tests/test_gpu_configs.py::test_shard_equals_unsharded).  Works with one GPU too
 // (a communicator of one rank), which is how the GPU tests run it.
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -109,13 +110,24 @@ int main(int argc, char** argv) {
     for (int g = 0; g < n_gpu; ++g)
         if (dsp_create(&desc, g, &handles[g]) != DSP_OK) { fprintf(stderr, "dsp_create(device %d): %s\n", g, dsp_last_error(nullptr)); return 1; }
 
-    // contiguous blocks of objects per GPU; one host thread per handle runs its batch
+    // contiguous, deliberately UNEVEN blocks of objects per GPU (GPU g takes a share ~ g + 1, at least one object: the gather pads uneven
+    // blocks to the largest); one host thread per handle runs its batch
+    std::vector<int> bound(n_gpu + 1, 0);
+    {
+        const int64_t tri = (int64_t)n_gpu * (n_gpu + 1) / 2;
+        for (int g = 1; g <= n_gpu; ++g) {
+            int b = (int)((int64_t)obj.n * ((int64_t)g * (g + 1) / 2) / tri);
+            b = std::max(b, bound[g - 1] + 1);                       // never an empty shard
+            bound[g] = std::min(b, (int)obj.n - (n_gpu - g));        // ... and room for one object on every later GPU
+        }
+        bound[n_gpu] = obj.n;
+    }
     std::vector<dsp_batch*> batches(n_gpu, nullptr);
     std::vector<int> rc(n_gpu, 0);
     std::vector<std::thread> threads;
     for (int g = 0; g < n_gpu; ++g)
         threads.emplace_back([&, g] {
-            const int a = (int)((int64_t)obj.n * g / n_gpu), b = (int)((int64_t)obj.n * (g + 1) / n_gpu);
+            const int a = bound[g], b = bound[g + 1];
             batches[g] = make_batch(handles[g], prm, obj, a, b);
             rc[g] = batches[g] ? dsp_batch_run(batches[g]) : DSP_E_ARG;
             dsp_stats st;

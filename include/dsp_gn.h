@@ -37,11 +37,14 @@ typedef struct dsp_batch dsp_batch;
 
 /* Folded decoder weights, layer k: weights[k] is (out_dims[k] x in_dims[k]) row-major, biases[k] (out_dims[k]).
  * Replaces deep_sdf/workspace.py:202-223 (config_decoder) + Decoder.__init__ (deep_sdf/deep_sdf_decoder.py:10-73):
- * weight-norm is folded by the caller, W = g * v / ||v||_row.  Supported geometry: hidden width 512, code_len 64,
- * 2..8 hidden layers, exactly one latent_in layer (input re-concatenated there), final layer 512 -> 1 + tanh. */
+ * weight-norm is folded by the caller, W = g * v / ||v||_row.  Supported geometry (checked by dsp_create, DSP_E_ARG otherwise): code_len
+ * 64 or 32; ONE hidden width, a multiple of 16 and at most 512 (narrower decoders run embedded in the 512-row slabs); 2..8 hidden layers;
+ * exactly one latent_in layer >= 2 whose input is [h | code | xyz] (the layer in front of it emits width - code_len - 3 rows); final layer
+ * width -> 1 + tanh.  The optimiser state always carries 64 code entries (the unused ones of a 32-D decoder stay zero).  The low-precision
+ * prepass additionally needs an even number of hidden layers (DeepSDF's 8); other decoders run with the prepass off. */
 typedef struct dsp_decoder_desc {
     int32_t n_layers;            /* number of Linear layers (9 for DSP-SLAM) */
-    int32_t code_len;            /* 64 */
+    int32_t code_len;            /* 64 or 32 */
     int32_t latent_in;           /* index of the layer whose input is [h | code | xyz] (4), or -1 */
     const int32_t* out_dims;     /* [n_layers] */
     const int32_t* in_dims;      /* [n_layers] */
@@ -71,8 +74,8 @@ typedef struct dsp_stats {
     double n_fwd_points;         /* forward-only decoder points actually evaluated (<= sum of V: samples behind a solid sample are skipped) */
     double n_jac_points;         /* points decoded forward + backward: sum of M (surface), plus K (render rows) without mask reuse */
     double ms_total;             /* HIP-event time of the whole run on the handle's stream */
-    double ms_mlp_fwd;           /* summed time of the forward-only decoder kernel launches */
-    double ms_mlp_jac;           /* summed time of the forward+gradient decoder kernel launches */
+    double ms_mlp_fwd;           /* summed time of the forward-only decoder kernel launches (0 with kernel timing off: dsp_batch_set_kernel_timing) */
+    double ms_mlp_jac;           /* summed time of the forward+gradient decoder kernel launches (likewise) */
     int32_t n_mlp_fwd_launches;
     int32_t n_mlp_jac_launches;
     double n_insphere_points;    /* sum over iterations and objects of V, the in-sphere sample count the reference decodes */
@@ -91,7 +94,7 @@ typedef struct dsp_stats {
     double prepass_guard_trips;  /* waves that saw |sdf_lp - sdf_fp32| >= half the object's margin (0 in a healthy run) */
     double prepass_guard_objects;/* objects with at least one trip */
     float prepass_guard_max_err; /* largest |sdf_lp - sdf_fp32| over the compared samples */
-    int32_t prepass_guard_rerun; /* 1: the guard tripped and the results come from a second run with the prepass off */
+    int32_t prepass_guard_rerun; /* 1: the guard tripped; the objects it tripped on were run again with the prepass off (their results come from that run) */
 } dsp_stats;
 
 /* ---- lifetime --------------------------------------------------------------------------------- */
@@ -223,9 +226,12 @@ int dsp_batch_set_prepass_audit(dsp_batch* b, int on);
 /* The guard is ON by default and costs ~0.3 % more fp32 points: with the prepass on, the fp32 kernel also re-decodes a sample of the
  * samples the prepass classified -- 1/8 of the ring th + delta <= |sdf_lp| < th + 2 delta, where an error between delta and 2 delta would
  * misclassify, 1/512 of everything farther out; a different sample every launch -- and compares EVERY sample it decodes (the whole
- * widened band included) with the prepass value it replaces.  A difference of half the object's margin or more trips the guard: dsp_batch_run then runs the batch AGAIN with the
- * prepass off and returns those results (dsp_stats.prepass_guard_rerun = 1), and the handle's margins are raised to 4 x the error
- * seen.  on = 0 turns the guard off (tests: what an unguarded run would have returned). */
+ * widened band included) with the prepass value it replaces.  A difference of half the object's margin or more trips the guard:
+ * dsp_batch_run then runs the OBJECTS IT TRIPPED ON again with the prepass off and returns those results for them (the healthy objects
+ * keep theirs: dsp_stats.prepass_guard_rerun = 1, prepass_guard_objects = how many were re-run); the stand-alone dsp_compute_render_loss
+ * re-evaluates the term the same way.  Where the run used the calibrated margins, the handle's margins are raised to 4 x the error seen
+ * (at most 0.125; dsp_prepass_reset_guard undoes it); a margin forced through dsp_batch_set_prepass leaves them alone.
+ * on = 0 turns the guard off (tests: what an unguarded run would have returned). */
 int dsp_batch_set_prepass_guard(dsp_batch* b, int on);
 /* Render rows (kept ray samples) need the decoder's input gradient at points the forward launches of the same iteration
  * already decoded.  With mask reuse on, those launches export the relu masks of band samples (|sdf| < cut_off, 512 B each)
@@ -244,9 +250,11 @@ int dsp_batch_set_split_rows(dsp_batch* b, int mode);
  * latency-form tiles in a launch of its own (~0.3 of a 64-point tile's time).  -1 = automatic (on where the 64-point forward kernel runs
  * without mask export), 0 = off, 1 = on where applicable.  Results are identical for every setting. */
 int dsp_batch_set_tail_split(dsp_batch* b, int mode);
-/* Per-ray bookkeeping (sampling + compaction, band selection, occupancy scan + row compaction) either as one thread block per 256 rays
- * with separate scan launches (throughput form) or fused per object (latency form: 3 launches instead of 11 per iteration).  -1 = automatic
- * (fused for batches of <= 16 objects), 0 = off, 1 = on.  Results are identical for every setting. */
+/* Per-ray bookkeeping (sampling + compaction, band selection, occupancy scan + row compaction): 0 = one thread block per 256 rays with
+ * separate count / scan / write launches (throughput form); 1 = fused per object, one workgroup each (3 launches instead of 11 per
+ * iteration; round 2); 2 = one WAVE per ray over the whole chip, list segments handed out by running counters instead of scans (round 4:
+ * a detection's rays no longer sit on one CU); -1 = automatic (2 for batches of <= 16 objects, else 0).  Results are identical for every
+ * setting. */
 int dsp_batch_set_fused_bookkeeping(dsp_batch* b, int mode);
 /* Latency path with the prepass on: the samples the prepass could not classify go straight into the jacobian launch (forward + backward,
  * their sdf scattered back for the occupancy scan) instead of a forward launch of their own -- one decoder launch less per iteration.
@@ -271,6 +279,17 @@ int dsp_batch_set_depth_schedule(dsp_batch* b, const float* depths, int32_t n_it
  * scan read: fp32 inside the band, the prepass value or the placeholder 1.0 elsewhere; NaN = not in the sphere), sdeds (de_ds of a kept
  * sample, 0 = not kept, NaN = not in the sphere).  cap = floats available in ssdf / sdeds (>= n_rays * num_depth_samples). */
 int dsp_batch_debug_samples(dsp_batch* b, int32_t obj, uint64_t* raymask, float* ssdf, float* sdeds, int64_t cap);
+/* The 71 x 71 (pose-only: 6 x 6) normal equations are solved in fp64 on the device: 0 = LDL^T with the right-hand side as an extra row +
+ * one back substitution (default, round 4: ~3x shorter), 1 = pivot-free Gauss-Jordan (rounds 2-3, kept as the A/B reference).  Both are
+ * exact to fp64 round-off on the symmetric positive definite H of optimizer.py:161-184; dx agrees to ~1e-12 relative. */
+int dsp_batch_set_solver(dsp_batch* b, int mode);
+/* HIP events around every decoder launch, i.e. the dsp_stats.ms_mlp_* fields: -1 = automatic (on for batches of more than 16 objects --
+ * the bench's roofline needs them; off for latency-sized batches, where an event record between two kernels is a queue packet of its own),
+ * 0 = off, 1 = on.  Launch COUNTS and ms_total are filled either way. */
+int dsp_batch_set_kernel_timing(dsp_batch* b, int mode);
+/* Forget what earlier guard trips on this handle have left behind (dsp_prepass_calibration_table: guard_err): the margins return to the
+ * decoder's calibration. */
+int dsp_prepass_reset_guard(dsp_handle* h);
 /* Record per-iteration traces during the following runs (testing; costs ~21 KB per object-iteration). */
 int dsp_batch_enable_trace(dsp_batch* b, int on);
 /* Per-iteration trace of the last run (testing): for iteration e < num_iterations and object i,

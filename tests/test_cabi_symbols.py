@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), "libdspgn.so does not export %s" % n
     bound = {n for n, _, _ in L.SYMBOLS}
     assert set(names) <= bound, "ctypes binding misses %s" % (set(names) - bound)
-    assert lib.dsp_abi_version() == 3    # 2: dsp_stats grew the prepass fields; 3: the guard fields
+    assert lib.dsp_abi_version() == 4    # 2: dsp_stats grew the prepass fields; 3: the guard fields; 4: solver / kernel-timing setters, partial guard re-run
 
 
 def test_gfx950_code_object_present():

@@ -73,7 +73,7 @@ def test_cfg2_full_size_first_iteration_vs_reference(eng, oracle_decoder):
                same_sets=sum(1 for p in per_iter if p["same_sets"]), flips=[p["flips"] for p in per_iter], rel_H=[p["rel_H"] for p in per_iter],
                rel_b=[p["rel_b"] for p in per_iter], oracle_jitter_rel_H=[p["oracle_jitter_rel_H"] for p in per_iter], K=[p["K"] for p in per_iter],
                first_iteration_vs_reference=dict(dK=int(dk), rel_H=float(np.abs(tr0["H"][0] - g["it_H"][0]).max() / np.abs(g["it_H"][0]).max())))
-    assert strict >= 1
+    assert strict == 3          # measured on MI355X (profiles/parity_r03.md): 3 of 3 strict
     b.close()
 
 
@@ -96,7 +96,7 @@ def test_cfg3_batch64_objects_vs_oracle(eng, oracle_decoder):
             out.append(dict(LAST_LINEARISATION, iteration=e, object=i, strict=strict))
     b.close()
     parity_log(kind="batch64", case="64 x cfg2 batch: objects 0 and 63, iterations 0 and 9 vs oracle", checks=out)
-    assert sum(1 for o in out if o["same_sets"]) >= 2
+    assert sum(1 for o in out if o["same_sets"]) == 4        # measured on MI355X: identical sets in 4 of 4 (profiles/parity_r03.md)
 
 
 def test_cfg3_batch64_deterministic_and_permutation_equivariant(eng):

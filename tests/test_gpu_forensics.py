@@ -135,7 +135,9 @@ def test_linearisation_at_reference_states(eng, name):
     _write_report(name, report)
     parity_log(kind="at_reference_states", case=name, n=n_it, strict=strict, rel_H=[r["rel_H"] for r in rows], rel_b=[r["rel_b"] for r in rows],
                rel_dx=[r["rel_dx"] for r in rows], flips=[r["flips"] for r in rows], K=[r["K"][1] for r in rows])
-    assert strict >= n_it - 2, "more than two iterations with (named) flips at the reference's own states: %d of %d strict" % (strict, n_it)
+    # measured on MI355X: strict in 45 of 45 recorded iterations (profiles/parity_r03.md); one named flip per run is the most a changed
+    # instruction schedule could plausibly add
+    assert strict >= n_it - 1, "more than one iteration with (named) flips at the reference's own states: %d of %d strict" % (strict, n_it)
 
 
 @pytest.mark.parametrize("name", CASES)

@@ -178,18 +178,18 @@ def compare_linearisation(tr, i, its, k4, tol_b=1e-4):
         assert flips == 0
         amp_h = np.abs(itj["H"] - it["H"]).max()
         amp_b = np.abs(itj["b"] - it["b"])[mask].max()
-        assert np.abs(tr["H"][i] - it["H"]).max() < 1e-4 * hs + 4 * amp_h
-        assert np.abs(tr["b"][i][mask] - it["b"][mask]).max() < tol_b * bs + 4 * amp_b
+        assert np.abs(tr["H"][i] - it["H"]).max() < 1e-4 * hs + 2 * amp_h
+        assert np.abs(tr["b"][i][mask] - it["b"][mask]).max() < tol_b * bs + 2 * amp_b
         # rotation-prior entries: k4 * J_rot * (1 + R_co[1,1]) is ulp-quantised in fp32 (see test_oracle_golden)
         j_rot = np.sqrt(np.abs(np.diag(it["H"])[3:6]) / max(k4, 1.0))
-        tol_rot = k4 * (j_rot + 1e-3) * 2.4e-7 + tol_b * bs + 4 * amp_b
+        tol_rot = k4 * (j_rot + 1e-3) * 2.4e-7 + tol_b * bs + 2 * amp_b
         assert np.all(np.abs(tr["b"][i][3:6] - it["b"][3:6]) <= tol_rot)
         # dx = H^-1 b: whatever difference is accepted on b (above) maps to |H^-1| tol_b on dx -- near convergence b, hence dx, is
         # a difference of large terms and a bound relative to |dx| alone would be ill-posed
-        tol_bv = np.full(it["b"].shape[0], tol_b * bs + 4 * amp_b)
+        tol_bv = np.full(it["b"].shape[0], tol_b * bs + 2 * amp_b)
         tol_bv[3:6] = np.maximum(tol_bv[3:6], tol_rot)
         tol_dx = np.abs(np.linalg.inv(it["H"].astype(np.float64))) @ tol_bv
-        assert np.all(np.abs(tr["dx"][i] - it["dx"]) <= 2e-4 * np.abs(it["dx"]).max() + 4 * np.abs(itj["dx"] - it["dx"]).max() + tol_dx)
+        assert np.all(np.abs(tr["dx"][i] - it["dx"]) <= 2e-4 * np.abs(it["dx"]).max() + 2 * np.abs(itj["dx"] - it["dx"]).max() + tol_dx)
         LAST_LINEARISATION.update(same_sets=True, flips=0, rel_H=float(np.abs(tr["H"][i] - it["H"]).max() / hs),
                                   rel_b=float(np.abs(tr["b"][i][mask] - it["b"][mask]).max() / bs), oracle_jitter_rel_H=float(amp_h / hs),
                                   V=int(it["V"]), K=int(it["K"]))
@@ -255,7 +255,7 @@ def _check_iterations(oracle_decoder, obj, traces, oprm, k4, name="", explain=No
                flips=[p["flips"] for p in per_iter], rel_H=[p["rel_H"] for p in per_iter], rel_b=[p["rel_b"] for p in per_iter],
                oracle_jitter_rel_H=[p["oracle_jitter_rel_H"] for p in per_iter], K=[p["K"] for p in per_iter], named_flips=named)
     n_same = sum(1 for p in per_iter if p["same_sets"])
-    assert n_same + len(named) == len(traces) and len(named) <= 2, "iterations whose sets differ from the oracle's: %s" % named
+    assert n_same + len(named) == len(traces) and len(named) <= 1, "iterations whose sets differ from the oracle's: %s" % named      # measured on MI355X: 0
 
 
 def test_reconstruct_small_each_iteration(eng, oracle_decoder):
