@@ -1319,6 +1319,16 @@ __device__ __forceinline__ double fast_recip(double d) {
     return r;
 }
 
+// last column held by register slot q of the LDL^T factorisation (elements 256 q .. 256 q + 255 of the packed lower triangle)
+__host__ __device__ constexpr int ldl_slot_last_col(int q) {
+    const int e_last = LDL_THREADS * q + LDL_THREADS - 1 < LDL_NP - 1 ? LDL_THREADS * q + LDL_THREADS - 1 : LDL_NP - 1;
+    int jl = 0;
+    for (int j = 0; j < NS1; ++j)
+        if (j * NS1 - j * (j - 1) / 2 <= e_last) jl = j;
+    return jl;
+}
+static_assert(ldl_slot_last_col(0) == 3 && ldl_slot_last_col(LDL_EPT - 1) == NS1 - 1, "packed column-major lower triangle");
+
 // SOLVER 0: LDL^T (round 4).  SOLVER 1: the round-2/3 pivot-free Gauss-Jordan, kept as the A/B reference (dsp_batch_set_solver).
 template <int SOLVER>
 __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, ObjState* st, const double* gsum, GnParamsDev prm, int iter,
@@ -1435,12 +1445,14 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
             s_sing = !(d0 > 0.0) ? 1 : 0;              // also NaN
         }
         double v[LDL_EPT];
-        int ei[LDL_EPT], ej[LDL_EPT];
+        int ej[LDL_EPT], oi[LDL_EPT], oj[LDL_EPT];     // column of the element (-1: not part of this system), LDS offsets of rows i and j
+        double* Af = &A[0][0];
+        constexpr int LDA = NS1 + 1;
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < LDL_EPT; ++q) {
             const int e = tid + LDL_THREADS * q;
-            ei[q] = 0; ej[q] = -1; v[q] = 0.0;
+            ej[q] = -1; oi[q] = 0; oj[q] = 0; v[q] = 0.0;
             if (tid < LDL_THREADS && e < LDL_NP) {
                 // packed column-major lower triangle: column j starts at j * NS1 - j (j - 1) / 2
                 int j = (int)((2 * NS1 + 1 - sqrtf((float)((2 * NS1 + 1) * (2 * NS1 + 1) - 8 * e))) * 0.5f);
@@ -1448,21 +1460,31 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
                 while (j > 0 && j * NS1 - j * (j - 1) / 2 > e) --j;
                 while ((j + 1) * NS1 - (j + 1) * j / 2 <= e) ++j;
                 const int i = j + (e - (j * NS1 - j * (j - 1) / 2));
-                if (i <= n && j <= n && !(i == n && j == n)) { ei[q] = i; ej[q] = j; v[q] = A[i][j]; }
+                if (i <= n && j <= n && !(i == n && j == n)) { ej[q] = j; oi[q] = i * LDA; oj[q] = j * LDA; v[q] = A[i][j]; }
             }
         }
         for (int k = 0; k < n; ++k) {
             __syncthreads();                              // column k and rdv[k] are published; every read of column k - 1 has retired
             if (tid < LDL_THREADS) {
                 const double rdk = rdv[k];
+                // every column entry this thread may need is read up front and unconditionally (always-valid addresses): as loads inside
+                // `if (ej[q] > k)` they were eleven serialised LDS round trips per step (116 k cycles for the 71 steps, first round-4
+                // profile) -- the lesson the Gauss-Jordan form had already recorded.  A register slot whose 256 elements all lie in
+                // columns <= k is finished for every thread: skipped by a workgroup-uniform test.
+                double cik[LDL_EPT], cjk[LDL_EPT];
+#pragma unroll
+                for (int q = 0; q < LDL_EPT; ++q) {
+                    const bool slot_live = k < ldl_slot_last_col(q);      // a constant per q once the loop is unrolled
+                    cik[q] = slot_live ? Af[oi[q] + k] : 0.0;
+                    cjk[q] = slot_live ? Af[oj[q] + k] : 0.0;
+                }
 #pragma unroll
                 for (int q = 0; q < LDL_EPT; ++q) {
                     if (ej[q] > k) {
-                        const double cik = A[ei[q]][k], cjk = A[ej[q]][k];
-                        v[q] = fma(-(cik * rdk), cjk, v[q]);
+                        v[q] = fma(-(cik[q] * rdk), cjk[q], v[q]);
                         if (ej[q] == k + 1) {             // final: publish (column k + 1 of the next step)
-                            A[ei[q]][k + 1] = v[q];
-                            if (ei[q] == k + 1) {
+                            Af[oi[q] + k + 1] = v[q];
+                            if (oi[q] == oj[q]) {         // the next pivot: its owner publishes the reciprocal with the column
                                 rdv[k + 1] = fast_recip(v[q]);
                                 if (!(v[q] > 0.0)) s_sing = 1;
                             }

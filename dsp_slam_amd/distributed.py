@@ -37,8 +37,9 @@ def pack_results(t_cam_obj, codes, loss, status):
     n = len(loss)
     out = np.zeros((n, RESULT_WIDTH), np.float32)
     out[:, :16] = np.asarray(t_cam_obj, np.float32).reshape(n, 16)
-    codes = np.asarray(codes, np.float32).reshape(n, -1)      # 32-D codes occupy the first 32 of the 64 slots
-    out[:, 16:16 + codes.shape[1]] = codes
+    if n:
+        codes = np.asarray(codes, np.float32).reshape(n, -1)      # 32-D codes occupy the first 32 of the 64 slots
+        out[:, 16:16 + codes.shape[1]] = codes
     out[:, 80] = loss
     out[:, 81] = np.asarray(status, np.float32)
     return out
