@@ -43,7 +43,7 @@ class Stats(C.Structure):
                 ("prepass_mode", C.c_int32), ("prepass_delta", C.c_float), ("prepass_max_err", C.c_float),
                 ("prepass_misclassified", C.c_double), ("prepass_audited", C.c_double),
                 ("prepass_guard_trips", C.c_double), ("prepass_guard_objects", C.c_double), ("prepass_guard_max_err", C.c_float),
-                ("prepass_guard_rerun", C.c_int32)]
+                ("prepass_guard_rerun", C.c_int32), ("n_cluster_tiles", C.c_double)]
 
 
 class DspError(RuntimeError):
@@ -95,6 +95,7 @@ SYMBOLS = [
     ("dsp_batch_debug_samples", C.c_int, [_VP, C.c_int32, C.POINTER(C.c_uint64), c_f32p, c_f32p, C.c_int64]),
     ("dsp_batch_set_split_rows", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_set_solver", C.c_int, [_VP, C.c_int]),
+    ("dsp_batch_set_cluster_tiles", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_set_kernel_timing", C.c_int, [_VP, C.c_int]),
     ("dsp_prepass_reset_guard", C.c_int, [_VP]),
     ("dsp_batch_enable_trace", C.c_int, [_VP, C.c_int]),

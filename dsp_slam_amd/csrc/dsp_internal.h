@@ -73,7 +73,19 @@ struct MlpArgs {
     int split_len_fwd[4];       //   ... of which the forward passes (a prefix of the wave's stream)
     unsigned long long* clk;    // optional: block 0 writes {clock64, wall_clock64} at entry and exit (effective shader clock)
     float* dbg;                 // development aid: [pass][wave][128][64] slab dump of tile 0 (nullptr = off)
+    // cluster form (mlp_cluster_kernel.hip): four workgroups per 16-point tile, layer rows split over their 16 waves
+    const float* wcluster;      //   the same chunks laid out per wave slot (two row tiles, two k-steps per 16-byte element; pack_decoder)
+    int cl_off[16];             //   first 4 KiB mini-chunk of wave slot u inside wcluster
+    int cl_len[16];             //   mini-chunks slot u consumes per tile (forward + backward)
+    float* cl_xbuf;             //   exchange buffers: [cluster][2][32 row tiles][64 lanes] float4
+    unsigned* cl_flags;         //   exchange counters: [cluster][16 wave slots]
+    unsigned* cl_err;           //   raised when a bounded spin ran out (the host discards the run)
+    double* cl_tiles_done;      //   optional: + the list's tile count when the cluster kernel takes it (dsp_stats.n_cluster_tiles)
+    unsigned cl_epoch_base;     //   counter value this launch starts from (the host advances it by CL_EPOCH_STRIDE per launch)
+    int cluster_max_tiles;      //   the cluster kernel runs lists of up to this many tiles ...
+    int split_min_tiles;        //   ... and the latency form (mlp_split_kernel<true>) lists of at least this many (0 = always)
 };
+constexpr int CL_EPOCH_STRIDE = 4096;      // exchanges a launch may count: 15 per tile and cluster
 
 
 // ---- low-precision prepass (mlp_lp_kernel.hip): f16 / bf16 MFMA forward used ONLY to classify ray samples ------------
@@ -181,6 +193,8 @@ hipError_t mlp_prepare_device();
 hipError_t launch_mlp(int mode, const MlpArgs& args, int n_blocks, hipStream_t stream);   // mode: see mlp_kernel
 hipError_t mlp_split_prepare_device();
 hipError_t launch_mlp_split(bool bwd, const MlpArgs& args, int n_blocks, hipStream_t stream);   // 16-point tiles; forward (+ backward)
+hipError_t mlp_cluster_prepare_device();
+hipError_t launch_mlp_cluster(const MlpArgs& args, int n_clusters, hipStream_t stream);   // 16-point tiles, four workgroups each; grid = 4 x n_clusters (n_clusters a multiple of 8), all resident
 hipError_t mlp_lp_prepare_device();
 hipError_t launch_mlp_lp(bool bf16, const LpArgs& args, int n_blocks, hipStream_t stream);   // 128-point tiles, forward only
 // run_mask (optional, B bytes): objects with a zero byte are left out of the run (status DSP_STATUS_SKIP, state and result row untouched);

@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256, 1) void mlp_split_kernel(const MlpArgs a) {
 
     const int n_tiles = *a.n_tiles;
     if ((int)blockIdx.x >= n_tiles) return;
+    if (BWD && n_tiles < a.split_min_tiles) return;      // a list this short is the cluster kernel's (mlp_cluster_kernel.hip): both are launched
     for (int i = tid; i < a.n_bias_rows * WIDTH; i += 256) bias_l[i] = a.bias_tab[i];
     __syncthreads();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

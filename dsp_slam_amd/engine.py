@@ -140,6 +140,10 @@ class Batch(object):
         """0 = LDL^T (default), 1 = pivot-free Gauss-Jordan (the round-2/3 kernel, kept as the A/B reference)."""
         L.check(L.load().dsp_batch_set_solver(self._h, int(mode)), self.engine._h, "dsp_batch_set_solver")
 
+    def set_cluster_tiles(self, mode):
+        """-1 = automatic, 0 = one workgroup per 16-point jacobian tile, 1 = four (cluster form) for lists of up to 128 tiles."""
+        L.check(L.load().dsp_batch_set_cluster_tiles(self._h, int(mode)), self.engine._h, "dsp_batch_set_cluster_tiles")
+
     def set_kernel_timing(self, mode):
         """HIP events around every decoder launch (stats ms_mlp_*): -1 = automatic (batches of more than 16 objects), 0 = off, 1 = on."""
         L.check(L.load().dsp_batch_set_kernel_timing(self._h, int(mode)), self.engine._h, "dsp_batch_set_kernel_timing")

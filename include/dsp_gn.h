@@ -95,6 +95,7 @@ typedef struct dsp_stats {
     double prepass_guard_objects;/* objects with at least one trip */
     float prepass_guard_max_err; /* largest |sdf_lp - sdf_fp32| over the compared samples */
     int32_t prepass_guard_rerun; /* 1: the guard tripped; the objects it tripped on were run again with the prepass off (their results come from that run) */
+    double n_cluster_tiles;      /* (ABI version 4) 16-point jacobian tiles that ran in the cluster form: four workgroups per tile (dsp_batch_set_cluster_tiles) */
 } dsp_stats;
 
 /* ---- lifetime --------------------------------------------------------------------------------- */
@@ -279,6 +280,11 @@ int dsp_batch_set_depth_schedule(dsp_batch* b, const float* depths, int32_t n_it
  * scan read: fp32 inside the band, the prepass value or the placeholder 1.0 elsewhere; NaN = not in the sphere), sdeds (de_ds of a kept
  * sample, 0 = not kept, NaN = not in the sphere).  cap = floats available in ssdf / sdeds (>= n_rays * num_depth_samples). */
 int dsp_batch_debug_samples(dsp_batch* b, int32_t obj, uint64_t* raymask, float* ssdf, float* sdeds, int64_t cap);
+/* Latency form of the jacobian launch, one step further: a list of at most 128 tiles of 16 points (a detection of SLAM's real size has
+ * 40-60) runs with FOUR workgroups per tile -- the rows of every layer split over their 16 waves, the layer's result handed round the
+ * cluster through L2 after every pass -- so that a detection occupies ~240 CUs instead of ~60.  Longer lists keep one workgroup per tile.
+ * -1 = automatic (on wherever the latency form is), 0 = off, 1 = on where applicable.  Results are identical for every setting. */
+int dsp_batch_set_cluster_tiles(dsp_batch* b, int mode);
 /* The 71 x 71 (pose-only: 6 x 6) normal equations are solved in fp64 on the device: 0 = LDL^T with the right-hand side as an extra row +
  * one back substitution (default, round 4: ~3x shorter), 1 = pivot-free Gauss-Jordan (rounds 2-3, kept as the A/B reference).  Both are
  * exact to fp64 round-off on the symmetric positive definite H of optimizer.py:161-184; dx agrees to ~1e-12 relative. */

@@ -272,3 +272,47 @@ def test_kernel_timing_switch(eng):
         assert np.array_equal(x, y)
     assert out[0][1]["n_mlp_jac_launches"] == out[1][1]["n_mlp_jac_launches"] > 0
     assert out[0][1]["ms_mlp_jac"] == 0.0 and out[1][1]["ms_mlp_jac"] > 0.0 and out[0][1]["ms_total"] > 0.0
+
+
+def test_cluster_kernel_is_exact(eng, chairs32_decoder):
+    """The cluster form of the jacobian launch (four workgroups per 16-point tile, layer rows split over their 16 waves, hand-off through
+    L2 after every pass) against the latency form it replaces for detection-sized lists: every bit of every iteration -- with the prepass
+    (speculative band rows: sdf scattered back, guard comparisons) and without (surface points + kept render rows), on the 64-D and on
+    the 32-D decoder (skip rows at other tiles), repeated runs (the exchange counters advance from launch to launch), and a list too
+    long for it (three detections: > 128 tiles), which must take the latency form."""
+    n_it = 4
+    prm = E.gn_params(num_iterations=n_it)
+    det = synth.make_object(4242, n_surface=250, n_background=200)
+    for prepass in (1, 0):
+        off = _run_traced(eng, prm, [det], n_it, prepass=prepass, cluster_tiles=0)
+        on = _run_traced(eng, prm, [det], n_it, prepass=prepass, cluster_tiles=1)
+        _assert_same_bits(off, on, np.array([0]), "cluster vs latency form, prepass %d" % prepass)
+        assert off[2]["n_cluster_tiles"] == 0 and on[2]["n_cluster_tiles"] > 0, (off[2]["n_cluster_tiles"], on[2]["n_cluster_tiles"])
+        assert on[2]["n_jac_points"] == off[2]["n_jac_points"]
+        again = _run_traced(eng, prm, [det], n_it, prepass=prepass, cluster_tiles=1)
+        _assert_same_bits(on, again, np.array([0]), "cluster form, repeated")
+    # a resident batch run several times: counters keep advancing, bits stay
+    b = eng.batch(prm, *_args([det]))
+    b.run()
+    first = b.results()
+    for _ in range(5):
+        b.run()
+        for x, y in zip(first, b.results()):
+            assert np.array_equal(x, y)
+    assert b.stats()["n_cluster_tiles"] > 0          # the automatic choice for one detection
+    b.close()
+    # three detections at once: the list is too long for two rounds of clusters -> one workgroup per tile, same bits as ever
+    objs = synth.make_batch(3, first_seed=2400, n_surface=800, n_background=300)
+    off = _run_traced(eng, prm, objs, n_it, cluster_tiles=0, split_rows=1, mask_reuse=0)
+    on = _run_traced(eng, prm, objs, n_it, cluster_tiles=1, split_rows=1, mask_reuse=0)
+    _assert_same_bits(off, on, np.arange(3), "long list")
+    assert on[2]["n_cluster_tiles"] == 0
+    # the 32-D decoder: xyz re-enters at tile 29, code gradient rows at tiles 30, 31
+    e32 = E.Engine(chairs32_decoder.layers, chairs32_decoder.latent_in, chairs32_decoder.code_len, device=0)
+    o32 = synth.make_object(21, n_surface=220, n_background=60, code_len=32, half=synth.CHAIR_HALF)
+    p32 = E.gn_params(k1=10.0, k2=100.0, k3=2.5, k4=0.0, b1=0.2, b2=0.02, lr=1.0, s_damp=100.0, num_iterations=n_it)
+    off = _run_traced(e32, p32, [o32], n_it, cluster_tiles=0)
+    on = _run_traced(e32, p32, [o32], n_it, cluster_tiles=1)
+    e32.close()
+    _assert_same_bits(off, on, np.array([0]), "32-D decoder")
+    assert on[2]["n_cluster_tiles"] > 0

@@ -88,6 +88,44 @@ def test_split_stream_layout(packed):
     assert ln[0] > ln[1] == ln[2] > ln[3]
 
 
+def test_cluster_stream_layout(packed):
+    """Cluster-form kernel (mlp_cluster_kernel.hip): wave slot u of the 16 in a cluster streams row tiles 2u, 2u + 1 of every pass whose
+    output group u / 2 exists, as k-step PAIRS: lane element = {tile 0 @ k-step 2p, tile 1 @ 2p, tile 0 @ 2p + 1, tile 1 @ 2p + 1}.  Checked
+    against the throughput stream (itself pinned by the emulated forward / jacobian above): same A operands, every one exactly once."""
+    import ctypes as C
+    from dsp_slam_amd import _lib as L
+    dec, pk = packed
+    lib = L.load()
+    lib.dsp_debug_cluster_stream.restype = C.c_int
+    lib.dsp_debug_cluster_stream.argtypes = [C.c_void_p, L.c_i32p, L.c_f32p, L.c_i64p]
+    layout = np.zeros(32, np.int32)
+    n = C.c_int64(0)
+    L.check(lib.dsp_debug_cluster_stream(C.byref(pk["_holder"].desc), L.ptr(layout, L.c_i32p), None, C.byref(n)), None, "cluster(size)")
+    assert n.value == pk["stream"].size
+    cs = np.zeros(n.value, np.float32)
+    L.check(lib.dsp_debug_cluster_stream(C.byref(pk["_holder"].desc), L.ptr(layout, L.c_i32p), L.ptr(cs), C.byref(n)), None, "cluster")
+    off, ln = layout[:16], layout[16:]
+    minis = cs.reshape(-1, 4, 64, 4)                     # [mini-chunk][pair in mini][lane][element]
+    assert off[0] == 0 and all(off[u + 1] == off[u] + ln[u] for u in range(15)) and off[15] + ln[15] == minis.shape[0]
+    p = pk["passes"]
+    for u in range(16):
+        og, half = u >> 1, u & 1
+        pos = int(off[u])
+        for ps in range(pk["n_pass"]):
+            nog, nchunks, chunk_base = int(p[ps, 0]), int(p[ps, 1]), int(p[ps, 6])
+            if og >= nog:
+                continue
+            for c in range(nchunks):
+                ch = pk["stream"][chunk_base + og * nchunks + c]          # [k-step 16][lane 64][tile-in-group 4]
+                got = minis[pos:pos + 2].reshape(8, 64, 4)                 # 8 pairs
+                pos += 2
+                for e in range(4):
+                    assert np.array_equal(got[:, :, e], ch[(e >> 1)::2, :, 2 * half + (e & 1)]), (u, ps, c, e)
+        assert pos == off[u] + ln[u]
+    # slots 0 and 1 also carry the first layer's backward pass (one output group); the two top groups skip the 445/448-row passes
+    assert ln[0] == ln[1] > ln[2] == ln[13] > ln[14] == ln[15]
+
+
 def _specs(code_len=64, width=512):
     import copy
     sp = copy.deepcopy(fixtures.SPECS)

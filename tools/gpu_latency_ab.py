@@ -31,12 +31,13 @@ for name, (M, Bg) in (("KITTI-size 250+200", (250, 200)), ("cfg2-size 2000+500",
     o = synth.make_object(4242 if M == 250 else 1, n_surface=M, n_background=Bg)
     args = ([o["t_cam_obj_init"]], [o["pts"]], [o["rays"]], [o["depth"]])
     print("## %s" % name)
-    variants = [("automatic (wave bookkeeping, LDL^T, no per-kernel events)", {}),
+    variants = [("automatic (cluster tiles, wave bookkeeping, LDL^T, no per-kernel events)", {}),
+                ("one workgroup per jacobian tile (cluster form off)", dict(cluster_tiles=0)),
                 ("fused per-object bookkeeping (round 3)", dict(fused_bookkeeping=1)),
                 ("throughput bookkeeping", dict(fused_bookkeeping=0)),
                 ("Gauss-Jordan solve (round 3)", dict(solver=1)),
                 ("per-kernel events on", dict(kernel_timing=1)),
-                ("round-3 equivalent: fused=1 (or 0 for large), GJ, events on", dict(fused_bookkeeping=1 if M == 250 else 0, solver=1, kernel_timing=1)),
+                ("round-3 equivalent: fused=1 (or 0 for large), GJ, events on, no clusters", dict(fused_bookkeeping=1 if M == 250 else 0, solver=1, kernel_timing=1, cluster_tiles=0)),
                 ("prepass off", dict(prepass=0))]
     ref = None
     for label, kw in variants:
@@ -53,8 +54,8 @@ for name, (M, Bg) in (("KITTI-size 250+200", (250, 200)), ("cfg2-size 2000+500",
         if ref is None:
             ref = res
         same = all(np.array_equal(x, y) for x, y in zip(res, ref))
-        print("%-70s p50 %7.3f ms  min %7.3f  device %7.3f ms  launches fwd/jac/lp %d/%d/%d  bits==auto %s" % (
-            label, med, mn, st["ms_total"], st["n_mlp_fwd_launches"], st["n_mlp_jac_launches"], st["n_mlp_prepass_launches"], same), flush=True)
+        print("%-78s p50 %7.3f ms  min %7.3f  device %7.3f ms  launches fwd/jac/lp %d/%d/%d  cluster tiles %d  bits==auto %s" % (
+            label, med, mn, st["ms_total"], st["n_mlp_fwd_launches"], st["n_mlp_jac_launches"], st["n_mlp_prepass_launches"], st["n_cluster_tiles"], same), flush=True)
         b.close()
     med, mn = p50(lambda: eng.reconstruct_batch(prm, *args))
     print("%-70s p50 %7.3f ms  min %7.3f" % ("one-shot dsp_reconstruct_batch (host buffers in, results out)", med, mn), flush=True)
