@@ -82,6 +82,7 @@ struct MlpArgs {
     unsigned* cl_err;           //   raised when a bounded spin ran out (the host discards the run)
     double* cl_tiles_done;      //   optional: + the list's tile count when the cluster kernel takes it (dsp_stats.n_cluster_tiles)
     unsigned cl_epoch_base;     //   counter value this launch starts from (the host advances it by CL_EPOCH_STRIDE per launch)
+    int cl_fault;               //   fault injection (tests): workgroup 3 of every cluster never raises its counters -> its siblings' bounded spins run out
     int cluster_max_tiles;      //   the cluster kernel runs lists of up to this many tiles ...
     int split_min_tiles;        //   ... and the latency form (mlp_split_kernel<true>) lists of at least this many (0 = always)
 };

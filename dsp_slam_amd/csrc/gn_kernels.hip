@@ -1344,7 +1344,7 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const ObjState* st, const f
 
 constexpr int SOLVE_THREADS = 1024;   // 16 waves: assembly, trace and the code bias use all of them; the factorisation four (LDL^T) or all (Gauss-Jordan)
 constexpr int NS1 = NSOLVE + 1;       // rows of the augmented system: the unknowns + the right-hand side as row n
-constexpr int LDL_THREADS = 256, LDL_NP = NS1 * (NS1 + 1) / 2, LDL_EPT = (LDL_NP + LDL_THREADS - 1) / LDL_THREADS;   // 2628 packed elements, 11 per thread
+constexpr int LDL_THREADS = 512, LDL_NP = NS1 * (NS1 + 1) / 2, LDL_EPT = (LDL_NP + LDL_THREADS - 1) / LDL_THREADS;   // 2628 packed elements, 6 per thread of eight waves
 
 // 1 / d to full double precision without the IEEE division sequence (it sits on the factorisation's critical path, once per pivot):
 // v_rcp_f64 (>= 25 bits) + two Newton steps
@@ -1354,16 +1354,6 @@ __device__ __forceinline__ double fast_recip(double d) {
     r = fma(r, fma(-d, r, 1.0), r);
     return r;
 }
-
-// last column held by register slot q of the LDL^T factorisation (elements 256 q .. 256 q + 255 of the packed lower triangle)
-__host__ __device__ constexpr int ldl_slot_last_col(int q) {
-    const int e_last = LDL_THREADS * q + LDL_THREADS - 1 < LDL_NP - 1 ? LDL_THREADS * q + LDL_THREADS - 1 : LDL_NP - 1;
-    int jl = 0;
-    for (int j = 0; j < NS1; ++j)
-        if (j * NS1 - j * (j - 1) / 2 <= e_last) jl = j;
-    return jl;
-}
-static_assert(ldl_slot_last_col(0) == 3 && ldl_slot_last_col(LDL_EPT - 1) == NS1 - 1, "packed column-major lower triangle");
 
 // SOLVER 0: LDL^T (round 4).  SOLVER 1: the round-2/3 pivot-free Gauss-Jordan, kept as the A/B reference (dsp_batch_set_solver).
 template <int SOLVER>
@@ -1467,11 +1457,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
         //    right-hand side rides along as row n of the augmented matrix [[H, b], [b^T, .]]: after the n elimination steps row n holds
         //    z = L^-1 b, and dx follows from L^T dx = D^-1 z.
         //    Right-looking, one step per pivot: a_ij -= c_ik c_jk / d_k with UNSCALED columns c_ik = l_ik d_k.  The lower triangle (2628
-        //    elements of the 72 x 72 augmented matrix, packed column-major) lives in the REGISTERS of four waves, 11 elements per thread;
+        //    elements of the 72 x 72 augmented matrix, packed column-major) lives in the REGISTERS of eight waves, 6 elements per thread;
         //    an element is final after step j - 1 and is published then, once, to its own LDS cell A[i][j] -- so step k reads column k
         //    that step k - 1 wrote, writes column k + 1, and ONE barrier per step orders both.  The pivot's reciprocal is published by the
-        //    diagonal's owner with the column.  ~250 cycles per step against ~1800 for the Gauss-Jordan form (16 waves, an fp64 division
-        //    per thread and step): 74 -> ~25 us per k_solve at n = 71 (profiles/r04_latency_kernel_stats.md).
+        //    diagonal's owner with the column.  (profiles/r04_latency_kernel_stats.md for what it costs.)
         __shared__ double rdv[NS1];
         __shared__ int s_sing;
         if (tid < n) A[n][tid] = A[tid][n];           // b as row n
@@ -1499,32 +1488,37 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
                 if (i <= n && j <= n && !(i == n && j == n)) { ej[q] = j; oi[q] = i * LDA; oj[q] = j * LDA; v[q] = A[i][j]; }
             }
         }
+        // ONE compact loop body, executed n times: k_solve runs once per object and iteration with a cold instruction cache, and the
+        // first two forms of this loop (eleven branchy blocks; then nine unswitched copies of a 380-instruction body) spent their time
+        // FETCHING code -- 48 and 58 us for the 71 steps, ~1800 cycles each, like the Gauss-Jordan form whose notes say the same.  So:
+        // no per-slot liveness tests (every thread reads its 12 column entries every step, always-valid addresses, all in flight at once:
+        // six elements per thread keep them within the 128 registers a 1024-thread workgroup allows), selects instead of branches, and one
+        // publication block per step (a column has <= 72 consecutive packed elements: at most one per thread).
+#pragma unroll 1
         for (int k = 0; k < n; ++k) {
             __syncthreads();                              // column k and rdv[k] are published; every read of column k - 1 has retired
             if (tid < LDL_THREADS) {
                 const double rdk = rdv[k];
-                // every column entry this thread may need is read up front and unconditionally (always-valid addresses): as loads inside
-                // `if (ej[q] > k)` they were eleven serialised LDS round trips per step (116 k cycles for the 71 steps, first round-4
-                // profile) -- the lesson the Gauss-Jordan form had already recorded.  A register slot whose 256 elements all lie in
-                // columns <= k is finished for every thread: skipped by a workgroup-uniform test.
                 double cik[LDL_EPT], cjk[LDL_EPT];
 #pragma unroll
-                for (int q = 0; q < LDL_EPT; ++q) {
-                    const bool slot_live = k < ldl_slot_last_col(q);      // a constant per q once the loop is unrolled
-                    cik[q] = slot_live ? Af[oi[q] + k] : 0.0;
-                    cjk[q] = slot_live ? Af[oj[q] + k] : 0.0;
-                }
+                for (int q = 0; q < LDL_EPT; ++q) { cik[q] = Af[oi[q] + k]; cjk[q] = Af[oj[q] + k]; }
+                double pv = 0.0;
+                int po = -1;
+                bool pdiag = false;
 #pragma unroll
                 for (int q = 0; q < LDL_EPT; ++q) {
-                    if (ej[q] > k) {
-                        v[q] = fma(-(cik[q] * rdk), cjk[q], v[q]);
-                        if (ej[q] == k + 1) {             // final: publish (column k + 1 of the next step)
-                            Af[oi[q] + k + 1] = v[q];
-                            if (oi[q] == oj[q]) {         // the next pivot: its owner publishes the reciprocal with the column
-                                rdv[k + 1] = fast_recip(v[q]);
-                                if (!(v[q] > 0.0)) s_sing = 1;
-                            }
-                        }
+                    const double nv = fma(-(cik[q] * rdk), cjk[q], v[q]);
+                    v[q] = ej[q] > k ? nv : v[q];
+                    const bool pub = ej[q] == k + 1;      // final after this step: column k + 1 of the next one
+                    pv = pub ? v[q] : pv;
+                    po = pub ? oi[q] : po;
+                    pdiag = pub ? (oi[q] == oj[q]) : pdiag;
+                }
+                if (po >= 0) {
+                    Af[po + k + 1] = pv;
+                    if (pdiag) {                          // the next pivot: its owner publishes the reciprocal with the column
+                        rdv[k + 1] = fast_recip(pv);
+                        if (!(pv > 0.0)) s_sing = 1;
                     }
                 }
             }

@@ -34,7 +34,7 @@ constexpr int CL_MINI = 4096;                               // 4 k-step pairs x 
 constexpr int CL_MASK_BYTES = MASK_SLOTS * 256 * 2;         // [slot][tid] u16: 2 tiles x 4 rows = 8 bits used
 constexpr int CL_XCH_BYTES = 32 * 64 * 16;                  // one layer's output slab: 32 row tiles x 64 lanes x float4
 constexpr int CL_RING_BYTES = 4 * CL_SNB * CL_MINI;
-constexpr unsigned CL_SPIN_LIMIT = 1u << 22;                // ~1 s of polling: far beyond any healthy wait
+constexpr unsigned CL_SPIN_LIMIT = 1u << 20;                // ~1 s of polling (one L2 round trip + s_sleep per poll): far beyond any healthy wait
 
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256, 1) void mlp_cluster_kernel(const MlpArgs a) {
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, pub[1]), xrs, par + ((2 * u + 1) * 64 + lane) * 16, 0, 16);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the payload has left this CU (and the weight ring is drained: stores and LDS-DMA share the counter)
-        if (lane == 0) __hip_atomic_store(flags + u, ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0 && !(a.cl_fault && rank == 3)) __hip_atomic_store(flags + u, ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (wave < 3) {                                    // this wave relays ONE remote workgroup's tiles into LDS
             const int r = (rank + 1 + wave) & 3;
             if (!dead) {

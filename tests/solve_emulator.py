@@ -1,5 +1,5 @@
 """CPU emulation of k_solve<0> (gn_kernels.hip): the LDL^T factorisation of the augmented normal equations with the lower triangle held
-as packed, column-major elements in the registers of 256 threads, one LDS publication per element, and the back substitution by one
+as packed, column-major elements in the registers of 512 threads, one LDS publication per element, and the back substitution by one
 wave.  Test infrastructure: it follows the kernel's data flow statement by statement (same packing formula, same publication rule, same
 lane assignment in the back substitution), so that the algorithm -- index mapping, which step may read what, the b-as-row-n trick -- is
 checked on the CPU (tests/test_solve_emulation.py); the GPU tests then compare the kernel itself with the Gauss-Jordan kernel and the
@@ -8,7 +8,7 @@ import numpy as np
 
 NSOLVE = 71
 NS1 = NSOLVE + 1
-LDL_THREADS = 256
+LDL_THREADS = 512
 LDL_NP = NS1 * (NS1 + 1) // 2
 LDL_EPT = (LDL_NP + LDL_THREADS - 1) // LDL_THREADS
 

@@ -316,3 +316,37 @@ def test_cluster_kernel_is_exact(eng, chairs32_decoder):
     e32.close()
     _assert_same_bits(off, on, np.array([0]), "32-D decoder")
     assert on[2]["n_cluster_tiles"] > 0
+
+
+def test_cluster_fallback_on_a_lost_hand_off(eng):
+    """Every spin of the cluster kernel is bounded.  With one workgroup's exchange counters suppressed (test hook) its siblings give up
+    after ~1 s, raise the error word and keep going; the library discards that run, repeats it with one workgroup per tile and keeps the
+    cluster form off for the batch -- the caller gets the correct bits, late, never a hang or a wrong result."""
+    import ctypes as C
+    import time
+    from dsp_slam_amd import _lib as L
+    lib = L.load()
+    lib.dsp_debug_cluster_fault.restype = C.c_int
+    lib.dsp_debug_cluster_fault.argtypes = [C.c_void_p, C.c_int]
+    prm = E.gn_params(num_iterations=2)
+    det = synth.make_object(4242, n_surface=250, n_background=200)
+    b = eng.batch(prm, *_args([det]))
+    b.run()
+    want = b.results()
+    assert b.stats()["n_cluster_tiles"] > 0
+    assert lib.dsp_debug_cluster_fault(b._h, 1) == 0
+    t0 = time.perf_counter()
+    b.run()
+    dt = time.perf_counter() - t0
+    got, st = b.results(), b.stats()
+    for x, y in zip(got, want):
+        assert np.array_equal(x, y)
+    assert st["n_cluster_tiles"] == 0                     # the results come from the repeated run, latency form
+    assert lib.dsp_debug_cluster_fault(b._h, 0) == 1      # one fallback so far
+    assert dt < 30.0, dt
+    b.run()                                               # the cluster form stays off for this batch
+    assert b.stats()["n_cluster_tiles"] == 0
+    for x, y in zip(b.results(), want):
+        assert np.array_equal(x, y)
+    b.close()
+    print("fallback after a lost hand-off: %.2f s" % dt)

@@ -14,7 +14,7 @@ def test_packed_index_mapping_is_a_bijection_on_the_lower_triangle():
         assert 0 <= j <= i < S.NS1
         assert e == j * S.NS1 - j * (j - 1) // 2 + (i - j)
         seen.add((i, j))
-    assert len(seen) == S.LDL_NP == 2628 and S.LDL_EPT == 11
+    assert len(seen) == S.LDL_NP == 2628 and S.LDL_EPT == 6
 
 
 @pytest.mark.parametrize("name", ["golden_recon_cfg2.npz", "golden_recon_cfg5.npz", "golden_recon_small.npz"])
