@@ -4,7 +4,7 @@
 bench.py times oracle/torch_baseline.py on the GPU box (no checkout of the reference there).  This script times the SAME cfg2
 object through (a) the unmodified reference, reconstruct/optimizer.py via oracle/ref_shim.py, decoder parameters left requiring
 grad as deep_sdf/workspace.py:213-221 leaves them, and (b) oracle/torch_baseline.py, alternating, and writes the ratio to
-profiles/r03_cpu_baseline_calibration.md + profiles/cpu_baseline_calibration.json (read by bench.py for `calibrated_vs_reference`).
+profiles/r04_cpu_baseline_calibration.md + profiles/cpu_baseline_calibration.json (read by bench.py for `calibrated_vs_reference`).
 Also checks that the two agree on the result (same algorithm: differences are round-off of identical torch ops => bit-identical
 unless thread scheduling differs).
 
@@ -79,8 +79,8 @@ def main():
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     with open(os.path.join(ROOT, "profiles", "cpu_baseline_calibration.json"), "w") as f:
         json.dump(rec, f, indent=1)
-    with open(os.path.join(ROOT, "profiles", "r03_cpu_baseline_calibration.md"), "w") as f:
-        f.write("# CPU baseline calibration (round 3)\n\n`python tools/calibrate_cpu_baseline.py` in the build container (%d host threads, torch %s).\n\n" % (ncpu, torch.__version__))
+    with open(os.path.join(ROOT, "profiles", "r04_cpu_baseline_calibration.md"), "w") as f:
+        f.write("# CPU baseline calibration (round 4: five alternating repetitions)\n\n`python tools/calibrate_cpu_baseline.py` in the build container (%d host threads, torch %s).\n\n" % (ncpu, torch.__version__))
         f.write("One cfg2 object, all 10 Gauss-Newton iterations, alternating runs:\n\n| implementation | runs (s) | median (s) |\n|---|---|---|\n")
         f.write("| unmodified reference (`reconstruct/optimizer.py` via `oracle/ref_shim.py`, parameters requiring grad) | %s | %.3f |\n" % (
             ", ".join("%.2f" % x for x in t_ref), m_ref))

@@ -2,7 +2,7 @@
 # Round 4, GPU call 2: cluster kernel + new solve + gram; latency A/B + rocprof; bench; whole GPU suite.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/r04b
+OUT=$R/gpurun_out/${1:-r04b}
 mkdir -p $OUT
 cd $R
 timeout 900 python -m pytest tests/test_gpu_round4.py tests/test_gpu_bench_objects.py --maxfail=12 -q -m gpu > $OUT/new_tests.log 2>&1; echo "new tests rc=$?"
