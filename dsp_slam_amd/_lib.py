@@ -96,6 +96,7 @@ SYMBOLS = [
     ("dsp_batch_set_split_rows", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_set_solver", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_set_cluster_tiles", C.c_int, [_VP, C.c_int]),
+    ("dsp_batch_set_mixed_reuse", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_set_kernel_timing", C.c_int, [_VP, C.c_int]),
     ("dsp_prepass_reset_guard", C.c_int, [_VP]),
     ("dsp_batch_enable_trace", C.c_int, [_VP, C.c_int]),

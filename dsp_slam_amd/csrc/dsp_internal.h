@@ -67,6 +67,7 @@ struct MlpArgs {
     int guard_stride;
     float* sdf_scatter;         // BWD, optional: tiles from *scatter_tile_begin on also store their sdf at sdf_scatter[int(pt.w)] (speculative band rows)
     const int* scatter_tile_begin;
+    const int* bwd_only_tile_begin;   // latency form, mixed launch: tiles from *this on run the backward sweep only, from exported masks (mlp_split_kernel<2>); nullptr = none
     const float* wsplit;        // latency form (mlp_split_kernel): the same chunks laid out per wave (see pack_decoder)
     int split_off[4];           //   first chunk of wave w's stream inside wsplit
     int split_len[4];           //   chunks wave w consumes per tile (forward + backward)
@@ -193,7 +194,7 @@ void launch_code_bias(const float* codew, const float* b0, const float* blat, co
 hipError_t mlp_prepare_device();
 hipError_t launch_mlp(int mode, const MlpArgs& args, int n_blocks, hipStream_t stream);   // mode: see mlp_kernel
 hipError_t mlp_split_prepare_device();
-hipError_t launch_mlp_split(bool bwd, const MlpArgs& args, int n_blocks, hipStream_t stream);   // 16-point tiles; forward (+ backward)
+hipError_t launch_mlp_split(int mode, const MlpArgs& args, int n_blocks, hipStream_t stream);   // 16-point tiles; mode 0 forward, 1 forward + mask export, 2 forward + backward (+ backward-only tiles)
 hipError_t mlp_cluster_prepare_device();
 hipError_t launch_mlp_cluster(const MlpArgs& args, int n_clusters, hipStream_t stream);   // 16-point tiles, four workgroups each; grid = 4 x n_clusters (n_clusters a multiple of 8), all resident
 hipError_t mlp_lp_prepare_device();

@@ -14,8 +14,15 @@
 // weight stream out per wave (`wsplit`: for each pass, the chunks of the wave's two output groups in consumption order),
 // so the stream position is a single wrapping pointer per wave.
 //
-// Replaces get_batch_sdf_jacobian (reconstruct/loss_utils.py:82-103) and, as mlp_split_kernel<false>, decode_sdf
+// Replaces get_batch_sdf_jacobian (reconstruct/loss_utils.py:82-103) and, as mlp_split_kernel<0 / 1>, decode_sdf
 // (loss_utils.py:51-79) for latency-sized batches.
+//
+// MODE 0: forward only.  MODE 1: forward, and the relu masks of samples with |sdf| < th are exported (mlp_kernel<1>'s layout) -- the tail
+// tiles / small lists of a mask-exporting forward launch.  MODE 2: forward + backward; and, from tile *bwd_only_tile_begin on, BACKWARD
+// ONLY from the masks and sdf a MODE 1 launch exported (round 4, "mixed" launch): the kept render rows skip their second forward sweep
+// in the SAME launch as the surface points' forward + backward tiles, so the two kinds share the rounds over the CUs.  A wave's weight
+// stream is [forward passes | backward passes]; a backward-only tile consumes the second part only, so where the stream wraps to is
+// decided by the kind of the workgroup's NEXT tile (known at tile start; the prefetch wraps four mini-chunks before the tile ends).
 #include "dsp_internal.h"
 #include "mlp_common.h"
 
@@ -27,10 +34,11 @@ constexpr int SPLIT_MASK_BYTES = MASK_SLOTS * 2 * 256 * 2;  // [slot][own group 
 constexpr int XCH_BYTES = 32 * 64 * 16;                     // one layer's output slab: 32 row tiles x 64 lanes x float4
 constexpr int SPLIT_RING_BYTES = 4 * SNB * MINI_BYTES;      // 80 KiB
 
-// BWD = false: forward only (decode_sdf, reconstruct/loss_utils.py:51-79) -- the same tile shape for the ray-sample passes of a
-// latency-sized batch; it consumes the forward prefix of each wave's stream and needs no masks.
-template <bool BWD>
+// MODE < 2 consumes the forward prefix of each wave's stream.
+template <int MODE>
 __global__ __launch_bounds__(256, 1) void mlp_split_kernel(const MlpArgs a) {
+    constexpr bool BWD = MODE == 2;
+    constexpr bool MASKS = MODE != 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -54,13 +62,17 @@ __global__ __launch_bounds__(256, 1) void mlp_split_kernel(const MlpArgs a) {
 
     // ---- this wave's weight stream (wave-uniform state) -----------------------------------------------------------------
     const int total_minis = (BWD ? a.split_len[wave] : a.split_len_fwd[wave]) * (CHUNK_BYTES / MINI_BYTES);
+    const int fwd_minis = a.split_len_fwd[wave] * (CHUNK_BYTES / MINI_BYTES);
     const char* wbase = reinterpret_cast<const char*>(a.wsplit) + (size_t)a.split_off[wave] * CHUNK_BYTES;   // wave-uniform
     const unsigned lane_off = lane * 16;
-    int issue_pos = 0, issue_slot = 0, rd_slot = 0;
-    const char* isrc = wbase;
+    // mixed launch: tiles from bo_begin on run the backward sweep only; the stream then starts (and wraps to) the backward part
+    const int bo_begin = (BWD && a.bwd_only_tile_begin) ? *a.bwd_only_tile_begin : 0x7fffffff;
+    int wrap_to = (BWD && (int)blockIdx.x >= bo_begin) ? fwd_minis : 0;       // where the stream (re)starts: the kind of the NEXT tile to be fed
+    int issue_pos = wrap_to, issue_slot = 0, rd_slot = 0;
+    const char* isrc = wbase + (size_t)issue_pos * MINI_BYTES;
     unsigned idst = ring0;
     auto issue_next = [&]() {
-        issue_pos = (issue_pos + 1 == total_minis) ? 0 : issue_pos + 1;
+        issue_pos = (issue_pos + 1 == total_minis) ? wrap_to : issue_pos + 1;
         issue_slot = (issue_slot + 1 == SNB) ? 0 : issue_slot + 1;
         isrc = wbase + (size_t)issue_pos * MINI_BYTES;
         idst = ring0 + issue_slot * MINI_BYTES;
@@ -115,10 +127,26 @@ __global__ __launch_bounds__(256, 1) void mlp_split_kernel(const MlpArgs a) {
         const int src = (!BWD && a.index) ? a.index[pidx] : pidx;
         float4 pt = a.pts[src];
         if (!valid) pt = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool bo = BWD && tile >= bo_begin;                                   // backward sweep only, from exported masks (workgroup-uniform)
+        if (BWD) wrap_to = ((int)(tile + gridDim.x) >= bo_begin) ? fwd_minis : 0;  // the prefetch wraps during this tile: to where the NEXT tile starts
         lds_barrier();        // previous tile's readers of cb_l are done
         reinterpret_cast<float4*>(cb_l)[tid] = reinterpret_cast<const float4*>(a.code_bias + (size_t)td.z * a.code_bias_stride)[tid];
         lds_barrier();
-        {   // layer 0 on the VALU, redundantly in every wave (the slab is needed everywhere); masks of the own groups only
+        float y = 0.f;
+        if (bo) {
+            // masks and sdf of this point as the forward (MODE 1 / mlp_kernel<1>) launch of the same iteration exported them: this lane's words
+            // of the wave's two output groups for the eight mask slots.  Layout [sample][lane group][slot 8][group 8] u16; as u32 words,
+            // word 4 slot + w holds groups 2w (low half) and 2w + 1.
+            const int sidx = __float_as_int(pt.w);
+            const unsigned* mp = reinterpret_cast<const unsigned*>(a.mask_buf + ((size_t)sidx * 4 + g) * 64) + wave;
+#pragma unroll
+            for (int sl = 0; sl < MASK_SLOTS; ++sl) {
+                const unsigned w = valid ? mp[4 * sl] : 0u;
+                mask_l[(sl * 2 + 0) * 256 + tid] = (unsigned short)(w & 0xffffu);
+                mask_l[(sl * 2 + 1) * 256 + tid] = (unsigned short)(w >> 16);
+            }
+            y = valid ? a.sdf_in[sidx] : 0.f;
+        } else {   // layer 0 on the VALU, redundantly in every wave (the slab is needed everywhere); masks of the own groups only
             const float* w0 = bias_l + a.w0_row * WIDTH + 4 * g;
 #pragma unroll
             for (int o = 0; o < 8; ++o) {
@@ -137,18 +165,39 @@ __global__ __launch_bounds__(256, 1) void mlp_split_kernel(const MlpArgs a) {
                         sin_[16 * o + 4 * j + r] = relu1(pre);
                     }
                 }
-                if (BWD && (o >> 1) == wave) mask_l[(0 * 2 + (o & 1)) * 256 + tid] = (unsigned short)bits;
+                if (MASKS && (o >> 1) == wave) mask_l[(0 * 2 + (o & 1)) * 256 + tid] = (unsigned short)bits;
             }
         }
         float skipc[16];
         float skipx[3];
-        float y = 0.f;
         float gfirst = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) skipc[i] = 0.f;
         skipx[0] = skipx[1] = skipx[2] = 0.f;
 
-        for (int ps = 0; ps < a.n_pass; ++ps) {
+        // seed of the backward sweep on the own rows: d tanh * W_last, masked by the last hidden layer's relu (mask slot `slot`); then round the workgroup
+        auto seed_backward = [&](int slot) {
+            const float* wl = bias_l + a.wlast_row * WIDTH + 4 * g;
+            const float d = 1.f - y * y;
+            float seed[2][16];
+#pragma unroll
+            for (int ol = 0; ol < 2; ++ol) {
+                const int og = 2 * wave + ol;
+                const unsigned bits = mask_l[(slot * 2 + ol) * 256 + tid];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(wl + 16 * (4 * og + j));
+                    seed[ol][4 * j + 0] = ((bits >> (4 * j + 0)) & 1u) ? d * w4.x : 0.f;
+                    seed[ol][4 * j + 1] = ((bits >> (4 * j + 1)) & 1u) ? d * w4.y : 0.f;
+                    seed[ol][4 * j + 2] = ((bits >> (4 * j + 2)) & 1u) ? d * w4.z : 0.f;
+                    seed[ol][4 * j + 3] = ((bits >> (4 * j + 3)) & 1u) ? d * w4.w : 0.f;
+                }
+            }
+            exchange(seed, 8);
+        };
+        if (bo) seed_backward(a.seed_slot);       // (the mask words written above are this lane's own: no barrier needed before reading them back)
+
+        for (int ps = bo ? a.n_fwd : 0; ps < a.n_pass; ++ps) {
             const PassDesc pd = a.pass[ps];
             if (pd.kind == 2) {
                 // (row 445 = tile 27, row 477 = tile 29 with 32-D codes; both are row 13 of their tile: lane group 3, registers 1..3)
@@ -260,7 +309,7 @@ __global__ __launch_bounds__(256, 1) void mlp_split_kernel(const MlpArgs a) {
                             bits |= (own[ol][k] > 0.f ? 1u : 0u) << k;
                             own[ol][k] = relu1(own[ol][k]);
                         }
-                        if (BWD) mask_l[(pd.mask_slot * 2 + ol) * 256 + tid] = (unsigned short)bits;
+                        if (MASKS) mask_l[(pd.mask_slot * 2 + ol) * 256 + tid] = (unsigned short)bits;
                     } else if (BWD && pd.mask_slot >= 0) {
                         if (pd.kind == 4) {      // latent_in layer: gradients of the re-injected xyz / code rows, unmasked (wave 3)
                             if (a.lat_tile != 29) {          // 64-D codes: xyz at rows 445..447, code at 448..511
@@ -304,24 +353,17 @@ __global__ __launch_bounds__(256, 1) void mlp_split_kernel(const MlpArgs a) {
                         if (a.guard) prepass_guard(a, td.z, st, st ? a.out_sdf[a.index ? src : pidx + td.w] : 1.0f, y);
                         if (st) a.out_sdf[a.index ? src : pidx + td.w] = y;
                     }
+                    if (MODE == 1 && valid && y > -a.th && y < a.th) {
+                        // a candidate row of the render term (loss.py:88): export this lane's mask words of the wave's two output groups,
+                        // all eight slots, in mlp_kernel<1>'s layout -- the mixed jacobian launch runs this sample backward-only from them
+                        unsigned* mp = reinterpret_cast<unsigned*>(a.mask_buf + ((size_t)src * 4 + g) * 64) + wave;
+#pragma unroll
+                        for (int sl = 0; sl < MASK_SLOTS; ++sl)
+                            mp[4 * sl] = (unsigned)mask_l[(sl * 2 + 0) * 256 + tid] | ((unsigned)mask_l[(sl * 2 + 1) * 256 + tid] << 16);
+                    }
                     continue;
                 }
-                const float d = 1.f - y * y;
-                float seed[2][16];
-#pragma unroll
-                for (int ol = 0; ol < 2; ++ol) {
-                    const int og = 2 * wave + ol;
-                    const unsigned bits = mask_l[(pd.mask_slot * 2 + ol) * 256 + tid];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(wl + 16 * (4 * og + j));
-                        seed[ol][4 * j + 0] = ((bits >> (4 * j + 0)) & 1u) ? d * w4.x : 0.f;
-                        seed[ol][4 * j + 1] = ((bits >> (4 * j + 1)) & 1u) ? d * w4.y : 0.f;
-                        seed[ol][4 * j + 2] = ((bits >> (4 * j + 2)) & 1u) ? d * w4.z : 0.f;
-                        seed[ol][4 * j + 3] = ((bits >> (4 * j + 3)) & 1u) ? d * w4.w : 0.f;
-                    }
-                }
-                exchange(seed, 8);
+                seed_backward(pd.mask_slot);
             }
         }
 
@@ -359,22 +401,28 @@ __global__ __launch_bounds__(256, 1) void mlp_split_kernel(const MlpArgs a) {
 
 size_t mlp_split_lds_bytes() { return BIAS_BYTES + CODEBIAS_BYTES + SPLIT_MASK_BYTES + XCH_BYTES + SPLIT_RING_BYTES; }
 
-template __global__ void mlp_split_kernel<false>(const MlpArgs);
-template __global__ void mlp_split_kernel<true>(const MlpArgs);
+template __global__ void mlp_split_kernel<0>(const MlpArgs);
+template __global__ void mlp_split_kernel<1>(const MlpArgs);
+template __global__ void mlp_split_kernel<2>(const MlpArgs);
 
 hipError_t mlp_split_prepare_device() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_split_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)mlp_split_lds_bytes());
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_split_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)mlp_split_lds_bytes());
+    const void* fns[3] = {reinterpret_cast<const void*>(&mlp_split_kernel<0>), reinterpret_cast<const void*>(&mlp_split_kernel<1>),
+                          reinterpret_cast<const void*>(&mlp_split_kernel<2>)};
+    for (const void* f : fns) {
+        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlp_split_lds_bytes());
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
-hipError_t launch_mlp_split(bool bwd, const MlpArgs& args, int n_blocks, hipStream_t stream) {
-    if (bwd)
-        hipLaunchKernelGGL(mlp_split_kernel<true>, dim3(n_blocks), dim3(256), mlp_split_lds_bytes(), stream, args);
+// mode 0 forward, 1 forward + relu-mask export, 2 forward + backward (+ backward-only tiles from args.bwd_only_tile_begin on)
+hipError_t launch_mlp_split(int mode, const MlpArgs& args, int n_blocks, hipStream_t stream) {
+    if (mode == 2)
+        hipLaunchKernelGGL(mlp_split_kernel<2>, dim3(n_blocks), dim3(256), mlp_split_lds_bytes(), stream, args);
+    else if (mode == 1)
+        hipLaunchKernelGGL(mlp_split_kernel<1>, dim3(n_blocks), dim3(256), mlp_split_lds_bytes(), stream, args);
     else
-        hipLaunchKernelGGL(mlp_split_kernel<false>, dim3(n_blocks), dim3(256), mlp_split_lds_bytes(), stream, args);
+        hipLaunchKernelGGL(mlp_split_kernel<0>, dim3(n_blocks), dim3(256), mlp_split_lds_bytes(), stream, args);
     return hipGetLastError();
 }
 

@@ -140,6 +140,10 @@ class Batch(object):
         """0 = LDL^T (default), 1 = pivot-free Gauss-Jordan (the round-2/3 kernel, kept as the A/B reference)."""
         L.check(L.load().dsp_batch_set_solver(self._h, int(mode)), self.engine._h, "dsp_batch_set_solver")
 
+    def set_mixed_reuse(self, mode):
+        """-1 = automatic, 0 = off, 1 = kept render rows backward-only from exported masks INSIDE the latency-form jacobian launch."""
+        L.check(L.load().dsp_batch_set_mixed_reuse(self._h, int(mode)), self.engine._h, "dsp_batch_set_mixed_reuse")
+
     def set_cluster_tiles(self, mode):
         """-1 = automatic, 0 = one workgroup per 16-point jacobian tile, 1 = four (cluster form) for lists of up to 128 tiles."""
         L.check(L.load().dsp_batch_set_cluster_tiles(self._h, int(mode)), self.engine._h, "dsp_batch_set_cluster_tiles")

@@ -280,6 +280,12 @@ int dsp_batch_set_depth_schedule(dsp_batch* b, const float* depths, int32_t n_it
  * scan read: fp32 inside the band, the prepass value or the placeholder 1.0 elsewhere; NaN = not in the sphere), sdeds (de_ds of a kept
  * sample, 0 = not kept, NaN = not in the sphere).  cap = floats available in ssdf / sdeds (>= n_rays * num_depth_samples). */
 int dsp_batch_debug_samples(dsp_batch* b, int32_t obj, uint64_t* raymask, float* ssdf, float* sdeds, int64_t cap);
+/* Mask reuse in the latency path ("mixed" form, round 4): where the jacobian launch runs 16-point latency-form tiles and the list is too long
+ * for the speculative band rows (one cfg2-size object), the forward launch exports the relu masks of its band samples and the kept render
+ * rows run the backward sweep only -- as tiles of the SAME launch as the surface points' forward + backward tiles.  -1 = automatic (on),
+ * 0 = off, 1 = on where applicable; dsp_batch_set_mask_reuse(b, 0) turns every form of mask reuse off.  Results are identical for every
+ * setting. */
+int dsp_batch_set_mixed_reuse(dsp_batch* b, int mode);
 /* Latency form of the jacobian launch, one step further: a list of at most 128 tiles of 16 points (a detection of SLAM's real size has
  * 40-60) runs with FOUR workgroups per tile -- the rows of every layer split over their 16 waves, the layer's result handed round the
  * cluster through L2 after every pass -- so that a detection occupies ~240 CUs instead of ~60.  Longer lists keep one workgroup per tile.

@@ -350,3 +350,46 @@ def test_cluster_fallback_on_a_lost_hand_off(eng):
         assert np.array_equal(x, y)
     b.close()
     print("fallback after a lost hand-off: %.2f s" % dt)
+
+
+def test_mixed_reuse_is_exact(eng):
+    """Latency path, lists too long for the speculative band rows (one cfg2-size object: 2500 rays x 50): the forward launch exports the
+    relu masks of its band samples -- 64-point tiles of mlp_kernel<1> + the tail round as 16-point tiles of mlp_split_kernel<1>, or all
+    of it as 16-point tiles -- and the kept render rows run the backward sweep only, as tiles of the SAME launch as the surface points'
+    forward + backward tiles (mlp_split_kernel<2>, whose weight stream jumps to its backward part for them).  Every bit of every
+    iteration equals the launch in which the render rows repeat their forward sweep; the work counters show the sweep was skipped."""
+    g = golden("golden_recon_cfg2.npz")
+    big = dict(t_cam_obj_init=g["in_t_cam_obj_init"], pts=g["in_pts"], rays=g["in_rays"], depth=g["in_depth"])
+    n_it = 3
+    prm = E.gn_params(num_iterations=n_it)
+    for prepass in (1, 0):
+        off = _run_traced(eng, prm, [big], n_it, prepass=prepass, mixed_reuse=0)
+        on = _run_traced(eng, prm, [big], n_it, prepass=prepass, mixed_reuse=1)
+        _assert_same_bits(off, on, np.array([0]), "mixed reuse, cfg2-size, prepass %d" % prepass)
+        assert off[2]["n_render_rows"] == 0 and on[2]["n_render_rows"] > 0
+        assert on[2]["n_jac_points"] + on[2]["n_render_rows"] == off[2]["n_jac_points"]
+        assert on[2]["n_mlp_jac_launches"] == off[2]["n_mlp_jac_launches"] == n_it          # still ONE jacobian launch per iteration
+        assert on[2]["n_fwd_points"] == off[2]["n_fwd_points"]
+        auto = _run_traced(eng, prm, [big], n_it, prepass=prepass)
+        _assert_same_bits(on, auto, np.array([0]), "automatic == mixed for this shape")
+        assert auto[2]["n_render_rows"] == on[2]["n_render_rows"]
+        # without the tail split (the whole forward launch in 64-point mask-exporting tiles), and with the forward launch in 16-point tiles
+        for kw in (dict(tail_split=0), dict(split_rows=1)):
+            v = _run_traced(eng, prm, [big], n_it, prepass=prepass, mixed_reuse=1, **kw)
+            _assert_same_bits(off, v, np.array([0]), "mixed reuse %s" % kw)
+            assert v[2]["n_render_rows"] == on[2]["n_render_rows"]
+    # several mid-size objects, ragged tiles, a failing one among them
+    objs = synth.make_batch(3, first_seed=2500, n_surface=700, n_background=260)
+    bad = synth.make_object(2590, 60, 20)
+    bad["t_cam_obj_init"] = bad["t_cam_obj_init"].copy()
+    bad["t_cam_obj_init"][:3, 3] += 500.0
+    objs.insert(1, bad)
+    off = _run_traced(eng, prm, objs, n_it, mixed_reuse=0, split_rows=1, speculative_band=0)
+    on = _run_traced(eng, prm, objs, n_it, mixed_reuse=1, split_rows=1, speculative_band=0)
+    assert list(off[0][3]) == [0, 1, 0, 0]
+    _assert_same_bits(off, on, np.array([0, 2, 3]), "mixed reuse, ragged batch")
+    assert on[2]["n_render_rows"] > 0
+    # mask reuse switched off as a whole turns the mixed form off too
+    none = _run_traced(eng, prm, [big], n_it, mask_reuse=0)
+    assert none[2]["n_render_rows"] == 0
+    _assert_same_bits(none, _run_traced(eng, prm, [big], n_it, mixed_reuse=1), np.array([0]), "mask_reuse=0 vs mixed")

@@ -33,11 +33,12 @@ for name, (M, Bg) in (("KITTI-size 250+200", (250, 200)), ("cfg2-size 2000+500",
     print("## %s" % name)
     variants = [("automatic (cluster tiles, wave bookkeeping, LDL^T, no per-kernel events)", {}),
                 ("one workgroup per jacobian tile (cluster form off)", dict(cluster_tiles=0)),
+                ("render rows repeat their forward sweep (mixed mask reuse off)", dict(mixed_reuse=0)),
                 ("fused per-object bookkeeping (round 3)", dict(fused_bookkeeping=1)),
                 ("throughput bookkeeping", dict(fused_bookkeeping=0)),
                 ("Gauss-Jordan solve (round 3)", dict(solver=1)),
                 ("per-kernel events on", dict(kernel_timing=1)),
-                ("round-3 equivalent: fused=1 (or 0 for large), GJ, events on, no clusters", dict(fused_bookkeeping=1 if M == 250 else 0, solver=1, kernel_timing=1, cluster_tiles=0)),
+                ("round-3 equivalent: fused=1 (or 0 for large), GJ, events on, no clusters", dict(fused_bookkeeping=1 if M == 250 else 0, solver=1, kernel_timing=1, cluster_tiles=0, mixed_reuse=0)),
                 ("prepass off", dict(prepass=0))]
     ref = None
     for label, kw in variants:
