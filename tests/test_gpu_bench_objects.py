@@ -124,7 +124,19 @@ def test_batch64_at_the_references_recorded_states(batch64, oracle_decoder):
             assert np.array_equal(tr["depths"][i][:n_d], g["tr%d_it_depths" % i][e])
             v_ref, k_ref = int(g["tr%d_it_V" % i][e]), int(g["tr%d_it_K" % i][e])
             h_ref, b_ref, dx_ref = g["tr%d_it_H" % i][e], g["tr%d_it_b" % i][e], g["tr%d_it_dx" % i][e]
-            rh, rb = F.rel_max(tr["H"][i], h_ref), F.rel_max(tr["b"][i][mask], b_ref[mask])
+            # The 3 x 3 rotation block of H carries k4 * J_rot^T J_rot with k4 = 1e7, and the reference derives J_rot = (R_oc n_g) x e_y through
+            # two float32 inversions, a float32 pow and a division (loss.py:155-178): a few ulp of 1.0 on entries of ~1e-3, times 1e7.  For a
+            # tilted state that is 1e-4 ... 1e-3 of |H| of noise IN THE REFERENCE (object 54, iteration 7: the numpy oracle, which derives J_rot
+            # in fp64, differs from the recorded H[3, 3] by 3.1e-4 of |H|max exactly as the device does, while its response to sdf jitter is
+            # 7e-7).  So, as for b[3:6]: the block is held to the prior's own noise, the rest of H to the tight bound.
+            hm = np.ones((71, 71), bool)
+            hm[3:6, 3:6] = False
+            hs = np.abs(h_ref).max()
+            rh = float(np.abs(tr["H"][i] - h_ref)[hm].max() / hs)
+            rb = F.rel_max(tr["b"][i][mask], b_ref[mask])
+            j_rot = np.sqrt(np.abs(np.diag(h_ref)[3:6]) / max(k4, 1.0)) + 1e-3
+            tol_rot_h = k4 * (j_rot[:, None] + j_rot[None, :]) * 1e-6 + 3e-5 * hs
+            assert np.all(np.abs(tr["H"][i] - h_ref)[3:6, 3:6] <= tol_rot_h), (i, e, np.abs(tr["H"][i] - h_ref)[3:6, 3:6].max(), tol_rot_h.max())
             n_named = 0
             if (int(tr["V"][i]), int(tr["K"][i])) != (v_ref, k_ref):
                 o = objs[i]
@@ -150,7 +162,7 @@ def test_batch64_at_the_references_recorded_states(batch64, oracle_decoder):
                     it0, itj = F.oracle_linearisation(*args), F.oracle_linearisation(*args, sdf_jitter=2e-7)
                     assert (it0["V"], it0["K"]) == (v_ref, k_ref)
                     # (where 2e-7 of sdf moves a sample of the ORACLE across a threshold, a whole row enters or leaves: that response is the yardstick too)
-                    amp_h = F.rel_max(itj["H"], it0["H"])
+                    amp_h = float(np.abs(itj["H"] - it0["H"])[hm].max() / hs)
                     amp_b = float(np.abs(itj["b"] - it0["b"])[mask].max() / np.abs(it0["b"][mask]).max())
                     jitter_rows.append(dict(object=i, iteration=e, rel_H=rh, rel_b=rb, oracle_jitter_rel_H=amp_h, oracle_jitter_rel_b=amp_b,
                                             oracle_jitter_flips_a_sample=bool((it0["vsum"], it0["ksum"]) != (itj["vsum"], itj["ksum"]))))
