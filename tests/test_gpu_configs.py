@@ -402,7 +402,10 @@ def test_speculative_band_rows_are_exact(eng, oracle_decoder):
             assert np.array_equal(ta[k], tc[k]), k
     assert out[0][2]["n_fwd_points"] > 0 and out[1][2]["n_fwd_points"] == 0          # no forward launch of their own
     assert out[1][2]["n_mlp_fwd_launches"] == 0 and out[1][2]["n_mlp_jac_launches"] == 5
-    assert out[1][2]["n_jac_points"] == out[0][2]["n_jac_points"] - sum(int(t["K"].sum()) for t in out[0][1]) + out[0][2]["n_fwd_points"]
+    # (without the speculative rows the kept render rows either repeat their forward sweep inside the jacobian launch -- counted in
+    # n_jac_points -- or, with the mixed form of mask reuse the latency path now picks, run backward-only -- counted in n_render_rows)
+    assert out[1][2]["n_jac_points"] == (out[0][2]["n_jac_points"] + out[0][2]["n_render_rows"] - sum(int(t["K"].sum()) for t in out[0][1])
+                                         + out[0][2]["n_fwd_points"])
     assert out[1][2]["prepass_misclassified"] == 0
     # automatic mode picks it for a detection of this size
     b = eng.batch(prm, *[a[:1] for a in args])
