@@ -92,7 +92,7 @@ def main():
             "  (HIP events inside `bench.py`, un-profiled: %.2f ms) -- %.0f k points each = %.2f TFLOP per launch = **%.1f TFLOP/s = %.3f of the 157.3 TFLOP/s fp32 MFMA peak**"
             % (r["avg_launch_ms"], pts_per_launch / 1e3, r["alg_flop_per_launch"] / 1e12, r["alg_flop_per_launch"] / (k1["avg_us"] * 1e-6) / 1e12,
                r["alg_flop_per_launch"] / (k1["avg_us"] * 1e-6) / 1e12 / PEAK32),
-            "  (bench: %.3f).  Round 1: 100 launches x 10.2 ms; first round-2 profile: 20.97 ms (0.860) before the instruction-stream work (DESIGN.md, K1)." % r["frac"],
+            "  (bench: %.3f).  Round 3: 20.95 ms (0.893); round 1: 100 launches x 10.2 ms." % r["frac"],
             "* `mlp_kernel<3>` (render rows, backward sweep only from those masks): 10 launches x %.2f ms; `mlp_kernel<2>` (surface points, forward + backward):"
             % (k2r["avg_us"] / 1e3),
             "  10 x %.2f ms (the %d calls include the latency probes); together %.3f of peak in the bench." % (k2["avg_us"] / 1e3, k2["calls"], r["jac_kernel_frac"]),
@@ -193,30 +193,40 @@ def main():
     runs = [v["calls"] for k, v in ls.items() if "k_solve" in k][0] // 10
     per_run = sum(v["total_ms"] for v in ls.values()) / runs
     tail = [l for l in read("latency_run.txt").splitlines() if not l.startswith("W2") and not l.startswith("E2") and l.strip()][-4:]
-    split = [v for k, v in ls.items() if "mlp_split_kernel" in k][0]
-    lpk = [v for k, v in ls.items() if "mlp_lp_kernel" in k][0]
-    solve = [v for k, v in ls.items() if "k_solve" in k][0]
+    n_it = [v for k, v in ls.items() if "k_solve" in k][0]["calls"]
+
+    def per_it(sub):      # us per Gauss-Newton iteration spent in kernels whose name contains `sub`
+        return 1e3 * sum(v["total_ms"] for k, v in ls.items() if sub in k and "ILb1EEEvNS_6LpArgs" not in k) / n_it
+
     book = sum(v["total_ms"] for k, v in ls.items() if not any(x in k for x in ("mlp_", "k_solve", "__amd", "k_init_state", "k_finalize", "k_code_bias")))
     ltxt = ["# Round %s -- single-detection latency path, rocprofv3 kernel stats" % ROUND, "",
             "`cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -- python tools/gpu_small_loop.py <M> <Bg> <reps>`: a resident batch of ONE object",
             "re-run `reps`+1 times (10 joint Gauss-Newton iterations each); tables by `tools/rocpd_stats.py`, this file by `tools/make_profiles.py`.",
-            "Automatic kernel choice (no setters).", "",
+            "Automatic kernel choice (no setters).  The object of this loop is seed 1 at detection size: some of its iterations keep more than 128",
+            "jacobian tiles, which then take the latency form (`mlp_split_kernel<2>`) instead of the cluster form -- both kernels are launched every",
+            "iteration and one of them returns at once (its ~4.5 us minimum in the table).", "",
             "## Real-KITTI-size detection: 250 surface points + 200 background rays (450 rays x 50 samples), %d runs -- %.2f ms of kernels per run under the profiler"
             % (runs, per_run),
-            "## (%.2f ms p50 in `bench.py`, un-profiled); first round-2 profile 6.25 / 5.77 ms, round 1: 11.06 ms" % b["latency_kitti_size_ms_p50"], "",
+            "## (%.2f ms p50 in `bench.py`, un-profiled, on the bench's own detection, whose lists all fit the cluster form; round 3: 5.43 ms, round 1: 11.06 ms)" % b["latency_kitti_size_ms_p50"], "",
             table_only("latency_kernel_stats.md"), "", "```"] + tail + ["```", "",
-            "Per iteration (%d iterations): ONE prepass launch over every in-sphere sample (%.0f us), ONE latency-form jacobian launch over surface points +"
-            % (solve["calls"], lpk["avg_us"]),
-            "band samples (%.0f us: the band samples get forward + backward speculatively, their sdf is scattered back for the occupancy scan; 283 us before"
-            % split["avg_us"],
-            "the SGPR-base LDS-DMA and the paired A-operand reads), `k_solve` %.0f us (it also computes the next iteration's code bias), and the small"
-            % solve["avg_us"],
-            "bookkeeping launches (`k_front_fused`, `k_band_fused`, `k_render_scan`, `k_render_tail_fused`, `k_gram`, 2 x `k_build_tiles`, `k_gram_reduce`):",
-            "**%.0f us per iteration = %.2f ms per call** (round 1: ~300 launches, 2.4 ms).  11 launches per iteration instead of 27."
-            % (1e3 * book / solve["calls"], book / runs), "",
-            "## cfg2-size object: 2000 surface points + 500 background rays (2500 rays) -- %.2f ms p50 in `bench.py`" % b["latency_ms_p50"], "",
+            "Per iteration (%d iterations), us: prepass `mlp_lp_kernel` %.0f; jacobian launch -- cluster form %.0f + latency form %.0f (one of the two does the work);"
+            % (n_it, per_it("mlp_lp_kernel"), per_it("mlp_cluster_kernel"), per_it("mlp_split_kernel")),
+            "`k_solve` %.0f (LDL^T; round 3: 74); `k_gram` %.0f + `k_gram_reduce` %.0f; `k_render_scan` %.0f; `k_render_tail_wave` %.0f; `k_front_wave` %.0f; `k_band_wave` %.0f;"
+            % (per_it("k_solve"), per_it("k_gramE"), per_it("k_gram_reduce"), per_it("k_render_scan"), per_it("k_render_tail_wave"), per_it("k_front_wave"), per_it("k_band_wave")),
+            "two `k_build_tiles` %.0f.  Everything that is not a decoder launch or the solve: **%.0f us per iteration = %.2f ms per call** (round 3: 126 us / 1.26 ms)."
+            % (per_it("k_build_tiles"), 1e3 * book / n_it, book / runs), "",
+            "## cfg2-size object: 2000 surface points + 500 background rays (2500 rays) -- %.2f ms p50 in `bench.py` (round 3: 17.30)" % b["latency_ms_p50"], "",
+            "(the forward launch exports relu masks -- `mlp_kernel<1>` + its tail round as `mlp_split_kernel<1>` -- and the kept render rows run backward-only",
+            "inside the jacobian launch `mlp_split_kernel<2>`: mixed mask reuse)", "",
             table_only("latency_cfg2_kernel_stats.md"), ""]
     open(os.path.join(DST, TAG + "_latency_kernel_stats.md"), "w").write("\n".join(ltxt))
+    if os.path.exists(os.path.join(SRC, "latency_ab.txt")):
+        ab = ["# Round %s -- per-detection latency, A/B of every switch on ONE box" % ROUND, "",
+              "`python tools/gpu_latency_ab.py 15`: host wall clock p50 / min over 15 runs around `run + results` of a resident one-object batch (and the one-shot",
+              "entry point, host buffers in).  Every variant returns the automatic path's bits (last column).", "", "```", read("latency_ab.txt").rstrip(), "```", "",
+              "one-shot = `dsp_reconstruct_batch` (what `Optimizer.reconstruct_object` calls): build the batch out of the handle's pools, upload through pinned staging,",
+              "run, ONE read-back, drop.", ""]
+        open(os.path.join(DST, TAG + "_latency_ab.md"), "w").write("\n".join(ab))
     print("wrote profiles/%s_{bench_lines,kernel_stats,pmc,latency_kernel_stats}.md and pmc_traffic.json" % TAG)
     print("K1 busy %.1f%% clk %.2f; K2 %.1f%%; K2r %.1f%%; K0 busy %.1f%% clk %.2f" % (100 * busy(K1), clk(K1), 100 * busy(K2), 100 * busy(K2R), 100 * busy(K0), clk(K0)))
     print("K1 fetch B/pt %.0f  K0 fetch B/pt %.0f write B/pt %.0f" % (k1_fetch / k1_pts, k0_fetch / k0_pts, wr[(K0, "WRITE_SIZE")][1] * 1024 / k0_pts))

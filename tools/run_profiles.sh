@@ -3,7 +3,7 @@
 # (each in its own run, --pmc only), latency-sized kernel stats.  Outputs under gpurun_out/<tag>/ ; copy what is to be judged into profiles/.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r02}
+TAG=${1:-r04}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
@@ -35,4 +35,5 @@ timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_lat2 -o stats -- pytho
 DB=$(find /tmp/prof_lat2 -name "*.db" | head -1)
 python $R/tools/rocpd_stats.py $DB > $OUT/latency_cfg2_kernel_stats.md 2>&1
 cd $R
+timeout 600 python tools/gpu_latency_ab.py 15 > $OUT/latency_ab.txt 2>&1
 cut -c1-600 $OUT/bench.json; head -12 $OUT/kernel_stats.md; tail -4 $OUT/latency_run.txt
