@@ -128,12 +128,12 @@ def main():
     def clk(k):
         return mf[(k, "GRBM_GUI_ACTIVE")][1] / 8 / (dm[k][1] * 1e-3) / 1e9
 
-    n1 = dm[K1][0]
+    n1 = 20        # 2 steps x 10 iterations of the bench batch; the cfg2-size latency probes add small mlp_kernel<1> launches (mixed mask reuse) on top
     # points per launch from the un-profiled bench of the same run (same workload, same seeds)
     k1_pts = pts_per_launch * n1
     k1_fetch = fe[(K1, "FETCH_SIZE")][1] * 1024 * 2
     k0_pts = lp["alg_flop_per_launch"] / F_FWD * 10 * (dm[K0][0] // 100) * 10     # 100 launches per step
-    steps_in_pmc = dm[K1][0] / 10.0
+    steps_in_pmc = n1 / 10.0
     k0_pts = lp["alg_flop_per_launch"] / F_FWD * 100 * steps_in_pmc
     k0_fetch = fe[(K0, "FETCH_SIZE")][1] * 1024 * 2
     wave1 = mf[(K1, "SQ_WAVE_CYCLES")][1]
@@ -141,7 +141,7 @@ def main():
     txt = ["# Round %s -- rocprofv3 PMC passes" % ROUND + " at the bench configuration", "",
            "Four separate `--pmc` passes (no `--stats`, no tracing; one counter group per run) over",
            "`python bench.py --steps 1 --warmup 1 --no-cpu-baseline --latency-runs 1` -- **64 objects per GPU, the bench configuration** (round 1's pass was",
-           "taken at 32).  2 steps = %d launches of the fp32 forward kernel `mlp_kernel<1>`, 200 of the prepass kernel (+ ~60 from the latency probes)." % n1,
+           "taken at 32).  2 steps = %d launches of the fp32 forward kernel `mlp_kernel<1>` (+ %d small ones from the cfg2-size latency probe, whose forward launch now exports masks too: < 2 %% of the counters), 200 of the prepass kernel (+ ~80 from the latency probes)." % (n1, dm[K1][0] - n1),
            "Tables by `tools/rocpd_pmc.py` (kernels matching `mlp_`), this file by `tools/make_profiles.py`.", "",
            "## FETCH_SIZE (KiB)", "", table_only("pmc_fetch.md"), "", "## WRITE_SIZE (KiB)", "", table_only("pmc_write.md"), "",
            "## MFMA / busy counters", "", table_only("pmc_mfma.md"), "", "## LDS / wait counters", "", table_only("pmc_lds.md"), "", "## Reading", "",
