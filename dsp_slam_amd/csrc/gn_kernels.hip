@@ -1355,7 +1355,8 @@ __device__ __forceinline__ double fast_recip(double d) {
     return r;
 }
 
-// SOLVER 0: LDL^T (round 4).  SOLVER 1: the round-2/3 pivot-free Gauss-Jordan, kept as the A/B reference (dsp_batch_set_solver).
+// SOLVER 2: LDL^T, rows in lanes, eight columns per wave (default).  SOLVER 0: LDL^T with the packed triangle in the registers of eight waves (first
+// round-4 form).  SOLVER 1: the round-2/3 pivot-free Gauss-Jordan.  Both kept as A/B references (dsp_batch_set_solver).
 template <int SOLVER>
 __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, ObjState* st, const double* gsum, GnParamsDev prm, int iter,
                                                          const float* codew, const float* cb0, const float* cblat, float* cbias,
@@ -1451,7 +1452,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
         }
         __syncthreads();
     }
-    if constexpr (SOLVER == 0) {
+    if constexpr (SOLVER != 1) {
         // 2. H dx = b by LDL^T in fp64.  H = sum w J^T J + positive diagonal is symmetric (bit for bit: the Gram kernel's fmaf chains
         //    commute) positive definite, so no pivoting is needed (the reference inverts H with fp32 LU, optimizer.py:186).  The
         //    right-hand side rides along as row n of the augmented matrix [[H, b], [b^T, .]]: after the n elimination steps row n holds
@@ -1464,6 +1465,69 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
         __shared__ double rdv[NS1];
         __shared__ int s_sing;
         if (tid < n) A[n][tid] = A[tid][n];           // b as row n
+        if constexpr (SOLVER == 2) {
+        // Rows-in-lanes form (default).  What bounds the packed form below is the LDS: twelve 8-byte reads per thread and step = 96
+        // wave-wide LDS instructions = 42 KB through a 128 B/clk port, ~400 of its ~1100 cycles per step (a 9 x 9-blocked form with 11
+        // broadcast reads per lane cost the same: the port does not care that 56 of 64 lanes read the same word).  Here wave w < 9 owns
+        // columns 8w .. 8w+7 and lane l is row l: v0[jj] = A[l][8w+jj]; rows 64 .. 71 (seven code unknowns and the right-hand side) sit
+        // in one more register, vx = A[64 + (l & 7)][8w + (l >> 3)].  A step costs a wave THREE LDS reads (its rows' entries of column
+        // k for both register sets, and the per-lane column entry of vx); the pivot and the eight column entries c_jk are rows of the
+        // same column, i.e. other lanes' values of the register just read: v_readlane into scalar operands of the FMAs.  Waves whose
+        // columns are all finished skip the step.  
+        // Values computed for columns <= k are never read again.
+        const int w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;      // w in a scalar register: lane selects below are scalar
+        const bool worker = w < 9;
+        double* Af = &A[0][0];
+        constexpr int LDA = NS1 + 1;
+        const int o0 = lane * LDA, oxr = (64 + (lane & 7)) * LDA, oxc = (8 * w + (lane >> 3)) * LDA;
+        __syncthreads();
+        double v0[8], vx = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) v0[jj] = worker ? Af[o0 + 8 * w + jj] : 0.0;
+        if (worker) vx = Af[oxr + 8 * w + (lane >> 3)];
+        bool sing = false;
+        auto readlane_f64 = [](double x, int l) {
+            return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+        };
+#pragma unroll 1
+        for (int kb = 0; 8 * kb < n; ++kb) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int k = 8 * kb + t;
+                if (k < n) {                                  // uniform
+                    __syncthreads();                          // column k is published; every read of column k - 1 has retired
+                    if (worker && 8 * w + 7 > k) {            // uniform per wave: a column of mine is still open (wave 8: always)
+                        const double ci0 = Af[o0 + k], cix = Af[oxr + k], cjx = Af[oxc + k];
+                        const double d = readlane_f64(k >= 64 ? cix : ci0, k & 63);      // row k of column k
+                        const double rdk = fast_recip(d);
+                        sing = sing || !(d > 0.0);            // also NaN
+                        if (tid == 8 * 64) rdv[k] = rdk;
+                        const double csrc = (w == 8) ? cix : ci0;                        // rows 8w .. 8w+7 of column k are lanes of this
+                        const int cbase = (w == 8) ? 0 : 8 * w;
+                        // rows ABOVE the pivot are eliminated too (Gauss-Jordan on the symmetric trailing part: the lanes are there anyway),
+                        // so there is no back substitution: after step n - 1 column n holds d_i dx_i.  Only the pivot row itself rests.
+                        const double l0 = lane == k ? 0.0 : ci0 * rdk, lx = (64 + (lane & 7)) == k ? 0.0 : cix * rdk;
+#pragma unroll
+                        for (int jj = 0; jj < 8; ++jj) v0[jj] = fma(-l0, readlane_f64(csrc, cbase + jj), v0[jj]);
+                        vx = fma(-lx, cjx, vx);
+                        const int tn = (t + 1) & 7;           // (compile-time after unrolling) column k + 1 is final after this step: its owner publishes it
+                        if (w == (t == 7 ? kb + 1 : kb)) {
+                            Af[o0 + k + 1] = v0[tn];
+                            if ((lane >> 3) == tn) Af[oxr + k + 1] = vx;
+                        }
+                    }
+                }
+            }
+        }
+        if (tid == 8 * 64) s_sing = sing ? 1 : 0;
+        __syncthreads();
+        // dx_i = A[i][n] / d_i: column n is register n & 7 of wave n >> 3 (n = 71: wave 8, v0[7] and the vx lanes of column 7; n = 6: wave 0, v0[6])
+        if (w == (n >> 3)) {
+            const double bn = n == NSOLVE ? v0[NSOLVE & 7] : v0[6];
+            if (lane < n) Af[o0 + n] = bn * rdv[lane];
+            if ((lane >> 3) == (n & 7) && 64 + (lane & 7) < n) Af[oxr + n] = vx * rdv[64 + (lane & 7)];
+        }
+        } else {
         if (tid == 0) {
             const double d0 = A[0][0];
             rdv[0] = fast_recip(d0);
@@ -1523,12 +1587,14 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
                 }
             }
         }
+        }
         __syncthreads();
+        if (stamp) g_solve_clk[7] = wall_clock64();
         if (s_sing) { if (tid == 0) s.status = DSP_STATUS_NAN; return; }      // uniform
         // back substitution L^T dx = D^-1 z by wave 0, column-oriented from the last unknown up: lane j holds w_j = z_j - sum_{i > j}
         // c_ij dx_i for j = lane and lane + 64; dx_i = rd_i w_i is final when every i' > i has been folded in.  Rows of c are contiguous
         // in LDS; the next row is fetched while the current one is folded.
-        if (tid < 64) {
+        if (SOLVER == 0 && tid < 64) {
             const int j0 = tid, j1 = tid + 64;
             double w0 = j0 < n ? A[n][j0] : 0.0, w1 = j1 < n ? A[n][j1] : 0.0;
             const double rd0 = j0 < n ? rdv[j0] : 0.0, rd1 = j1 < n ? rdv[j1] : 0.0;
@@ -1869,6 +1935,8 @@ void launch_solve(const ObjConst* oc, ObjState* st, const float* partials, doubl
     hipLaunchKernelGGL(k_gram_reduce, dim3((72 * 72 + 255) / 256, B, prm.pose_only ? 1 : 2), dim3(256), 0, s, st, partials, n_slices, gsum);
     if (solver == 1)
         hipLaunchKernelGGL(k_solve<1>, dim3(B), dim3(SOLVE_THREADS), 0, s, oc, st, gsum, prm, iter, codew, b0, blat, cbias, trace, depths_next, B);
+    else if (solver == 2)
+        hipLaunchKernelGGL(k_solve<2>, dim3(B), dim3(SOLVE_THREADS), 0, s, oc, st, gsum, prm, iter, codew, b0, blat, cbias, trace, depths_next, B);
     else
         hipLaunchKernelGGL(k_solve<0>, dim3(B), dim3(SOLVE_THREADS), 0, s, oc, st, gsum, prm, iter, codew, b0, blat, cbias, trace, depths_next, B);
 }

@@ -291,9 +291,10 @@ int dsp_batch_set_mixed_reuse(dsp_batch* b, int mode);
  * cluster through L2 after every pass -- so that a detection occupies ~240 CUs instead of ~60.  Longer lists keep one workgroup per tile.
  * -1 = automatic (on wherever the latency form is), 0 = off, 1 = on where applicable.  Results are identical for every setting. */
 int dsp_batch_set_cluster_tiles(dsp_batch* b, int mode);
-/* The 71 x 71 (pose-only: 6 x 6) normal equations are solved in fp64 on the device: 0 = LDL^T with the right-hand side as an extra row +
- * one back substitution (default, round 4: ~3x shorter), 1 = pivot-free Gauss-Jordan (rounds 2-3, kept as the A/B reference).  Both are
- * exact to fp64 round-off on the symmetric positive definite H of optimizer.py:161-184; dx agrees to ~1e-12 relative. */
+/* The 71 x 71 (pose-only: 6 x 6) normal equations are solved in fp64 on the device: LDL^T with the right-hand side as an extra row + one
+ * back substitution -- 2 = blocked over nine waves (default), 0 = packed triangle in the registers of eight waves (bit-identical to 2) --
+ * or 1 = pivot-free Gauss-Jordan (rounds 2-3).  0 and 1 are kept as A/B references.  All are exact to fp64 round-off on the symmetric
+ * positive definite H of optimizer.py:161-184; dx agrees to ~1e-12 relative. */
 int dsp_batch_set_solver(dsp_batch* b, int mode);
 /* HIP events around every decoder launch, i.e. the dsp_stats.ms_mlp_* fields: -1 = automatic (on for batches of more than 16 objects --
  * the bench's roofline needs them; off for latency-sized batches, where an event record between two kernels is a queue packet of its own),

@@ -87,3 +87,57 @@ def ldl_solve(H, b):
                 cc = A[i, j] if j < i else 0.0
                 w[lane, s] = w[lane, s] - cc * xi
     return dx, False
+
+
+def solve_rows_in_lanes(H, b):
+    """k_solve<2> (default): the factorisation with rows in lanes.  Wave w < 9 owns columns 8w .. 8w+7; lane l holds v0[jj] =
+    A[l][8w+jj] (rows 0 .. 63) and vx = A[64 + (l & 7)][8w + (l >> 3)] (rows 64 .. 71).  Per step a wave reads its rows' entries of column
+    k (ci0, cix) and vx's column entry (cjx) from LDS; the pivot and the eight column entries c_jk are other lanes' values of ci0 / cix
+    (v_readlane).  Every row except the pivot row is eliminated (Gauss-Jordan on the symmetric trailing part), so column n ends as
+    d_i dx_i and there is no back substitution.  Waves whose columns are all <= k skip the step.  Column k + 1 is published by its owner
+    for all rows.  Rows and columns beyond the system (n = 6: everything past index 6) hold garbage -- NaN here -- that must stay where
+    it is."""
+    n = H.shape[0]
+    A = np.full((NS1, NS1 + 1), np.nan)
+    A[:n, :n] = H
+    A[:n, n] = b
+    A[n, :n] = A[:n, n]
+    rdv = np.full(NS1, np.nan)
+    lanes = np.arange(64)
+    xr, xj = 64 + (lanes & 7), lanes >> 3
+    v0 = [np.array([[A[l, 8 * w + jj] for jj in range(8)] for l in lanes]) for w in range(9)]          # [w][lane, jj]
+    vx = [np.array([A[xr[l], 8 * w + xj[l]] for l in lanes]) for w in range(9)]
+    sing = False
+    with np.errstate(invalid="ignore"):
+        for k in range(n):
+            col = A[:, k].copy()                              # barrier: what the waves read this step
+            for w in range(9):
+                if not 8 * w + 7 > k:
+                    continue
+                ci0, cix, cjx = col[lanes], col[xr], col[8 * w + xj]
+                d = (cix if k >= 64 else ci0)[k & 63]
+                rdk = fast_recip(d)
+                if w == 8:
+                    sing = sing or not (d > 0.0)
+                    rdv[k] = rdk
+                csrc, cbase = (cix, 0) if w == 8 else (ci0, 8 * w)
+                l0 = np.where(lanes == k, 0.0, ci0 * rdk)
+                lx = np.where(xr == k, 0.0, cix * rdk)
+                for jj in range(8):
+                    v0[w][:, jj] = v0[w][:, jj] - l0 * csrc[cbase + jj]
+                vx[w] = vx[w] - lx * cjx
+                if w == (k + 1) >> 3:
+                    tn = (k + 1) & 7
+                    A[lanes, k + 1] = v0[w][:, tn]
+                    sel = xj == tn
+                    A[xr[sel], k + 1] = vx[w][sel]
+    if sing:
+        return None, True
+    wn, jn = n >> 3, n & 7
+    dx = np.zeros(n)
+    for i in range(min(n, 64)):
+        dx[i] = v0[wn][i, jn] * rdv[i]
+    for l in lanes:
+        if xj[l] == jn and xr[l] < n:
+            dx[xr[l]] = vx[wn][l] * rdv[xr[l]]
+    return dx, False

@@ -102,8 +102,13 @@ def test_ldl_solver_equals_gauss_jordan(eng):
     n_it = 5
     prm = E.gn_params(num_iterations=n_it)
     objs = synth.make_batch(4, first_seed=2100, n_surface=300, n_background=120)
-    a = _run_traced(eng, prm, objs, n_it, solver=0)
+    a = _run_traced(eng, prm, objs, n_it, solver=2)
     c = _run_traced(eng, prm, objs, n_it, solver=1)
+    # the packed LDL^T form (solver 0, first round-4 form): same pivots, dx from a back substitution instead of the elimination above the diagonal
+    p0 = _run_traced(eng, prm, objs, n_it, solver=0)
+    assert np.array_equal(a[1][0]["H"], p0[1][0]["H"]) and np.array_equal(a[0][3], p0[0][3])
+    d0 = float((np.abs(a[1][0]["dx"] - p0[1][0]["dx"]) / np.abs(p0[1][0]["dx"]).max(axis=1, keepdims=True)).max())
+    assert d0 <= 2.5e-7, d0
     assert np.array_equal(a[0][3], c[0][3]) and (a[0][3] == 0).all()
     assert np.array_equal(a[1][0]["H"], c[1][0]["H"]) and np.array_equal(a[1][0]["b"], c[1][0]["b"])
     worst = 0.0
@@ -111,7 +116,8 @@ def test_ldl_solver_equals_gauss_jordan(eng):
         sc = np.abs(tc["dx"]).max(axis=1, keepdims=True)
         worst = max(worst, float((np.abs(ta["dx"] - tc["dx"]) / sc).max()))
     first = float((np.abs(a[1][0]["dx"] - c[1][0]["dx"]) / np.abs(c[1][0]["dx"]).max(axis=1, keepdims=True)).max())
-    parity_log(kind="solver_ab", case="LDL^T vs Gauss-Jordan", rel_dx_first_iteration=first, rel_dx_all_iterations=worst)
+    parity_log(kind="solver_ab", case="rows-in-lanes elimination vs Gauss-Jordan (round 3) and packed LDL^T", rel_dx_first_iteration=first, rel_dx_all_iterations=worst,
+               rel_dx_first_iteration_vs_packed_ldl=d0)
     assert first <= 2.5e-7, first          # one float32 ulp of the largest entry, from identical H and b
     assert worst <= 1e-4, worst            # later iterations: a propagated last-bit difference of the state
     assert np.abs(a[0][0] - c[0][0]).max() <= 1e-4 * np.abs(c[0][0]).max() and np.abs(a[0][1] - c[0][1]).max() <= 1e-4

@@ -31,11 +31,12 @@ for name, (M, Bg) in (("KITTI-size 250+200", (250, 200)), ("cfg2-size 2000+500",
     o = synth.make_object(4242 if M == 250 else 1, n_surface=M, n_background=Bg)
     args = ([o["t_cam_obj_init"]], [o["pts"]], [o["rays"]], [o["depth"]])
     print("## %s" % name)
-    variants = [("automatic (cluster tiles, wave bookkeeping, LDL^T, no per-kernel events)", {}),
+    variants = [("automatic (cluster tiles, wave bookkeeping, blocked LDL^T, no per-kernel events)", {}),
                 ("one workgroup per jacobian tile (cluster form off)", dict(cluster_tiles=0)),
                 ("render rows repeat their forward sweep (mixed mask reuse off)", dict(mixed_reuse=0)),
                 ("fused per-object bookkeeping (round 3)", dict(fused_bookkeeping=1)),
                 ("throughput bookkeeping", dict(fused_bookkeeping=0)),
+                ("packed LDL^T solve (first round-4 form)", dict(solver=0)),
                 ("Gauss-Jordan solve (round 3)", dict(solver=1)),
                 ("per-kernel events on", dict(kernel_timing=1)),
                 ("round-3 equivalent: fused=1 (or 0 for large), GJ, events on, no clusters", dict(fused_bookkeeping=1 if M == 250 else 0, solver=1, kernel_timing=1, cluster_tiles=0, mixed_reuse=0)),

@@ -24,4 +24,6 @@ if lib.dsp_debug_solve_clocks(eng._h, clk) == 0:
     c = list(clk)
     print("k_solve stages (us): setup %.1f, eliminate %.1f, divide+update+exp %.1f, derive_iter_state %.1f" % (
         (c[1] - c[0]) / 100.0, (c[2] - c[1]) / 100.0, (c[3] - c[2]) / 100.0, (c[4] - c[3]) / 100.0))
+    if c[7] > c[1]:
+        print("   eliminate = factorisation %.1f + back substitution %.1f" % ((c[7] - c[1]) / 100.0, (c[2] - c[7]) / 100.0))
     print("   shader clock during the elimination: %.0f MHz (%d cycles)" % ((c[6] - c[5]) / ((c[2] - c[1]) / 100.0), c[6] - c[5]))
