@@ -1122,13 +1122,14 @@ __device__ __forceinline__ void build_row(const float* g68, float4 p, float2 aux
     row[71] = rr;
 }
 
-constexpr int GRAM_PTS = 32;    // points staged per step
+constexpr int GRAM_PTS = 32;    // granularity of a slice's share of the rows (part of the summation grouping: do not change)
+constexpr int GRAM_SUB = 4;     // row groups of GRAM_PTS staged per barrier pair: the loads of all of them are in flight together
 constexpr int JLD = 73;         // LDS row stride (odd: conflict-free column access)
 
 __global__ __launch_bounds__(256) void k_gram(const ObjConst* oc, const ObjState* st, const float4* jpts, const float2* jaux,
                                               const float* jgrad, const int* jrow, const unsigned char* alive, float* partials, int n_slices,
                                               float b_sdf, float b_render, int robust) {
-    __shared__ float J[GRAM_PTS * JLD];
+    __shared__ float J[GRAM_SUB * GRAM_PTS * JLD];
     const int slice = blockIdx.x, b = blockIdx.y, term = blockIdx.z;
     const ObjConst c = oc[b];
     const ObjState& s = st[b];
@@ -1146,58 +1147,80 @@ __global__ __launch_bounds__(256) void k_gram(const ObjConst* oc, const ObjState
 #pragma unroll
         for (int j = 0; j < 6; ++j) acc[i][j] = 0.f;
     const float hb = (term == 0) ? b_sdf : b_render;
-    for (int p0 = lo; p0 < hi; p0 += GRAM_PTS) {
-        const int np = min(GRAM_PTS, hi - p0);
+    for (int p0 = lo; p0 < hi; p0 += GRAM_SUB * GRAM_PTS) {
+        const int np = min(GRAM_SUB * GRAM_PTS, hi - p0);
         __syncthreads();
-        {   // stage GRAM_PTS rows: 8 threads per row (the 64 code columns in eighths; the first of them also the 7 pose columns and the
-            // residual) -- build_row's arithmetic, spread over the workgroup instead of 32 threads building 72 entries each from 68
-            // dependent-latency loads (round 4: 12.7 -> ~7 us per iteration at detection size, 50 -> ~25 us at cfg2 size)
-            const int r = tid >> 3, part = tid & 7;
-            float* row = J + r * JLD;
-            if (r < np && (alive == nullptr || term != 0 || alive[off + p0 + r])) {
-                const int idx = off + p0 + r;
-                const int gi = (term == 1 && jrow) ? jrow[idx] : idx;     // speculative band rows: the gradient stays where the launch wrote it
-                const float* g68 = jgrad + (size_t)gi * GRAD_STRIDE;
-                const float2 aux = jaux[idx];
-                const float sc = aux.x;                                    // de_ds (render) or 1 (sdf)
-                const float4 ga = *reinterpret_cast<const float4*>(g68 + 8 * part), gb = *reinterpret_cast<const float4*>(g68 + 8 * part + 4);
-                float* rc = row + 7 + 8 * part;
-                rc[0] = __fmul_rn(sc, ga.x); rc[1] = __fmul_rn(sc, ga.y); rc[2] = __fmul_rn(sc, ga.z); rc[3] = __fmul_rn(sc, ga.w);
-                rc[4] = __fmul_rn(sc, gb.x); rc[5] = __fmul_rn(sc, gb.y); rc[6] = __fmul_rn(sc, gb.z); rc[7] = __fmul_rn(sc, gb.w);
-                if (part == 0) {
-                    const float4 gx = *reinterpret_cast<const float4*>(g68 + 64);      // d sdf / d xyz, sdf
-                    const float4 p = jpts[idx];
-                    const float res = (term == 0) ? gx.w : aux.y;   // sdf term: residual is the sdf itself (loss.py:34,43)
-                    const float d0 = __fmul_rn(sc, gx.x), d1 = __fmul_rn(sc, gx.y), d2 = __fmul_rn(sc, gx.z);
-                    row[0] = d0; row[1] = d1; row[2] = d2;
-                    // [I | -[p]x | p]  (loss_utils.py:166-185)
-                    row[3] = __fadd_rn(__fmul_rn(-p.z, d1), __fmul_rn(p.y, d2));
-                    row[4] = __fadd_rn(__fmul_rn(p.z, d0), __fmul_rn(-p.x, d2));
-                    row[5] = __fadd_rn(__fmul_rn(-p.y, d0), __fmul_rn(p.x, d1));
-                    row[6] = __fadd_rn(__fadd_rn(__fmul_rn(p.x, d0), __fmul_rn(p.y, d1)), __fmul_rn(p.z, d2));
-                    float rr = res;
-                    if (robust) {   // huber_norm_weights: w = sqrt(rho)/|r|, only the residual is reweighted (loss_utils.py:236-265)
-                        const float a = fabsf(res);
-                        const float rho = (a <= hb) ? __fmul_rn(a, a) : __fsub_rn(__fmul_rn(__fmul_rn(2.f, hb), a), __fmul_rn(hb, hb));
-                        const float w = (a == 0.f) ? 0.f : __fdiv_rn(__fsqrt_rn(rho), a);
-                        rr = __fmul_rn(w, res);
+        {   // stage up to 128 rows: 8 threads per row (the 64 code columns in eighths; the first of them also the 7 pose columns and the
+            // residual) -- build_row's arithmetic, spread over the workgroup.  A detection-sized slice (<= 128 rows) is ONE round of
+            // loads, all in flight together, instead of one dependent global round trip per 32 rows (14 -> ~7 us per iteration).
+            const int r0 = tid >> 3, part = tid & 7;
+            float4 ga[GRAM_SUB], gb[GRAM_SUB], gx[GRAM_SUB], pp[GRAM_SUB];
+            float2 aux[GRAM_SUB];
+            bool live[GRAM_SUB];
+#pragma unroll
+            for (int q = 0; q < GRAM_SUB; ++q) {
+                const int r = r0 + GRAM_PTS * q;
+                live[q] = r < np && (alive == nullptr || term != 0 || alive[off + p0 + r]);
+                ga[q] = gb[q] = gx[q] = pp[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                aux[q] = make_float2(0.f, 0.f);
+                if (live[q]) {
+                    const int idx = off + p0 + r;
+                    const int gi = (term == 1 && jrow) ? jrow[idx] : idx;     // speculative band rows: the gradient stays where the launch wrote it
+                    const float* g68 = jgrad + (size_t)gi * GRAD_STRIDE;
+                    aux[q] = jaux[idx];
+                    ga[q] = *reinterpret_cast<const float4*>(g68 + 8 * part);
+                    gb[q] = *reinterpret_cast<const float4*>(g68 + 8 * part + 4);
+                    if (part == 0) {
+                        gx[q] = *reinterpret_cast<const float4*>(g68 + 64);      // d sdf / d xyz, sdf
+                        pp[q] = jpts[idx];
                     }
-                    row[71] = rr;
                 }
-            } else {
+            }
+#pragma unroll
+            for (int q = 0; q < GRAM_SUB; ++q) {
+                const int r = r0 + GRAM_PTS * q;
+                if (r >= (np + GRAM_PTS - 1) / GRAM_PTS * GRAM_PTS) continue;      // row groups beyond this stage's rows are not read below
+                float* row = J + r * JLD;
                 float* rc = row + 7 + 8 * part;
+                if (live[q]) {
+                    const float sc = aux[q].x;                                    // de_ds (render) or 1 (sdf)
+                    rc[0] = __fmul_rn(sc, ga[q].x); rc[1] = __fmul_rn(sc, ga[q].y); rc[2] = __fmul_rn(sc, ga[q].z); rc[3] = __fmul_rn(sc, ga[q].w);
+                    rc[4] = __fmul_rn(sc, gb[q].x); rc[5] = __fmul_rn(sc, gb[q].y); rc[6] = __fmul_rn(sc, gb[q].z); rc[7] = __fmul_rn(sc, gb[q].w);
+                    if (part == 0) {
+                        const float4 p = pp[q];
+                        const float res = (term == 0) ? gx[q].w : aux[q].y;   // sdf term: residual is the sdf itself (loss.py:34,43)
+                        const float d0 = __fmul_rn(sc, gx[q].x), d1 = __fmul_rn(sc, gx[q].y), d2 = __fmul_rn(sc, gx[q].z);
+                        row[0] = d0; row[1] = d1; row[2] = d2;
+                        // [I | -[p]x | p]  (loss_utils.py:166-185)
+                        row[3] = __fadd_rn(__fmul_rn(-p.z, d1), __fmul_rn(p.y, d2));
+                        row[4] = __fadd_rn(__fmul_rn(p.z, d0), __fmul_rn(-p.x, d2));
+                        row[5] = __fadd_rn(__fmul_rn(-p.y, d0), __fmul_rn(p.x, d1));
+                        row[6] = __fadd_rn(__fadd_rn(__fmul_rn(p.x, d0), __fmul_rn(p.y, d1)), __fmul_rn(p.z, d2));
+                        float rr = res;
+                        if (robust) {   // huber_norm_weights: w = sqrt(rho)/|r|, only the residual is reweighted (loss_utils.py:236-265)
+                            const float a = fabsf(res);
+                            const float rho = (a <= hb) ? __fmul_rn(a, a) : __fsub_rn(__fmul_rn(__fmul_rn(2.f, hb), a), __fmul_rn(hb, hb));
+                            const float w = (a == 0.f) ? 0.f : __fdiv_rn(__fsqrt_rn(rho), a);
+                            rr = __fmul_rn(w, res);
+                        }
+                        row[71] = rr;
+                    }
+                } else {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) rc[i] = 0.f;
-                if (part == 0) {
+                    for (int i = 0; i < 8; ++i) rc[i] = 0.f;
+                    if (part == 0) {
 #pragma unroll
-                    for (int i = 0; i < 7; ++i) row[i] = 0.f;
-                    row[71] = 0.f;
+                        for (int i = 0; i < 7; ++i) row[i] = 0.f;
+                        row[71] = 0.f;
+                    }
                 }
             }
         }
         __syncthreads();
         if (active) {
-            for (int p = 0; p < GRAM_PTS; ++p) {
+            // rows in order; a stage's tail up to the next multiple of GRAM_PTS is zero rows (as every stage of 32 had them before)
+            const int nr = (np + GRAM_PTS - 1) / GRAM_PTS * GRAM_PTS;
+            for (int p = 0; p < nr; ++p) {
                 const float* row = J + p * JLD;
                 float a[4], bb[6];
 #pragma unroll
