@@ -1,12 +1,11 @@
 #!/bin/bash
-# The round's closing GPU sequence (one gpurun call): smoke(), the whole -m gpu suite, the profile sequence.  Outputs under gpurun_out/<tag>/.
+# GPU box, end of round: the whole GPU suite as the driver runs it + smoke, then the profile sequence.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r03}
-OUT=$R/gpurun_out/$TAG
+TAG=${1:-r04}
+OUT=$R/gpurun_out/${TAG}_tests
 mkdir -p $OUT
 cd $R
-rm -f gpurun_out/forensics_*.md
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log
-timeout 1500 python -m pytest tests -m gpu -q > $OUT/gpu_tests.log 2>&1; tail -4 $OUT/gpu_tests.log
-bash tools/run_profiles.sh $TAG > $OUT/run_profiles.log 2>&1; tail -12 $OUT/run_profiles.log | cut -c1-400
+timeout 1800 python -m pytest tests -x -q -m gpu > $OUT/gpu_tests.log 2>&1; echo "gpu tests rc=$?"; tail -6 $OUT/gpu_tests.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $OUT/smoke.log
+bash tools/run_profiles.sh $TAG

@@ -211,7 +211,7 @@ def main():
             table_only("latency_kernel_stats.md"), "", "```"] + tail + ["```", "",
             "Per iteration (%d iterations), us: prepass `mlp_lp_kernel` %.0f; jacobian launch -- cluster form %.0f + latency form %.0f (one of the two does the work);"
             % (n_it, per_it("mlp_lp_kernel"), per_it("mlp_cluster_kernel"), per_it("mlp_split_kernel")),
-            "`k_solve` %.0f (LDL^T; round 3: 74); `k_gram` %.0f + `k_gram_reduce` %.0f; `k_render_scan` %.0f; `k_render_tail_wave` %.0f; `k_front_wave` %.0f; `k_band_wave` %.0f;"
+            "`k_solve` %.0f (fp64 elimination with rows in lanes; round 3: 74); `k_gram` %.0f + `k_gram_reduce` %.0f; `k_render_scan` %.0f; `k_render_tail_wave` %.0f; `k_front_wave` %.0f; `k_band_wave` %.0f;"
             % (per_it("k_solve"), per_it("k_gramE"), per_it("k_gram_reduce"), per_it("k_render_scan"), per_it("k_render_tail_wave"), per_it("k_front_wave"), per_it("k_band_wave")),
             "two `k_build_tiles` %.0f.  Everything that is not a decoder launch or the solve: **%.0f us per iteration = %.2f ms per call** (round 3: 126 us / 1.26 ms)."
             % (per_it("k_build_tiles"), 1e3 * book / n_it, book / runs), "",
