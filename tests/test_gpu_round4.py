@@ -78,6 +78,33 @@ def test_wave_bookkeeping_is_exact(eng, prepass):
         assert one[2][2]["n_mlp_fwd_launches"] == 0 and one[2][2]["n_mlp_jac_launches"] == n_it
 
 
+def test_tail_tiles_are_exact_and_repeatable(eng):
+    """The tile lists behind k_front_wave / k_band_wave are built by the LAST workgroup of those kernels (a grid-wide ticket, no launch of
+    their own): same lists, hence every bit equal to the form with k_build_tiles launches -- and, because a stale read of another
+    workgroup's counter would show up as a short list only now and then, twenty runs in a row of a ragged batch (one object fails the
+    '< 10 samples' rule inside the fused builder) and of a single detection."""
+    n_it = 3
+    prm = E.gn_params(num_iterations=n_it)
+    objs = synth.make_batch(7, first_seed=2300, n_surface=250, n_background=200)
+    bad = synth.make_object(2310, 60, 20)
+    bad["t_cam_obj_init"] = bad["t_cam_obj_init"].copy()
+    bad["t_cam_obj_init"][:3, 3] += 500.0
+    objs.insert(4, bad)
+    good = np.array([0, 1, 2, 3, 5, 6, 7])
+    for batch, rows in ((objs, good), (objs[:1], np.array([0]))):
+        ref = _run_traced(eng, prm, batch, n_it, tail_tiles=0)
+        b = eng.batch(prm, *_args(batch), trace=True)
+        b.set_tail_tiles(1)
+        for rep in range(20):
+            b.run()
+            got = (b.results(), [b.trace(e) for e in range(n_it)], b.stats())
+            _assert_same_bits(ref, got, rows, "tail tiles, run %d" % rep)
+            for k in ("n_fwd_points", "n_jac_points", "n_insphere_points", "n_prepass_points"):
+                assert ref[2][k] == got[2][k], (rep, k)
+        b.close()
+    assert list(ref[0][3]) == [0]
+
+
 def test_wave_bookkeeping_on_a_full_size_object(eng):
     """One cfg2-size object (2500 rays x 50: not speculative, adaptive front-to-back prepass passes whose scan shares ObjState::P with
     k_band_wave's running counter) and the full-size golden: wave form == throughput form, bit for bit."""
