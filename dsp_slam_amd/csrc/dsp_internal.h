@@ -227,20 +227,10 @@ void launch_render_tail_fused(const ObjConst* oc, ObjState* st, const int* raycn
                               int B, hipStream_t s);
 // wave-per-ray forms of the three fused stages (one wave per ray, 16 rays per workgroup, whole chip): list segments from running counters
 // (ObjState::V / ::P) instead of scans; kept rows stay in ray-major order.  See gn_kernels.hip.
-// the tile list that follows a wave-form kernel, built by that kernel's last workgroup (gn_kernels.hip: tiles_tail): the arguments of
-// launch_build_tiles + a ticket word that is zero when the kernel starts
-struct FusedTiles {
-    unsigned* ticket;
-    int mode;
-    int4* tiles;
-    int* n_tiles;
-    double* counters;
-    int add_v, tile_pts, cnt_slot, apply_few;
-};
 void launch_front_wave(const ObjConst* oc, ObjState* st, const float* rays, const float* pts, unsigned long long* raymask, int* raycnt, int* rayoff,
-                       float4* spts, float* ssdf, unsigned char* alive, float4* jpts, float2* jaux, int D, int maxR, int maxM, int B, hipStream_t s, const FusedTiles* ft = nullptr);
+                       float4* spts, float* ssdf, unsigned char* alive, float4* jpts, float2* jaux, int D, int maxR, int maxM, int B, hipStream_t s);
 void launch_band_wave(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff, const float* ssdf, float th, unsigned guard_salt,
-                      int* plist, const float4* spts, float4* jpts, int* srow, int maxR, int B, hipStream_t s, const FusedTiles* ft = nullptr);   // jpts / srow: speculative band rows (or null)
+                      int* plist, const float4* spts, float4* jpts, int* srow, int maxR, int B, hipStream_t s);   // jpts / srow: speculative band rows (or null)
 void launch_render_tail_wave(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff, const float4* spts, const float* sdeds,
                              const float* ray_res, const int* kcnt, const int* mcnt, float4* jpts, float2* jaux, const int* srow, int* jrow, int maxR, int B,
                              hipStream_t s);

@@ -490,16 +490,14 @@ __global__ void k_surface(const ObjConst* oc, const ObjState* st, const float* p
 // ------------------------------------------------------------------------------------------------
 // tile lists for the decoder kernels (single workgroup; counts live on the device)
 // ------------------------------------------------------------------------------------------------
-template <int NT>      // threads of the workgroup that runs it: 256 as a kernel of its own, WAVE_THREADS as the tail of a wave-form kernel
-__device__ __forceinline__ void build_tiles_body(const ObjConst* oc, ObjState* st, int n_obj, int mode, int4* tiles,
-                                                 int* n_tiles, double* counters, int add_v, int tile_pts, int cnt_slot, int apply_few) {
-    constexpr int NW = NT / 64;
+__global__ __launch_bounds__(256) void k_build_tiles(const ObjConst* oc, ObjState* st, int n_obj, int mode, int4* tiles,
+                                                     int* n_tiles, double* counters, int add_v, int tile_pts, int cnt_slot, int apply_few) {
     // mode 0: forward tiles over the V in-sphere samples; mode 1: jacobian tiles over M surface + K render points;
     // mode 2: forward tiles over the P samples selected for the current front-to-back pass (indexed through plist)
-    // One thread per object (rounds of NT): tile counts, a block-wide exclusive scan for the list offsets, then the waves
+    // One thread per object (rounds of 256): tile counts, a block-wide exclusive scan for the list offsets, then the four waves
     // fill the objects' tile entries side by side -- same lists, in the same order, as walking the objects one by one.
-    __shared__ int s_n[NT], s_off[NT], s_base[NT], s_part[NW];
-    __shared__ double s_red[3][NW];
+    __shared__ int s_n[256], s_off[256], s_base[256], s_part[8];
+    __shared__ double s_red[3][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double cnt = 0.0, vtot = 0.0, rows = 0.0;       // per-thread partial sums of integers: exact in any order
     int base = 0, n_surface_tiles = 0;
@@ -507,7 +505,7 @@ __device__ __forceinline__ void build_tiles_body(const ObjConst* oc, ObjState* s
     // (forward+backward / backward-only) each take one contiguous range
     const bool jac = mode == 1 || mode == 3;   // mode 3: the band samples (P) stand in for the kept render rows (K): speculative band rows
     for (int phase = 0; phase < (jac ? 2 : 1); ++phase) {
-        for (int b0 = 0; b0 < n_obj; b0 += NT) {
+        for (int b0 = 0; b0 < n_obj; b0 += 256) {
             const int b = b0 + tid;
             int n = 0, off = 0;
             if (b < n_obj) {
@@ -542,7 +540,7 @@ __device__ __forceinline__ void build_tiles_body(const ObjConst* oc, ObjState* s
             __syncthreads();
             int before = 0, total = 0;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) {
+            for (int w = 0; w < 4; ++w) {
                 const int pw = s_part[w];
                 if (w < wave) before += pw;
                 total += pw;
@@ -551,8 +549,8 @@ __device__ __forceinline__ void build_tiles_body(const ObjConst* oc, ObjState* s
             s_off[tid] = off;
             s_base[tid] = base + before + incl - nt;
             __syncthreads();
-            const int in_round = min(NT, n_obj - b0);
-            for (int j = wave; j < in_round; j += NW) {
+            const int in_round = min(256, n_obj - b0);
+            for (int j = wave; j < in_round; j += 4) {
                 const int nj = s_n[j], oj = s_off[j], bj = s_base[j];
                 const int ntj = (nj + tile_pts - 1) / tile_pts;
                 for (int i = lane; i < ntj; i += 64) tiles[bj + i] = make_int4(oj + i * tile_pts, min(tile_pts, nj - i * tile_pts), b0 + j, 0);
@@ -572,47 +570,10 @@ __device__ __forceinline__ void build_tiles_body(const ObjConst* oc, ObjState* s
     if (tid == 0) {
         n_tiles[0] = base;
         if (jac) n_tiles[1] = n_surface_tiles;
-        double r0 = 0.0, r1 = 0.0, r2 = 0.0;          // sums of integers: exact in any order
-        for (int w = 0; w < NW; ++w) { r0 += s_red[0][w]; r1 += s_red[1][w]; r2 += s_red[2][w]; }
-        counters[jac ? 1 : cnt_slot] += r0;
-        if (add_v) counters[2] += r1;
-        if (jac) counters[3] += r2;
+        counters[jac ? 1 : cnt_slot] += s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+        if (add_v) counters[2] += s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+        if (jac) counters[3] += s_red[2][0] + s_red[2][1] + s_red[2][2] + s_red[2][3];
     }
-}
-
-__global__ __launch_bounds__(256) void k_build_tiles(const ObjConst* oc, ObjState* st, int n_obj, int mode, int4* tiles,
-                                                     int* n_tiles, double* counters, int add_v, int tile_pts, int cnt_slot, int apply_few) {
-    build_tiles_body<256>(oc, st, n_obj, mode, tiles, n_tiles, counters, add_v, tile_pts, cnt_slot, apply_few);
-}
-
-// The tile list that follows a wave-form kernel, built by that kernel's LAST workgroup instead of a launch of its own (a single-workgroup
-// kernel between two others costs ~4.6 us + a kernel boundary, twice per iteration of a detection).  Every workgroup of the grid -- the
-// ones with nothing to do included -- takes a ticket once its own stores are out; the one that draws the last ticket sees, behind an
-// acquire fence, everything the others wrote (the running counters ObjState::V / ::P are device-scope atomics), resets the ticket for the
-// next launch and runs build_tiles_body.  ticket == nullptr: not fused (the host launches k_build_tiles).
-struct TilesTail {
-    unsigned* ticket;
-    int n_obj, mode;
-    int4* tiles;
-    int* n_tiles;
-    double* counters;
-    int add_v, tile_pts, cnt_slot, apply_few;
-};
-
-template <int NT>
-__device__ __forceinline__ void tiles_tail(const ObjConst* oc, ObjState* st, const TilesTail& t) {
-    if (!t.ticket) return;                          // uniform
-    __shared__ int s_last;
-    __syncthreads();                                // the workgroup's stores are issued ...
-    if (threadIdx.x == 0) {
-        __threadfence();                            // ... and visible device-wide before the ticket is
-        s_last = atomicAdd(t.ticket, 1u) == gridDim.x * gridDim.y - 1u ? 1 : 0;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();                                // acquire: nothing below may be served from a line cached before the others finished
-    if (threadIdx.x == 0) *t.ticket = 0u;
-    build_tiles_body<NT>(oc, st, t.n_obj, t.mode, t.tiles, t.n_tiles, t.counters, t.add_v, t.tile_pts, t.cnt_slot, t.apply_few);
 }
 
 // Tail split of a forward tile list (latency-sized batches): a launch of T 64-point tiles on n_cu CUs takes ceil(T / n_cu) rounds of
@@ -962,9 +923,9 @@ __device__ __forceinline__ int wave_segment(int* counter, int* s_cnt, int* s_bas
 
 // k_sample_count + k_sample_write + k_surface (the scan is replaced by the running counter ObjState::V, zero at the start of an
 // iteration; the "< 10 samples" rule of loss.py:73-74 is applied by the tile builder that follows, k_build_tiles apply_few)
-__device__ __forceinline__ void front_wave_body(const ObjConst* oc, ObjState* st, const float* __restrict__ rays, const float* pts,
-                                                unsigned long long* raymask, int* raycnt, int* rayoff, float4* spts, float* ssdf,
-                                                unsigned char* alive, float4* jpts, float2* jaux, int n_depth, int n_ray_blocks) {
+__global__ __launch_bounds__(WAVE_THREADS) void k_front_wave(const ObjConst* oc, ObjState* st, const float* __restrict__ rays, const float* pts,
+                                                             unsigned long long* raymask, int* raycnt, int* rayoff, float4* spts, float* ssdf,
+                                                             unsigned char* alive, float4* jpts, float2* jaux, int n_depth, int n_ray_blocks) {
     __shared__ int s_cnt[WAVE_RAYS], s_base;
     __shared__ unsigned s_hash[WAVE_RAYS];
     const int b = blockIdx.y;
@@ -1013,19 +974,11 @@ __device__ __forceinline__ void front_wave_body(const ObjConst* oc, ObjState* st
     }
 }
 
-__global__ __launch_bounds__(WAVE_THREADS) void k_front_wave(const ObjConst* oc, ObjState* st, const float* __restrict__ rays, const float* pts,
-                                                             unsigned long long* raymask, int* raycnt, int* rayoff, float4* spts, float* ssdf,
-                                                             unsigned char* alive, float4* jpts, float2* jaux, int n_depth, int n_ray_blocks,
-                                                             TilesTail tail) {
-    front_wave_body(oc, st, rays, pts, raymask, raycnt, rayoff, spts, ssdf, alive, jpts, jaux, n_depth, n_ray_blocks);
-    tiles_tail<WAVE_THREADS>(oc, st, tail);
-}
-
 // k_band_count + k_band_write (+ the speculative band rows of k_band_fused): the selection of band_select_thread with lane = depth
 // index; list slots from the running counter ObjState::P (zero at the start of an iteration)
-__device__ __forceinline__ void band_wave_body(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff,
-                                               const float* ssdf, float th, unsigned salt, int* plist, const float4* spts, float4* jpts,
-                                               int* srow) {
+__global__ __launch_bounds__(WAVE_THREADS) void k_band_wave(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff,
+                                                            const float* ssdf, float th, unsigned salt, int* plist, const float4* spts, float4* jpts,
+                                                            int* srow) {
     __shared__ int s_cnt[WAVE_RAYS], s_base;
     const int b = blockIdx.y;
     const ObjConst c = oc[b];
@@ -1064,13 +1017,6 @@ __device__ __forceinline__ void band_wave_body(const ObjConst* oc, ObjState* st,
             srow[idx] = c.jren_off + pos;
         }
     }
-}
-
-__global__ __launch_bounds__(WAVE_THREADS) void k_band_wave(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff,
-                                                            const float* ssdf, float th, unsigned salt, int* plist, const float4* spts, float4* jpts,
-                                                            int* srow, TilesTail tail) {
-    band_wave_body(oc, st, raymask, rayoff, ssdf, th, salt, plist, spts, jpts, srow);
-    tiles_tail<WAVE_THREADS>(oc, st, tail);
 }
 
 // k_scan_rays(1) + k_sum_m + k_render_write behind k_render_scan: 64 rays per workgroup (16 waves x 4); the rows keep ray-major,
@@ -1959,25 +1905,16 @@ void launch_render_tail_fused(const ObjConst* oc, ObjState* st, const int* raycn
     hipLaunchKernelGGL(k_render_tail_fused, dim3(B), dim3(FUSED_THREADS), 0, s, oc, st, raycnt, rayoff, spts, sdeds, ray_res, kcnt, koff, mcnt, jpts, jaux,
                        srow, jrow);
 }
-static TilesTail tiles_tail_of(const FusedTiles* ft, int B) {
-    TilesTail t{};
-    if (ft && ft->ticket) {
-        t.ticket = ft->ticket; t.n_obj = B; t.mode = ft->mode; t.tiles = ft->tiles; t.n_tiles = ft->n_tiles; t.counters = ft->counters;
-        t.add_v = ft->add_v; t.tile_pts = ft->tile_pts; t.cnt_slot = ft->cnt_slot; t.apply_few = ft->apply_few;
-    }
-    return t;
-}
 void launch_front_wave(const ObjConst* oc, ObjState* st, const float* rays, const float* pts, unsigned long long* raymask, int* raycnt, int* rayoff,
-                       float4* spts, float* ssdf, unsigned char* alive, float4* jpts, float2* jaux, int D, int maxR, int maxM, int B, hipStream_t s,
-                       const FusedTiles* ft) {
+                       float4* spts, float* ssdf, unsigned char* alive, float4* jpts, float2* jaux, int D, int maxR, int maxM, int B, hipStream_t s) {
     const int nrb = std::max(1, (maxR + WAVE_RAYS - 1) / WAVE_RAYS), nsb = (maxM + WAVE_THREADS - 1) / WAVE_THREADS;
     hipLaunchKernelGGL(k_front_wave, dim3((unsigned)(nrb + nsb), (unsigned)B), dim3(WAVE_THREADS), 0, s, oc, st, rays, pts, raymask, raycnt, rayoff, spts, ssdf, alive,
-                       jpts, jaux, D, nrb, tiles_tail_of(ft, B));
+                       jpts, jaux, D, nrb);
 }
 void launch_band_wave(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff, const float* ssdf, float th, unsigned guard_salt,
-                      int* plist, const float4* spts, float4* jpts, int* srow, int maxR, int B, hipStream_t s, const FusedTiles* ft) {
+                      int* plist, const float4* spts, float4* jpts, int* srow, int maxR, int B, hipStream_t s) {
     hipLaunchKernelGGL(k_band_wave, dim3((unsigned)std::max(1, (maxR + WAVE_RAYS - 1) / WAVE_RAYS), (unsigned)B), dim3(WAVE_THREADS), 0, s, oc, st, raymask, rayoff,
-                       ssdf, th, guard_salt, plist, spts, jpts, srow, tiles_tail_of(ft, B));
+                       ssdf, th, guard_salt, plist, spts, jpts, srow);
 }
 void launch_render_tail_wave(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff, const float4* spts, const float* sdeds,
                              const float* ray_res, const int* kcnt, const int* mcnt, float4* jpts, float2* jaux, const int* srow, int* jrow, int maxR, int B,

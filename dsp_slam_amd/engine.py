@@ -59,6 +59,7 @@ class Batch(object):
                                      L.ptr(r), L.ptr(do, L.c_i64p), L.ptr(d), L.ptr(t), L.ptr(c), C.byref(self._h)),
                 engine._h, "dsp_batch_create")
         self.iters = prm.num_iterations
+        engine._batches.add(self)          # Engine.close() closes its live batches first: a batch must not outlive its handle
         if trace:
             L.check(lib.dsp_batch_enable_trace(self._h, 1), engine._h, "dsp_batch_enable_trace")
 
@@ -135,10 +136,6 @@ class Batch(object):
     def set_tail_split(self, mode):
         """-1 = automatic, 0 = off, 1 = the last partial round of the fp32 forward launch runs as 16-point latency-form tiles."""
         L.check(L.load().dsp_batch_set_tail_split(self._h, int(mode)), self.engine._h, "dsp_batch_set_tail_split")
-
-    def set_tail_tiles(self, mode):
-        """-1 automatic / 1: the tile lists of the wave bookkeeping are built by the producing kernel's last workgroup; 0: launches of their own."""
-        L.check(L.load().dsp_batch_set_tail_tiles(self._h, int(mode)), self.engine._h, "dsp_batch_set_tail_tiles")
 
     def set_solver(self, mode):
         """0 = LDL^T (default), 1 = pivot-free Gauss-Jordan (the round-2/3 kernel, kept as the A/B reference)."""
@@ -263,6 +260,7 @@ class Engine(object):
         """layers: list of (W (out,in), b (out,)) float32 with weight-norm already folded."""
         lib = L.load()
         self._desc = L.DecoderDescHolder(layers, latent_in, code_len)
+        self._batches = weakref.WeakSet()
         self._h = C.c_void_p()
         rc = lib.dsp_create(C.byref(self._desc.desc), int(device), C.byref(self._h))
         if rc != 0:
@@ -419,6 +417,8 @@ class Engine(object):
 
     def close(self):
         if self._h:
+            for b in list(self._batches):      # dsp_batch_destroy takes the handle's mutex: never after dsp_destroy
+                b.close()
             L.load().dsp_destroy(self._h)
             self._h = C.c_void_p()
 
