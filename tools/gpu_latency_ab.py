@@ -31,7 +31,7 @@ for name, (M, Bg) in (("KITTI-size 250+200", (250, 200)), ("cfg2-size 2000+500",
     o = synth.make_object(4242 if M == 250 else 1, n_surface=M, n_background=Bg)
     args = ([o["t_cam_obj_init"]], [o["pts"]], [o["rays"]], [o["depth"]])
     print("## %s" % name)
-    variants = [("automatic (cluster tiles, wave bookkeeping, blocked LDL^T, no per-kernel events)", {}),
+    variants = [("automatic (cluster tiles, wave bookkeeping, rows-in-lanes solve, no events)    ", {}),
                 ("one workgroup per jacobian tile (cluster form off)", dict(cluster_tiles=0)),
                 ("render rows repeat their forward sweep (mixed mask reuse off)", dict(mixed_reuse=0)),
                 ("fused per-object bookkeeping (round 3)", dict(fused_bookkeeping=1)),
