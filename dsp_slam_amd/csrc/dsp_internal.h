@@ -88,6 +88,7 @@ struct MlpArgs {
     int split_min_tiles;        //   ... and the latency form (mlp_split_kernel<true>) lists of at least this many (0 = always)
 };
 constexpr int CL_EPOCH_STRIDE = 4096;      // exchanges a launch may count: 15 per tile and cluster
+constexpr int CL_XCH_UNITS = 16 * 3;         // tagged 16-byte units per lane in one parity of a cluster's global exchange buffer (mlp_cluster_kernel.hip)
 
 
 // ---- low-precision prepass (mlp_lp_kernel.hip): f16 / bf16 MFMA forward used ONLY to classify ray samples ------------

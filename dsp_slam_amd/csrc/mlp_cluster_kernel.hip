@@ -7,15 +7,19 @@
 // four workgroups (16 waves, two 16-row tiles each, 256 MFMAs per wave and layer pass instead of 1024) and the layer's [512 x 16] result
 // is handed round the cluster through L2 / Infinity Cache after every pass:
 //
-//   own rows -> LDS (the three sibling waves on this CU) and, write-through (sc1), -> the cluster's exchange buffer in global memory;
-//   s_waitcnt vmcnt(0); ONE relaxed agent-scope flag store per wave (the wave's exchange counter);
-//   waves 0..2 of every workgroup each wait for the four flags of ONE remote workgroup (relaxed polls), fetch its eight row tiles with
-//   sc1 loads (the producer stored write-through, so no acquire fence is needed: MI355X_MICROARCH.md, "visibility") and drop them into
-//   LDS; barrier; every wave reads the whole slab from LDS, as in the latency form.
+//   own rows -> LDS (the three sibling waves on this CU) and, write-through (sc1), -> the cluster's exchange buffer in global memory, as
+//   16-byte units that carry their own validity: three floats + the exchange counter (a lane's eight floats = three units).  No
+//   s_waitcnt, no flag: a 16-byte store of one lane lands as a whole, so a unit whose tag is the current counter IS the current data;
+//   waves 0..2 of every workgroup each poll the twelve units of ONE remote workgroup (sc1 loads: the producer stored write-through, so
+//   no acquire fence is needed: MI355X_MICROARCH.md, "visibility") until every tag matches, and drop the eight row tiles into LDS;
+//   barrier; every wave reads the whole slab from LDS, as in the latency form.  (Until the last day of round 4 the payload was
+//   followed by s_waitcnt vmcnt(0) + a flag store, and the readers polled the flag before fetching: one store acknowledgement and one
+//   L2 round trip more per hand-off, 16 hand-offs per tile.)
 //
 // Two exchange buffers alternate (a workgroup can only be one exchange ahead of its slowest sibling); counters, not flags: the epoch
-// base of a launch comes from the host, so nothing has to be cleared between launches.  Every spin is bounded: a workgroup that gives
-// up raises the error word, keeps publishing (so that nobody waits for it) and the host falls back to the latency form for the run.
+// base of a launch comes from the host, so nothing has to be cleared between launches (the host clears the buffers when its 32-bit
+// base wraps).  Every spin is bounded: a workgroup that gives up raises the error word, keeps publishing (so that nobody waits for it)
+// and the host falls back to the latency form for the run.
 // Same k order, same bias seeding, same relu masks per output element as mlp_kernel<2> / mlp_split_kernel<true>: bit-identical
 // gradients (tests/test_gpu_round4.py::test_cluster_kernel_is_exact).
 //
@@ -32,7 +36,8 @@ namespace dsp {
 constexpr int CL_SNB = 5;                                   // per-wave ring depth in mini-chunks
 constexpr int CL_MINI = 4096;                               // 4 k-step pairs x 64 lanes x 16 B = 8 k-steps of two row tiles
 constexpr int CL_MASK_BYTES = MASK_SLOTS * 256 * 2;         // [slot][tid] u16: 2 tiles x 4 rows = 8 bits used
-constexpr int CL_XCH_BYTES = 32 * 64 * 16;                  // one layer's output slab: 32 row tiles x 64 lanes x float4
+constexpr int CL_XCH_BYTES = 32 * 64 * 16;                  // one layer's output slab in LDS: 32 row tiles x 64 lanes x float4
+constexpr int CL_XCH_G_BYTES = CL_XCH_UNITS * 64 * 16;      // ... in the global exchange buffer: 16 wave slots x 3 tagged units x 64 lanes x 16 B
 constexpr int CL_RING_BYTES = 4 * CL_SNB * CL_MINI;
 constexpr unsigned CL_SPIN_LIMIT = 1u << 20;                // ~1 s of polling (one L2 round trip + s_sleep per poll): far beyond any healthy wait
 
@@ -92,9 +97,8 @@ __global__ __launch_bounds__(256, 1) void mlp_cluster_kernel(const MlpArgs a) {
 
     // ---- the cluster's exchange buffers and counters ----------------------------------------------------------------------
     // (descriptors from kernel arguments and blockIdx only: wave-uniform by construction)
-    const size_t xb_bytes = (size_t)2 * CL_XCH_BYTES;
+    const size_t xb_bytes = (size_t)2 * CL_XCH_G_BYTES;
     const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.cl_xbuf)) + (size_t)cl * xb_bytes, 0, (int)xb_bytes, 0x00020000);
-    unsigned* flags = a.cl_flags + (size_t)cl * 16;
     unsigned ep = a.cl_epoch_base;              // exchange counter: every wave of the cluster counts the same sequence
     bool dead = false;                           // a spin ran out: publish, never wait again (the host discards the run)
 
@@ -111,40 +115,62 @@ __global__ __launch_bounds__(256, 1) void mlp_cluster_kernel(const MlpArgs a) {
     // tiles 0..3 and the latent_in skip tiles at the top).  Slot = tile index, so tile t always comes from workgroup t / 8.
     auto exchange = [&](const f32x4 (&pub)[2], bool publish, int n_lo, int hi_from) {
         ++ep;
-        const unsigned par = (ep & 1u) * CL_XCH_BYTES;
+        const unsigned par = (ep & 1u) * CL_XCH_G_BYTES;
         lds_barrier();                                     // every wave of this CU is done reading the previous exchange from LDS
         if (publish) {
             xch[(2 * u) * 64 + lane] = pub[0];
             xch[(2 * u + 1) * 64 + lane] = pub[1];
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, pub[0]), xrs, par + ((2 * u) * 64 + lane) * 16, 0, 16);   // aux 16 = sc1: write-through
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, pub[1]), xrs, par + ((2 * u + 1) * 64 + lane) * 16, 0, 16);
+            if (!(a.cl_fault && rank == 3)) {             // (fault injection: a member that never publishes)
+                const unsigned ub = par + ((3 * u) * 64 + lane) * 16;
+                const u32x4_t u0 = {__float_as_uint(pub[0].x), __float_as_uint(pub[0].y), __float_as_uint(pub[0].z), ep};
+                const u32x4_t u1 = {__float_as_uint(pub[0].w), __float_as_uint(pub[1].x), __float_as_uint(pub[1].y), ep};
+                const u32x4_t u2 = {__float_as_uint(pub[1].z), __float_as_uint(pub[1].w), 0u, ep};
+                __builtin_amdgcn_raw_buffer_store_b128(u0, xrs, ub, 0, 16);                 // aux 16 = sc1: write-through
+                __builtin_amdgcn_raw_buffer_store_b128(u1, xrs, ub + 64 * 16, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(u2, xrs, ub + 2 * 64 * 16, 0, 16);
+            }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the payload has left this CU (and the weight ring is drained: stores and LDS-DMA share the counter)
-        if (lane == 0 && !(a.cl_fault && rank == 3)) __hip_atomic_store(flags + u, ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (wave < 3) {                                    // this wave relays ONE remote workgroup's tiles into LDS
             const int r = (rank + 1 + wave) & 3;
+            u32x4_t v[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) v[i] = (u32x4_t){0u, 0u, 0u, 0u};
             if (!dead) {
                 unsigned spins = 0;
                 for (;;) {
-                    const unsigned f = __hip_atomic_load(flags + 4 * r + (lane & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (__all((int)(f - ep) >= 0)) break;
+                    bool ok = true;
+#pragma unroll
+                    for (int sl = 0; sl < 4; ++sl) {       // wave slot 4 r + sl of the remote workgroup = its row tiles 8 r + 2 sl, + 1
+                        const int tl = 8 * r + 2 * sl;
+                        if (tl < n_lo || tl >= hi_from) {
+#pragma unroll
+                            for (int k = 0; k < 3; ++k)
+                                v[3 * sl + k] = __builtin_amdgcn_raw_buffer_load_b128(xrs, par + ((3 * (4 * r + sl) + k) * 64 + lane) * 16, 0, 16);
+                        }
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int sl = 0; sl < 4; ++sl) {
+                        const int tl = 8 * r + 2 * sl;
+                        if (tl < n_lo || tl >= hi_from) ok = ok && v[3 * sl][3] == ep && v[3 * sl + 1][3] == ep && v[3 * sl + 2][3] == ep;
+                    }
+                    if (__all(ok)) break;
                     if (++spins > CL_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(a.cl_err, 1u); break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
             }
-            u32x4_t v[8];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int tl = 8 * r + t;
-                if (tl < n_lo || tl >= hi_from) v[t] = __builtin_amdgcn_raw_buffer_load_b128(xrs, par + (tl * 64 + lane) * 16, 0, 16);
-            }
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int tl = 8 * r + t;
-                if (tl < n_lo || tl >= hi_from) xch[tl * 64 + lane] = __builtin_bit_cast(f32x4, v[t]);
+            for (int sl = 0; sl < 4; ++sl) {
+                const int tl = 8 * r + 2 * sl;
+                if (tl < n_lo || tl >= hi_from) {
+                    xch[tl * 64 + lane] = (f32x4){__uint_as_float(v[3 * sl][0]), __uint_as_float(v[3 * sl][1]), __uint_as_float(v[3 * sl][2]),
+                                                  __uint_as_float(v[3 * sl + 1][0])};
+                    xch[(tl + 1) * 64 + lane] = (f32x4){__uint_as_float(v[3 * sl + 1][1]), __uint_as_float(v[3 * sl + 1][2]), __uint_as_float(v[3 * sl + 2][0]),
+                                                        __uint_as_float(v[3 * sl + 2][1])};
+                }
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own stores out, relayed tiles in -- and the weight ring drained: stores and LDS-DMA share the counter
         lds_barrier();
     };
     // all live tiles of the exchange -> the input slab
