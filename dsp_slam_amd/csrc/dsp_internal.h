@@ -78,12 +78,11 @@ struct MlpArgs {
     const float* wcluster;      //   the same chunks laid out per wave slot (two row tiles, two k-steps per 16-byte element; pack_decoder)
     int cl_off[16];             //   first 4 KiB mini-chunk of wave slot u inside wcluster
     int cl_len[16];             //   mini-chunks slot u consumes per tile (forward + backward)
-    float* cl_xbuf;             //   exchange buffers: [cluster][2][32 row tiles][64 lanes] float4
-    unsigned* cl_flags;         //   exchange counters: [cluster][16 wave slots]
+    float* cl_xbuf;             //   exchange buffers: [cluster][2 parities][16 wave slots x 3 units][64 lanes] x 16 B (3 floats + counter tag)
     unsigned* cl_err;           //   raised when a bounded spin ran out (the host discards the run)
     double* cl_tiles_done;      //   optional: + the list's tile count when the cluster kernel takes it (dsp_stats.n_cluster_tiles)
     unsigned cl_epoch_base;     //   counter value this launch starts from (the host advances it by CL_EPOCH_STRIDE per launch)
-    int cl_fault;               //   fault injection (tests): workgroup 3 of every cluster never raises its counters -> its siblings' bounded spins run out
+    int cl_fault;               //   fault injection (tests): workgroup 3 of every cluster never publishes -> its siblings' bounded spins run out
     int cluster_max_tiles;      //   the cluster kernel runs lists of up to this many tiles ...
     int split_min_tiles;        //   ... and the latency form (mlp_split_kernel<true>) lists of at least this many (0 = always)
 };
