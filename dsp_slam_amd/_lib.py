@@ -95,6 +95,7 @@ SYMBOLS = [
     ("dsp_batch_debug_samples", C.c_int, [_VP, C.c_int32, C.POINTER(C.c_uint64), c_f32p, c_f32p, C.c_int64]),
     ("dsp_batch_set_split_rows", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_set_solver", C.c_int, [_VP, C.c_int]),
+    ("dsp_batch_set_direct_tiles", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_set_cluster_tiles", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_set_mixed_reuse", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_set_kernel_timing", C.c_int, [_VP, C.c_int]),

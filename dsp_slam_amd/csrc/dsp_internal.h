@@ -32,6 +32,19 @@ struct PassDesc {
     int32_t chunk_base; // first chunk of this pass in the packed stream
 };
 
+// Tile list of a ONE-object batch without a list: the decoder kernels derive their tiles from the object's counters themselves (the
+// k_build_tiles launch in front of them goes: 4.6 us + a kernel boundary, twice per iteration of a detection).  kind 0 = off (tiles /
+// n_tiles are read); 1 = forward list over the V in-sphere samples (with the "< 10 samples" rule of loss.py:73-74 and the work
+// counters k_build_tiles mode 0 keeps); 3 = jacobian list, n0 surface points then the P band rows (k_build_tiles mode 3).
+struct ObjState;
+struct DirectTiles {
+    int kind;
+    int off0, n0, off1;         // first point of segment 0 / its length where the host knows it (surface points) / first point of segment 1
+    ObjState* st;               // the object's state: status, V, P
+    double* counters;           // dsp_batch::counters()
+};
+struct DirectList { int n_tiles, nt0, n0, n1; };
+
 struct MlpArgs {
     const float* wstream;       // packed weight stream (fwd passes then bwd passes), chunk-major
     const float* bias_tab;      // [n_bias_rows][512]: hidden biases, last row = final layer weights
@@ -85,6 +98,7 @@ struct MlpArgs {
     int cl_fault;               //   fault injection (tests): workgroup 3 of every cluster never publishes -> its siblings' bounded spins run out
     int cluster_max_tiles;      //   the cluster kernel runs lists of up to this many tiles ...
     int split_min_tiles;        //   ... and the latency form (mlp_split_kernel<true>) lists of at least this many (0 = always)
+    DirectTiles direct;         // one-object batches: no tile list (kind != 0)
 };
 constexpr int CL_EPOCH_STRIDE = 4096;      // exchanges a launch may count: 15 per tile and cluster
 constexpr int CL_XCH_UNITS = 16 * 3;         // tagged 16-byte units per lane in one parity of a cluster's global exchange buffer (mlp_cluster_kernel.hip)
@@ -135,6 +149,7 @@ struct LpArgs {
     int code_bias_stride;
     float* out_sdf;
     unsigned long long* clk;
+    DirectTiles direct;         // one-object batches: no tile list (kind != 0)
 };
 
 // ---- Gauss-Newton batch state ------------------------------------------------------------------
@@ -171,6 +186,41 @@ struct ObjState {           // per-object optimiser state, lives on the device f
     unsigned guard_err;     // largest |sdf_lp - sdf_fp32| over the re-decoded samples (float bits)
     int pad0;
 };
+
+#ifdef __HIPCC__
+// (wave-uniform: kernel arguments and scalar loads only; no side effects -- every workgroup of every kernel that may take the list calls it)
+__device__ __forceinline__ DirectList direct_list(const DirectTiles& d, int tile_pts) {
+    DirectList l{0, 0, 0, 0};
+    const int status = d.st->status;
+    if (d.kind == 1) {
+        const int V = d.st->V;
+        l.n0 = (status == DSP_STATUS_GOOD && V >= 10) ? V : 0;          // "< 10 in-sphere samples": the object fails (direct_commit records it)
+    } else {
+        const bool good = status == DSP_STATUS_GOOD;
+        l.n0 = good ? d.n0 : 0;
+        l.n1 = good ? d.st->P : 0;
+    }
+    l.nt0 = (l.n0 + tile_pts - 1) / tile_pts;
+    l.n_tiles = l.nt0 + (l.n1 + tile_pts - 1) / tile_pts;
+    return l;
+}
+// ONE thread of the ONE kernel that takes the list: what k_build_tiles records besides the list
+__device__ __forceinline__ void direct_commit(const DirectTiles& d, const DirectList& l) {
+    if (d.kind == 1) {
+        if (d.st->status == DSP_STATUS_GOOD && d.st->V < 10) d.st->status = DSP_STATUS_FEW;
+        d.counters[4] += (double)l.n0;
+        d.counters[2] += (double)l.n0;
+    } else {
+        d.counters[1] += (double)l.n0;
+        d.counters[3] += (double)l.n1;
+    }
+}
+__device__ __forceinline__ int4 direct_tile(const DirectTiles& d, const DirectList& l, int tile, int tile_pts) {
+    if (tile < l.nt0) return make_int4(d.off0 + tile * tile_pts, min(tile_pts, l.n0 - tile * tile_pts), 0, 0);
+    const int t = tile - l.nt0;
+    return make_int4(d.off1 + t * tile_pts, min(tile_pts, l.n1 - t * tile_pts), 0, 0);
+}
+#endif
 static_assert(sizeof(ObjState) % 16 == 0, "ObjState is addressed as float4-aligned rows");
 
 // Prepass margin as a function of the code's largest entry: calibrate_prepass (dsp_gn.hip) measures the largest |sdf_lp - sdf_fp32|

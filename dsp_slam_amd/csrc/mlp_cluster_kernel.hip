@@ -51,7 +51,11 @@ __global__ __launch_bounds__(256, 1) void mlp_cluster_kernel(const MlpArgs a) {
     const int g = lane >> 4;
     const int pl = lane & 15;
 
-    const int n_tiles = *a.n_tiles;
+    DirectList dl{0, 0, 0, 0};
+    if (a.direct.kind) dl = direct_list(a.direct, SPLIT_TILE_PTS);
+    const int n_tiles = a.direct.kind ? dl.n_tiles : *a.n_tiles;
+    // (a one-object batch without a list: this kernel records the counts when the list is its own -- an empty one included)
+    if (a.direct.kind && n_tiles <= a.cluster_max_tiles && blockIdx.x == 0 && tid == 0) direct_commit(a.direct, dl);
     // the launch sequence issues this kernel AND the latency form for the same list; the tile count (known on the device only) picks one
     if (n_tiles > a.cluster_max_tiles || n_tiles <= 0) return;
     // cluster = 4 workgroups 8 apart in launch order: workgroup b runs on XCD b % 8 (observed, MI355X_MICROARCH.md), so the members of a
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(256, 1) void mlp_cluster_kernel(const MlpArgs a) {
     };
 
     for (int tile = cl; tile < n_tiles; tile += n_clusters) {
-        const int4 td = a.tiles[tile];
+        const int4 td = a.direct.kind ? direct_tile(a.direct, dl, tile, SPLIT_TILE_PTS) : a.tiles[tile];
         const bool valid = pl < td.y;
         const int pidx = td.x + (valid ? pl : 0);
         float4 pt = a.pts[pidx];
@@ -401,7 +405,7 @@ __global__ __launch_bounds__(256, 1) void mlp_cluster_kernel(const MlpArgs a) {
             const float s2 = __shfl(sx.w, pl + 48);
             const float sk = (g == 0) ? s0 : (g == 1) ? s1 : s2;
             if (valid) orow[64 + g] = (g < 3) ? (gfirst + sk) : y;
-            if (a.sdf_scatter && tile >= *a.scatter_tile_begin) {
+            if (a.sdf_scatter && tile >= (a.direct.kind ? dl.nt0 : *a.scatter_tile_begin)) {
                 const bool sc = valid && g == 3;
                 if (a.guard) prepass_guard(a, td.z, sc, sc ? a.sdf_scatter[__float_as_int(pt.w)] : 1.0f, y);
                 if (sc) a.sdf_scatter[__float_as_int(pt.w)] = y;

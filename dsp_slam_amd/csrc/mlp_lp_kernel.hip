@@ -247,7 +247,12 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpArgs a) {
     float* zero_l = reinterpret_cast<float*>(smem + BIAS_BYTES + CODEBIAS_BYTES);     // a row of zeros: the "final-layer weights" of every layer but the last
     char* ring_ptr = smem + BIAS_BYTES + CODEBIAS_BYTES + LP_ZERO_BYTES;
 
-    const int n_tiles = *a.n_tiles;
+    DirectList dl{0, 0, 0, 0};
+    if (a.direct.kind) {
+        dl = direct_list(a.direct, LP_TILE_PTS);
+        if (blockIdx.x == 0 && tid == 0) direct_commit(a.direct, dl);
+    }
+    const int n_tiles = a.direct.kind ? dl.n_tiles : *a.n_tiles;
     if ((int)blockIdx.x >= n_tiles) return;
     if (a.clk && blockIdx.x == 0 && tid == 0) { a.clk[0] = clock64(); a.clk[1] = wall_clock64(); }
     for (int i = tid; i < a.n_bias_rows * WIDTH; i += 256) bias_l[i] = a.bias_tab[i];
@@ -290,7 +295,7 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpArgs a) {
     const float* wl = bias_l + a.wlast_row * WIDTH;
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int4 td = a.tiles[tile];
+        const int4 td = a.direct.kind ? direct_tile(a.direct, dl, tile, LP_TILE_PTS) : a.tiles[tile];
         const int local = wave * LP_WAVE_PTS + pl;
         const bool valid = local < td.y;
         const int pidx = td.x + (valid ? local : 0);

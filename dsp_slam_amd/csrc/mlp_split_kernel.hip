@@ -53,9 +53,12 @@ __global__ __launch_bounds__(256, 1) void mlp_split_kernel(const MlpArgs a) {
     char* ring_ptr = smem + BIAS_BYTES + CODEBIAS_BYTES + SPLIT_MASK_BYTES + XCH_BYTES + wave * (SNB * MINI_BYTES);
     const unsigned ring0 = lds_addr(ring_ptr);
 
-    const int n_tiles = *a.n_tiles;
-    if ((int)blockIdx.x >= n_tiles) return;
+    DirectList dl{0, 0, 0, 0};
+    if (a.direct.kind) dl = direct_list(a.direct, SPLIT_TILE_PTS);
+    const int n_tiles = a.direct.kind ? dl.n_tiles : *a.n_tiles;
     if (BWD && n_tiles < a.split_min_tiles) return;      // a list this short is the cluster kernel's (mlp_cluster_kernel.hip): both are launched
+    if (a.direct.kind && blockIdx.x == 0 && tid == 0) direct_commit(a.direct, dl);       // (this kernel takes the list)
+    if ((int)blockIdx.x >= n_tiles) return;
     for (int i = tid; i < a.n_bias_rows * WIDTH; i += 256) bias_l[i] = a.bias_tab[i];
     __syncthreads();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(256, 1) void mlp_split_kernel(const MlpArgs a) {
     };
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int4 td = a.tiles[tile];
+        const int4 td = a.direct.kind ? direct_tile(a.direct, dl, tile, SPLIT_TILE_PTS) : a.tiles[tile];
         const bool valid = pl < td.y;
         const int pidx = td.x + (valid ? pl : 0);
         const int src = (!BWD && a.index) ? a.index[pidx] : pidx;
@@ -387,7 +390,7 @@ __global__ __launch_bounds__(256, 1) void mlp_split_kernel(const MlpArgs a) {
             const float s2 = __shfl(skipx[2], pl + 48);
             const float sk = (g == 0) ? s0 : (g == 1) ? s1 : s2;
             if (valid) orow[64 + g] = (g < 3) ? (gfirst + sk) : y;
-            if (a.sdf_scatter && tile >= *a.scatter_tile_begin) {
+            if (a.sdf_scatter && tile >= (a.direct.kind ? dl.nt0 : *a.scatter_tile_begin)) {
                 const bool sc = valid && g == 3;
                 if (a.guard) prepass_guard(a, td.z, sc, sc ? a.sdf_scatter[__float_as_int(pt.w)] : 1.0f, y);
                 if (sc) a.sdf_scatter[__float_as_int(pt.w)] = y;

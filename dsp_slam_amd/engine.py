@@ -137,6 +137,10 @@ class Batch(object):
         """-1 = automatic, 0 = off, 1 = the last partial round of the fp32 forward launch runs as 16-point latency-form tiles."""
         L.check(L.load().dsp_batch_set_tail_split(self._h, int(mode)), self.engine._h, "dsp_batch_set_tail_split")
 
+    def set_direct_tiles(self, mode):
+        """-1 automatic / 1: a one-object batch's decoder kernels derive their tile lists themselves; 0: k_build_tiles launches."""
+        L.check(L.load().dsp_batch_set_direct_tiles(self._h, int(mode)), self.engine._h, "dsp_batch_set_direct_tiles")
+
     def set_solver(self, mode):
         """0 = LDL^T (default), 1 = pivot-free Gauss-Jordan (the round-2/3 kernel, kept as the A/B reference)."""
         L.check(L.load().dsp_batch_set_solver(self._h, int(mode)), self.engine._h, "dsp_batch_set_solver")

@@ -291,6 +291,10 @@ int dsp_batch_set_mixed_reuse(dsp_batch* b, int mode);
  * cluster through L2 after every pass -- so that a detection occupies ~240 CUs instead of ~60.  Longer lists keep one workgroup per tile.
  * -1 = automatic (on wherever the latency form is), 0 = off, 1 = on where applicable.  Results are identical for every setting. */
 int dsp_batch_set_cluster_tiles(dsp_batch* b, int mode);
+/* A batch of ONE object in the wave-per-ray bookkeeping form: the decoder kernels derive their tile lists from the object's counters
+ * themselves instead of reading lists a single-workgroup kernel built in front of them (two launches less per iteration of a
+ * detection).  -1 = automatic (on), 0 = off, 1 = on.  Same tiles, same results. */
+int dsp_batch_set_direct_tiles(dsp_batch* b, int mode);
 /* The 71 x 71 (pose-only: 6 x 6) normal equations are solved in fp64 on the device: LDL^T with the right-hand side as an extra row + one
  * back substitution -- 2 = blocked over nine waves (default), 0 = packed triangle in the registers of eight waves (bit-identical to 2) --
  * or 1 = pivot-free Gauss-Jordan (rounds 2-3).  0 and 1 are kept as A/B references.  All are exact to fp64 round-off on the symmetric

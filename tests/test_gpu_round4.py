@@ -78,6 +78,38 @@ def test_wave_bookkeeping_is_exact(eng, prepass):
         assert one[2][2]["n_mlp_fwd_launches"] == 0 and one[2][2]["n_mlp_jac_launches"] == n_it
 
 
+def test_direct_tile_lists_are_exact(eng):
+    """A one-object batch in the wave form runs WITHOUT tile lists: the prepass and the jacobian kernels derive their tiles from the
+    object's counters (DirectTiles) instead of reading what k_build_tiles wrote -- same tiles, so every bit, every work counter and the
+    '< 10 in-sphere samples' failure (recorded by the prepass kernel now) must equal the form with the two launches; checked for a
+    detection that the cluster form takes, for one whose list is too long for it (one workgroup per tile), with the cluster form off,
+    and for a failing object, twenty runs each."""
+    n_it = 3
+    prm = E.gn_params(num_iterations=n_it)
+    small = synth.make_object(4242, n_surface=250, n_background=200)
+    big = synth.make_object(1, n_surface=250, n_background=200)          # some of its iterations keep more than 128 jacobian tiles
+    bad = synth.make_object(2310, 60, 20)
+    bad["t_cam_obj_init"] = bad["t_cam_obj_init"].copy()
+    bad["t_cam_obj_init"][:3, 3] += 500.0
+    for name, obj, extra in (("cluster", small, {}), ("long list", big, {}), ("cluster off", small, dict(cluster_tiles=0)), ("failing", bad, {})):
+        ref = _run_traced(eng, prm, [obj], n_it, direct_tiles=0, **extra)
+        b = eng.batch(prm, *_args([obj]), trace=True)
+        b.set_direct_tiles(1)
+        for k, v in extra.items():
+            getattr(b, "set_" + k)(v)
+        for rep in range(20):
+            b.run()
+            got = (b.results(), [b.trace(e) for e in range(n_it)], b.stats())
+            if name == "failing":
+                assert list(got[0][3]) == list(ref[0][3]) == [1]
+            else:
+                _assert_same_bits(ref, got, np.array([0]), "direct tiles, %s, run %d" % (name, rep))
+            # (the first run only: the guard draws a different sample of the classified points in every run, and those are jacobian points)
+            for k in ("n_fwd_points", "n_jac_points", "n_insphere_points", "n_prepass_points", "n_render_rows", "n_cluster_tiles") if rep == 0 else ("n_insphere_points", "n_prepass_points", "n_render_rows"):
+                assert ref[2][k] == got[2][k], (name, rep, k, ref[2][k], got[2][k])
+        b.close()
+
+
 def test_wave_bookkeeping_on_a_full_size_object(eng):
     """One cfg2-size object (2500 rays x 50: not speculative, adaptive front-to-back prepass passes whose scan shares ObjState::P with
     k_band_wave's running counter) and the full-size golden: wave form == throughput form, bit for bit."""
