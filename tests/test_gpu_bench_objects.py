@@ -3,9 +3,10 @@ configuration -- synth.make_batch(64, first_seed=1, 2000, 500), KITTI hyper-para
 for exactly these objects (tests/golden/golden_bench_cfg2x64.npz, tools/make_golden_bench.py):
 
   all 64   final pose / code / loss / is_good and V, m, K of every iteration;
-  8 of 64  full per-iteration traces (state, depth samples, H, b, dx) + the reference's own spread under eight 1-ulp input draws: the
+  16 of 64 full per-iteration traces (state, depth samples, H, b, dx) + the reference's own spread under eight 1-ulp input draws: the
            first and the last bench object, the three with the most render rows, the one with the fewest, the largest first step, the
-           largest initial yaw error.
+           largest initial yaw error (round 4, first batch), and the eight next-largest K (second batch, --extend: their all_* entries are
+           the traced run's -- the reference does not reproduce an earlier process's run bit for bit, tr<i>_rerun_dT records by how much).
 
 The device is checked INSIDE THE RESIDENT 64-OBJECT BATCH (the thing the bench times), not on single-object batches:
   (a) at the reference's own recorded states (pose, code, depth samples injected bit for bit for the 8 traced objects, every iteration):
@@ -176,7 +177,7 @@ def test_batch64_at_the_references_recorded_states(batch64, oracle_decoder):
                     assert np.all(np.abs(tr["dx"][i] - dx_ref) <= tol_dx), (i, e)
             rows.append(dict(object=i, iteration=e, V=v_ref, K=k_ref, rel_H=rh, rel_b=rb, named=n_named))
     b.set_start_state(None, zero_codes, None)
-    parity_log(kind="bench_at_reference_states", case="64 x cfg2 bench batch, 8 traced objects x 10 iterations inside the resident batch", objects=full,
+    parity_log(kind="bench_at_reference_states", case="64 x cfg2 bench batch, %d traced objects x 10 iterations inside the resident batch" % len(full), objects=full,
                n=len(rows), strict=strict, with_named_flips=named_total, beyond_tight_bounds=jitter_rows, max_rel_H=max(r["rel_H"] for r in rows), max_rel_b=max(r["rel_b"] for r in rows),
                per_object={str(i): dict(max_rel_H=max(r["rel_H"] for r in rows if r["object"] == i), max_rel_b=max(r["rel_b"] for r in rows if r["object"] == i),
                                         K=[r["K"] for r in rows if r["object"] == i], named=sum(r["named"] > 0 for r in rows if r["object"] == i)) for i in full})
