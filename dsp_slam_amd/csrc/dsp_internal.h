@@ -316,6 +316,7 @@ constexpr int DSP_RESULT_WIDTH_DEV = 82;   // == DSP_RESULT_WIDTH (dsp_gn.h): t_
 void launch_finalize(ObjState* st, const float* scale, int B, int pose_only, float* packed, unsigned* guard_out /*optional B x 3*/, hipStream_t s);
 
 hipError_t debug_solve_clocks(unsigned long long* out8);
+hipError_t launch_debug_lie(int kind, const float* x_dev, float* out_dev, int n_depth, hipStream_t s);   // testing: exp_sim3 / exp_se3 / rotation prior as k_solve evaluates them
 
 // ---- mesh extraction (mesh_kernels.hip) ---------------------------------------------------------
 constexpr int MC_MAX_TRI = 5;

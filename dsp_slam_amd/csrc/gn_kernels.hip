@@ -1273,13 +1273,20 @@ __device__ void exp_so3_parts(const float* w, float& theta, float wh[9], float w
     theta = sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
 }
 
+// float32 exp / sin / cos as the reference's CPU torch (Sleef u10) returns them: the correctly rounded value for 99 % / 95 % / 95 % of arguments
+// (measured over 2e5 arguments each, tools/make_golden_lie.py) -- here the float64 function rounded once.  It matters because exp_sim3 forms
+// c = (e^s - 1) / s, which amplifies the last bit of e^s by 1 / s: with s = 1e-3 one ulp of e^s moves the translation update by 6e-5 relative.
+__device__ __forceinline__ float exp_cr(float x) { return (float)exp((double)x); }
+__device__ __forceinline__ float sin_cr(float x) { return (float)sin((double)x); }
+__device__ __forceinline__ float cos_cr(float x) { return (float)cos((double)x); }
+
 __device__ void exp_sim3_dev(const float* x, float* out /*16*/) {   // loss_utils.py:188-233, quirks kept
     const float* v = x; const float* w = x + 3; const float s = x[6];
     float theta, wh[9], wh2[9];
     exp_so3_parts(w, theta, wh, wh2);
     const float t2 = theta * theta;
-    const float sn = sinf(theta), cs = cosf(theta);
-    const float es = expf(s);
+    const float sn = sin_cr(theta), cs = cos_cr(theta);
+    const float es = exp_cr(s);
     const float s2 = s * s;
     float ew[9], j[9];
     const float eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -1312,7 +1319,7 @@ __device__ void exp_se3_dev(const float* x, float* out /*16*/) {    // loss_util
     if (theta <= 1e-8f) {
         for (int i = 0; i < 9; ++i) { ew[i] = eye[i]; j[i] = eye[i]; }
     } else {
-        const float sn = sinf(theta), cs = cosf(theta);
+        const float sn = sin_cr(theta), cs = cos_cr(theta);
         const float t2 = theta * theta, t3 = t2 * theta;
         const float k1 = (1.f - cs) / t2, k2 = (theta - sn) / t3;
         for (int i = 0; i < 9; ++i) {
@@ -1972,5 +1979,44 @@ void launch_finalize(ObjState* st, const float* scale, int B, int pose_only, flo
 }
 
 hipError_t debug_solve_clocks(unsigned long long* out8) { return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_solve_clk), 64); }
+
+// Testing (dsp_debug_lie): the Lie-group maps and the rotation prior exactly as k_solve evaluates them -- ONE thread, the same device
+// functions, the same fp32 / fp64 arithmetic -- on caller-supplied arguments, so that each branch (theta <= 1e-8, s == 0, the
+// `c = 0 if s <= eps` quirk of loss_utils.py:223, the res < 1e-7 zero branch of loss.py:172-173) can be compared with the reference's
+// recorded vectors directly instead of through a chained trajectory.
+//   kind 0: x[7]  -> out[16] = exp_sim3(x)                          (loss_utils.py:188-233)
+//   kind 1: x[6]  -> out[16] = exp_se3(x)                           (loss_utils.py:129-163)
+//   kind 2: x[16] = t_obj_cam -> out[0..6] = J_rot, out[7] = res_rot, out[8] = scale, out[9] = d_min, out[10] = d_max
+//           (loss.py:155-178 on the state derive_iter_state builds: T_co, det^(1/3), depth range, as k_init_state / k_solve do)
+//   kind 3: x[16] = T_oc, x[16..23] = dx[7] -> out[16] = exp_sim3(dx) @ T_oc, the state update of optimizer.py:187-188 in k_solve's order
+__global__ void k_debug_lie(int kind, const float* x, float* out, int n_depth) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (kind == 0) { exp_sim3_dev(x, out); return; }
+    if (kind == 1) { exp_se3_dev(x, out); return; }
+    if (kind == 2) {
+        ObjState s;
+        for (int i = 0; i < 16; ++i) s.t_oc[i] = x[i];
+        s.status = DSP_STATUS_GOOD;
+        derive_iter_state(s, n_depth);
+        float jrot[7], res;
+        rotation_prior(s, jrot, res);
+        for (int i = 0; i < 7; ++i) out[i] = jrot[i];
+        out[7] = res; out[8] = s.scale; out[9] = s.dmin; out[10] = s.dmax;
+        out[11] = (float)s.status;
+        return;
+    }
+    float dT[16];
+    exp_sim3_dev(x + 16, dT);
+    for (int r = 0; r < 4; ++r)
+        for (int cc = 0; cc < 4; ++cc) {
+            float acc = 0.f;
+            for (int k = 0; k < 4; ++k) acc += dT[4 * r + k] * x[4 * k + cc];
+            out[4 * r + cc] = acc;
+        }
+}
+hipError_t launch_debug_lie(int kind, const float* x_dev, float* out_dev, int n_depth, hipStream_t s) {
+    hipLaunchKernelGGL(k_debug_lie, dim3(1), dim3(64), 0, s, kind, x_dev, out_dev, n_depth);
+    return hipGetLastError();
+}
 
 }  // namespace dsp

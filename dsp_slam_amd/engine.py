@@ -393,6 +393,14 @@ class Engine(object):
         return (j7[:k.value].copy(), jc[:k.value, :self.code_len].copy(), r[:k.value].copy()), stats
 
     # -- optimiser ----------------------------------------------------------------------------------
+    def debug_lie(self, kind, x, n_depth=50):
+        """Testing: exp_sim3 (kind 0, x[7]), exp_se3 (1, x[6]), the rotation prior + derived state (2, t_obj_cam 4x4) or the Sim(3) state
+        update exp_sim3(dx) @ t_obj_cam (3, 16 + 7 floats) evaluated by the device functions the solve kernel calls.  Returns 16 floats."""
+        x = L.f32(np.asarray(x, np.float32).reshape(-1))
+        out = np.zeros(16, np.float32)
+        L.check(L.load().dsp_debug_lie(self._h, int(kind), L.ptr(x), int(n_depth), L.ptr(out)), self._h, "dsp_debug_lie")
+        return out
+
     def batch(self, prm, t_cam_obj, pts, rays, depth, codes=None, trace=False):
         return Batch(self, prm, t_cam_obj, pts, rays, depth, codes, trace)
 

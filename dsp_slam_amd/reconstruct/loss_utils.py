@@ -72,7 +72,7 @@ def exp_se3(x):
     if theta <= 1e-8:
         e_w, j = eye, eye
     else:
-        s, c = F32(np.sin(theta)), F32(np.cos(theta))
+        s, c = F32(np.sin(np.float64(theta))), F32(np.cos(np.float64(theta)))     # correctly rounded, as the reference's torch returns them (95 %)
         e_w = eye + w_hat * s / theta + w_hat2 * (F32(1) - c) / theta ** 2
         j = eye + ((F32(1) - c) / theta ** 2) * w_hat + ((theta - s) / theta ** 3) * w_hat2
     out = np.eye(4, dtype=F32)
@@ -86,13 +86,13 @@ def exp_sim3(x):
     x = _np(x).astype(F32)
     w_hat, w_hat2, theta = _so3_terms(x[3:6])
     s = F32(x[6])
-    e_s = F32(np.exp(s))
+    e_s = F32(np.exp(np.float64(s)))       # correctly rounded like torch's (numpy's float32 exp is one ulp off for 40 % of arguments, and (e^s - 1) / s amplifies that by 1 / s)
     eye = np.eye(3, dtype=F32)
     if theta <= 1e-8:
         e_w = eye
         j = eye if s == 0 else ((e_s - F32(1)) / s) * eye
     else:
-        sn, cs = F32(np.sin(theta)), F32(np.cos(theta))
+        sn, cs = F32(np.sin(np.float64(theta))), F32(np.cos(np.float64(theta)))
         t2, s2 = F32(theta ** 2), F32(s ** 2)
         e_w = eye + w_hat * sn / theta + w_hat2 * (F32(1) - cs) / t2
         a, b = e_s * sn, e_s * cs

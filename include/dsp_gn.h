@@ -307,6 +307,17 @@ int dsp_batch_set_kernel_timing(dsp_batch* b, int mode);
 /* Forget what earlier guard trips on this handle have left behind (dsp_prepass_calibration_table: guard_err): the margins return to the
  * decoder's calibration. */
 int dsp_prepass_reset_guard(dsp_handle* h);
+/* Testing: the Lie-group maps and the rotation prior evaluated ON THE DEVICE by the very functions the solve kernel calls (one thread, same
+ * fp32 / fp64 arithmetic), so that every branch can be compared with vectors recorded from the reference:
+ *   kind 0: x[7]  -> out[16] = exp_sim3(x)   -- reconstruct/loss_utils.py:188-233 (theta <= 1e-8 / s == 0 branch :211-218, the
+ *                                               `c = 0. if s <= eps` quirk :223)
+ *   kind 1: x[6]  -> out[16] = exp_se3(x)    -- reconstruct/loss_utils.py:129-163
+ *   kind 2: x[16] = t_obj_cam -> out[0..6] = J_rot, out[7] = res_rot (compute_rotation_loss_sim3, reconstruct/loss.py:155-178, zero branch
+ *           :172-173), out[8] = scale = det(R_co)^(1/3), out[9], out[10] = the depth range t_z -+ scale (reconstruct/optimizer.py:120-125),
+ *           out[11] = status (DSP_OBJ_NAN for a singular matrix)
+ *   kind 3: x[0..15] = t_obj_cam, x[16..22] = dx -> out[16] = exp_sim3(dx) @ t_obj_cam  (the update of reconstruct/optimizer.py:187-188)
+ * n_depth = num_depth_samples (2..64; only kind 2 reads it). */
+int dsp_debug_lie(dsp_handle* h, int kind, const float* x, int32_t n_depth, float* out16);
 /* Record per-iteration traces during the following runs (testing; costs ~21 KB per object-iteration). */
 int dsp_batch_enable_trace(dsp_batch* b, int on);
 /* Per-iteration trace of the last run (testing): for iteration e < num_iterations and object i,

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), "libdspgn.so does not export %s" % n
     bound = {n for n, _, _ in L.SYMBOLS}
     assert set(names) <= bound, "ctypes binding misses %s" % (set(names) - bound)
-    assert lib.dsp_abi_version() == 4    # 2: dsp_stats grew the prepass fields; 3: the guard fields; 4: solver / kernel-timing setters, partial guard re-run
+    assert lib.dsp_abi_version() == 5    # 2: dsp_stats grew the prepass fields; 3: the guard fields; 4: solver / kernel-timing setters, partial guard re-run; 5: dsp_debug_lie, dsp_trim, cluster time-out
 
 
 def test_gfx950_code_object_present():

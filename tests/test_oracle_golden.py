@@ -259,3 +259,21 @@ def test_chairs32_decoder_and_reconstruction(chairs32_decoder):
     y, grad = O.get_batch_sdf_jacobian(chairs32_decoder, g["code"], g["pts"])
     assert np.abs(y - g["y_jac"]).max() < 5e-7 and rel(grad, g["grad"]) < 2e-6
     _check_trace(chairs32_decoder, "golden_recon_chairs32.npz", 1e-4)
+
+
+def test_lie_maps_against_the_extended_reference_vectors():
+    """tests/golden/golden_lie.npz (tools/make_golden_lie.py): 32 exp vectors on both sides of every branch, 8 rotation-prior poses,
+    32 state updates, all recorded from the unmodified reference.  The oracle agrees to one float32 ulp of the matrix's largest entry."""
+    g = golden("golden_lie.npz")
+    ulp = float(np.finfo(np.float32).eps)
+
+    def u(a, ref):
+        return np.abs(np.asarray(a, np.float64) - ref).max() / (ulp * max(1.0, np.abs(ref).max()))
+    for x, e7, e6 in zip(g["exp_x"], g["exp_sim3"], g["exp_se3"]):
+        assert u(O.exp_sim3(x), e7) <= 1.0, x
+        assert u(O.exp_se3(x[:6]), e6) <= 1.0, x
+    for t, j, r in zip(g["rot_t"], g["rot_j"], g["rot_r"]):
+        jo, ro = O.compute_rotation_loss_sim3(t)
+        assert abs(float(ro) - float(r)) <= 2 * ulp and np.abs(jo - j).max() <= 2 * ulp
+    for t, dx, ref in zip(g["upd_t"], g["upd_dx"], g["upd_out"]):
+        assert u((O.exp_sim3(dx) @ t).astype(np.float32), ref) <= 2.0
