@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", choices=("cfg2x64", "cfg4", "cfg5"), default="cfg2x64")
     ap.add_argument("--objects-per-gpu", type=int, default=0)   # 0 = the config's own size
+    ap.add_argument("--total-objects", type=int, default=1024)  # cfg4: the fixed job size (strong scaling)
     ap.add_argument("--prepass", choices=sorted(PREPASS), default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prepass-off", action="store_true")     # skip the prepass-off sub-record
@@ -147,17 +148,34 @@ def main():
         workload = ("cfg2: single KITTI-like car per object -- 2000 surface pts + 500 free-space rays (2500 rays x 50 depth "
                     "samples), 64-D code, 10 joint GN iterations (Optimizer.reconstruct_object), batch of %d objects per GPU" % B)
     elif args.config == "cfg4":
-        per = args.objects_per_gpu or 128
-        total = per * world
+        # BASELINE configs[3]: a FIXED job of 1024 objects sharded over the GPUs (strong scaling); --objects-per-gpu N makes it N x world (weak)
+        total = args.objects_per_gpu * world if args.objects_per_gpu else args.total_objects
+        strong = not args.objects_per_gpu
         prm = E.gn_params()
-        costs = [D.object_cost(2000, 2500)] * total
-        shards = D.shard_objects(costs, world)            # the production partitioner (uneven shards are padded in the gather)
+        # the production partitioner on MEASURED costs: every rank runs one GN iteration over its equal-count slice (a tenth of a step, outside
+        # the timed region), the per-object costs are all-gathered, shard_objects cuts the list where the summed cost balances
+        sa, sb = rank * total // world, (rank + 1) * total // world
+        made = {i: synth.make_object(1 + i, n_surface=2000, n_background=500) for i in range(sa, sb)}
+        mine_costs = D.measure_costs(eng, prm, [made[i] for i in range(sa, sb)])
+        if dist is not None:
+            n_max = -(-total // world)
+            tt = torch.zeros(n_max, dtype=torch.float64, device=coll_device)
+            tt[:len(mine_costs)] = torch.tensor(mine_costs, dtype=torch.float64)
+            allc = [torch.empty_like(tt) for _ in range(world)]
+            dist.all_gather(allc, tt)
+            costs = []
+            for r in range(world):
+                costs += [float(x) for x in allc[r][:(r + 1) * total // world - r * total // world].tolist()]
+        else:
+            costs = mine_costs
+        shards = D.shard_objects(costs, world)            # uneven shards are padded in the gather
         a, b = shards[rank]
-        objs = [synth.make_object(1 + i, n_surface=2000, n_background=500) for i in range(a, b)]
+        objs = [made[i] if i in made else synth.make_object(1 + i, n_surface=2000, n_background=500) for i in range(a, b)]
+        del made
         B = b - a
         groups = [(eng, objs)]
-        workload = ("cfg4: %d cfg2 objects block-sharded over %d GPU(s) by estimated cost (distributed.shard_objects), one RCCL gather "
-                    "of codes + poses per step" % (total, world))
+        workload = ("cfg4: %d cfg2 objects block-sharded over %d GPU(s) by measured first-iteration cost (distributed.measure_costs -> shard_objects: "
+                    "shards %s), one RCCL gather of codes + poses per step" % (total, world, [y - x for x, y in shards]))
     else:
         half = (args.objects_per_gpu or 64) // 2
         B = 2 * half
@@ -184,14 +202,27 @@ def main():
 
     gathered = [None]
 
-    k1_all = {"ms": 0.0, "n": 0}      # every launch of the fp32 forward kernel in this process (warm-up and the prepass-off leg included)
+    # Legs of this process, for matching against `rocprofv3 --kernel-trace` of the same command (tools/rocpd_legs.py): every leg starts with ONE
+    # launch of a marker kernel nothing else in this file runs (k_debug_lie through dsp_debug_lie, ~10 us, always outside the timed regions),
+    # so a trace splits into the same legs by the marker's dispatches alone; per leg the HIP-event totals of the decoder kernels are kept.
+    legs = []
+
+    def mark(name):
+        eng.debug_lie(0, np.zeros(7, np.float32))
+        legs.append({"leg": name, "fwd_fp32": {"launches": 0, "ms": 0.0}, "prepass": {"launches": 0, "ms": 0.0}, "jacobian": {"launches": 0, "ms": 0.0}})
+
+    def leg_add(st):
+        if not legs:
+            return
+        for key, n, ms in (("fwd_fp32", "n_mlp_fwd_launches", "ms_mlp_fwd"), ("prepass", "n_mlp_prepass_launches", "ms_mlp_prepass"),
+                           ("jacobian", "n_mlp_jac_launches", "ms_mlp_jac")):
+            legs[-1][key]["launches"] += int(st[n])
+            legs[-1][key]["ms"] += float(st[ms])
 
     def step():
         for bt in batches:
             bt.run()
-            st = bt.stats()
-            k1_all["ms"] += st["ms_mlp_fwd"]
-            k1_all["n"] += st["n_mlp_fwd_launches"]
+            leg_add(bt.stats())
         if dist is not None and backend == "nccl":     # the single collective of the path: results device -> RCCL gather over xGMI -> rank 0's host, no host bounce
             gathered[0] = D.gather_results_device(batches, shards, dist, device=torch.device("cuda", local_rank))
         elif dist is not None:                         # plumbing test on gloo: host rows
@@ -207,11 +238,13 @@ def main():
 
     NOT_SUMMED = ("prepass_mode", "prepass_delta", "prepass_max_err", "prepass_guard_max_err")
 
-    def timed(n_warm, n_steps):
+    def timed(n_warm, n_steps, leg):
         """n_warm untimed + exactly n_steps timed steps, barrier + synchronize on both sides, MAX over ranks.
         -> (elapsed of the slowest rank, every rank's own elapsed, summed kernel stats of this rank)"""
+        mark(leg + "_warmup")
         for _ in range(n_warm):
             step()
+        mark(leg + "_timed")
         sync()
         t0 = time.perf_counter()
         acc = {}
@@ -233,14 +266,14 @@ def main():
             per_rank = [float(x[1].item()) for x in allt]
         return elapsed, per_rank, acc
 
-    elapsed, per_rank_s, acc = timed(args.warmup, args.steps)
+    elapsed, per_rank_s, acc = timed(args.warmup, args.steps, "headline")
     # the same batch with the prepass OFF, timed in the same run (every rank takes part: the steps contain the collective)
     off_run = None
     if args.config == "cfg2x64" and int(acc.get("prepass_mode", 0)) != 0 and not args.no_prepass_off:
         for bt in batches:
             bt.set_prepass(0)
-        off_steps = max(1, min(args.steps, 3))
-        off_run = timed(1, off_steps) + (off_steps,)
+        off_steps = max(1, args.steps)        # the strict reference-precision leg is timed over as many steps as the headline
+        off_run = timed(1, off_steps, "prepass_off") + (off_steps,)
         for bt in batches:
             bt.set_prepass(PREPASS[args.prepass])
     n_good = int(sum(int((bt.results()[3] == 0).sum()) for bt in batches))
@@ -273,11 +306,14 @@ def main():
     def rate(pts, flop, ms):
         return pts * flop / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
 
+    mark("clock_probe")
     my_clock = rank_clock_mhz() if int(acc.get("prepass_mode", 0)) else 0.0
     mine_rec = [rate(acc["n_fwd_points"], F_FWD, acc["ms_mlp_fwd"]),
                 (acc["n_jac_points"] * F_JAC + acc["n_render_rows"] * (F_JAC - F_FWD)) / (acc["ms_mlp_jac"] * 1e-3) / 1e12 if acc["ms_mlp_jac"] > 0 else 0.0,
                 rate(acc["n_prepass_points"], F_FWD, acc["ms_mlp_prepass"]), my_clock, acc.get("prepass_guard_trips", 0.0),
-                acc.get("prepass_guard_rerun", 0.0), acc.get("prepass_guard_max_err", 0.0), float(n_good)]
+                acc.get("prepass_guard_rerun", 0.0), acc.get("prepass_guard_max_err", 0.0), float(n_good),
+                float(sum(bt.n for bt in batches)), acc["n_insphere_points"] / max(args.steps, 1), acc["n_render_rows"] / max(args.steps, 1),
+                acc["ms_mlp_fwd"] / max(args.steps, 1), acc["ms_mlp_jac"] / max(args.steps, 1), acc["ms_mlp_prepass"] / max(args.steps, 1)]
     all_recs = [mine_rec]
     if dist is not None:
         tt = torch.tensor(mine_rec, dtype=torch.float64, device=coll_device)
@@ -317,11 +353,16 @@ def main():
         "ms_per_step_by_rank": [round(x / args.steps * 1e3, 3) for x in per_rank_s],
         "by_rank": [{"rank": r, "fwd_fp32_frac": round(x[0] / PEAK_FP32_MFMA_TFLOPS, 4), "jac_fp32_frac": round(x[1] / PEAK_FP32_MFMA_TFLOPS, 4),
                      "prepass_tflops": round(x[2], 1), "prepass_clock_mhz": round(x[3]), "guard_trips": x[4], "guard_reruns": x[5],
-                     "guard_max_err": x[6], "objects_good": int(x[7])} for r, x in enumerate(all_recs)],
+                     "guard_max_err": x[6], "objects_good": int(x[7]), "objects": int(x[8]), "sum_V_per_step": round(x[9]), "sum_K_per_step": round(x[10]),
+                     "ms_per_step_by_kernel": {"fwd_fp32": round(x[11], 2), "jacobian_fp32": round(x[12], 2), "prepass": round(x[13], 2)}}
+                    for r, x in enumerate(all_recs)],
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if (args.config == "cfg4" and not args.objects_per_gpu) else "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        # what computed: every result-bearing value in fp32 (v_mfma_f32_16x16x4_f32); with the prepass on, an f16 MFMA kernel additionally
+        # CLASSIFIES ray samples whose occupancy is exactly 0 or 1 (results bit-identical to the fp32-only run, value_fp32_only below)
+        "dtype": "f32 + f16 classifier" if mode == 1 else ("f32 + bf16 classifier" if mode == 2 else "f32"),
+        "value_fp32_only": None,      # objects/s of the same batch with the prepass off (every sample the reference decodes, decoded in fp32): filled below
         "data": "synthetic (seeded rounded-box objects, decoder fixture fitted to them; no real weights/datasets offline)",
         "config": {
             "workload": workload,
@@ -343,9 +384,9 @@ def main():
             "traffic": pmc.get("fwd_fetch_bytes_per_point", 0.0) * fwd_pts / max(n_fwd, 1) or None,
             "traffic_note": pmc.get("note", "no PMC pass recorded (profiles/pmc_traffic.json missing)"),
             "avg_launch_ms": round(fwd_ms / max(n_fwd, 1), 4),
-            # what `rocprofv3 --kernel-trace --stats` of THIS command reports for the kernel: it also sees the warm-up step and, when the
-            # prepass-off leg runs, that leg's (ten shorter per iteration) launches -- profiles/rNN_kernel_stats.md must agree with this
-            "rocprof_check": {"launches_in_this_process": k1_all["n"], "avg_launch_ms_over_all_of_them": round(k1_all["ms"] / max(k1_all["n"], 1), 4)},
+            # what `rocprofv3 --kernel-trace` of THIS command must show, leg by leg (filled at the end: tools/rocpd_legs.py splits the trace by the
+            # marker kernel's dispatches and compares every leg's launch count and average duration with these HIP-event figures)
+            "rocprof_check": None,
             "alg_flop_per_launch": round(fwd_pts * F_FWD / max(n_fwd, 1)),
             "fwd_points_evaluated_over_insphere": round(fwd_pts / max(insphere_pts, 1.0), 4),
             "render_rows_kept_over_fwd_points": round(ren_rows / max(fwd_pts, 1.0), 4),
@@ -400,36 +441,46 @@ def main():
             "whole_path_fp32_tflops": round((o_acc["n_fwd_points"] * F_FWD + o_jflop) / o_el / 1e12 * world, 2),
             "note": "same batch, same process, prepass off: every sample in front of a ray's first solid sample decoded by the fp32 kernel; results bit-identical to the headline run",
         }
+        result["value_fp32_only"] = result["prepass_off"]["value"]
+    elif mode == 0:
+        result["value_fp32_only"] = result["value"]
 
     if world == 1 and args.config == "cfg2x64":
         # single-object latency (ms/object p50): batch of ONE cfg2 object
         o = objs[0]
         one = eng.batch(prm, [o["t_cam_obj_init"]], [o["pts"]], [o["rays"]], [o["depth"]])
         one.set_prepass(PREPASS[args.prepass])
+        mark("latency_cfg2_object")
         one.run()
+        leg_add(one.stats())
         lat = []
         for _ in range(max(args.latency_runs, 1)):
             t1 = time.perf_counter()
             one.run()
             one.results()
             lat.append((time.perf_counter() - t1) * 1e3)
+            leg_add(one.stats())
         one.close()
         result["latency_ms_p50"] = round(statistics.median(lat), 3)
         # a detection of the reference's real KITTI size (config_kitti.json:17 num_lidar_max 250, kitti_sequence.py:203-205 <= 200 background rays)
         k = synth.make_object(4242, n_surface=250, n_background=200)
         one = eng.batch(prm, [k["t_cam_obj_init"]], [k["pts"]], [k["rays"]], [k["depth"]])
         one.set_prepass(PREPASS[args.prepass])
+        mark("latency_kitti_size_detection")
         one.run()
+        leg_add(one.stats())
         lat = []
         for _ in range(max(args.latency_runs, 1)):
             t1 = time.perf_counter()
             one.run()
             one.results()
             lat.append((time.perf_counter() - t1) * 1e3)
+            leg_add(one.stats())
         one.close()
         result["latency_kitti_size_ms_p50"] = round(statistics.median(lat), 3)
         # the call SLAM really makes (Optimizer.reconstruct_object -> dsp_reconstruct_batch: build the batch from host buffers, run, drop): same detection
         args1 = ([k["t_cam_obj_init"]], [k["pts"]], [k["rays"]], [k["depth"]])
+        mark("latency_one_shot (launch counts not recorded: the one-shot entry point returns no stats)")
         eng.reconstruct_batch(prm, *args1)
         lat = []
         for _ in range(max(args.latency_runs, 1)):
@@ -451,6 +502,7 @@ def main():
                 t_se3.append(t); scales.append(sc)
             zero_codes = [np.zeros(64, np.float32)] * len(objs)
             pts_list = [o["pts"] for o in objs]
+            mark("pose_only (launch counts not recorded)")
             eng.estimate_pose_batch(prm, t_se3, scales, pts_list, zero_codes)
             t1 = time.perf_counter()
             reps = 5
@@ -512,6 +564,14 @@ def main():
             "gpu_vs_cpu": round(value * dt, 1),
             "pose_max_abs_diff_vs_gpu": float(np.abs(r["t_cam_obj"] - gpu_t).max()) if r["is_good"] else None,
         }
+    kernel_of = {"fwd_fp32": "mlp_kernel<1> (+ mlp_split_kernel<1> tail tiles in the one-object legs)", "prepass": "mlp_lp_kernel<f16|bf16>",
+                 "jacobian": "mlp_kernel<2> + mlp_kernel<3> (64-object legs) / mlp_cluster_kernel + mlp_split_kernel<2> (one-object legs)"}
+    result["roofline"]["rocprof_check"] = {
+        "marker_kernel": "k_debug_lie: one dispatch opens every leg, in this order (dispatches before the first marker: dsp_create's prepass calibration)",
+        "kernels": kernel_of,
+        "note": "avg_ms = HIP-event time on the library's stream / launches; null where the leg runs without per-kernel events (batches of <= 16 objects)",
+        "legs": [{"leg": lg["leg"], **{k: {"launches": lg[k]["launches"], "avg_ms": round(lg[k]["ms"] / lg[k]["launches"], 4) if lg[k]["launches"] and lg[k]["ms"] > 0 else None}
+                                         for k in ("fwd_fp32", "prepass", "jacobian")}} for lg in legs]}
     for bt in batches:
         bt.close()
     for e in engines:

@@ -43,7 +43,7 @@ class Stats(C.Structure):
                 ("prepass_mode", C.c_int32), ("prepass_delta", C.c_float), ("prepass_max_err", C.c_float),
                 ("prepass_misclassified", C.c_double), ("prepass_audited", C.c_double),
                 ("prepass_guard_trips", C.c_double), ("prepass_guard_objects", C.c_double), ("prepass_guard_max_err", C.c_float),
-                ("prepass_guard_rerun", C.c_int32), ("n_cluster_tiles", C.c_double)]
+                ("prepass_guard_rerun", C.c_int32), ("n_cluster_tiles", C.c_double), ("cluster_fallback", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class DspError(RuntimeError):
@@ -100,6 +100,7 @@ SYMBOLS = [
     ("dsp_batch_set_mixed_reuse", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_set_kernel_timing", C.c_int, [_VP, C.c_int]),
     ("dsp_prepass_reset_guard", C.c_int, [_VP]),
+    ("dsp_trim", C.c_int, [_VP]),
     ("dsp_debug_lie", C.c_int, [_VP, C.c_int, c_f32p, C.c_int32, c_f32p]),
     ("dsp_batch_enable_trace", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_trace", C.c_int, [_VP, C.c_int32, c_f32p, c_f32p, c_f32p, c_i64p, c_i64p, c_i64p, c_f32p, c_f32p, C.POINTER(C.c_uint32), c_f32p]),

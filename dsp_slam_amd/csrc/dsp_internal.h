@@ -92,7 +92,8 @@ struct MlpArgs {
     int cl_off[16];             //   first 4 KiB mini-chunk of wave slot u inside wcluster
     int cl_len[16];             //   mini-chunks slot u consumes per tile (forward + backward)
     float* cl_xbuf;             //   exchange buffers: [cluster][2 parities][16 wave slots x 3 units][64 lanes] x 16 B (3 floats + counter tag)
-    unsigned* cl_err;           //   raised when a bounded spin ran out (the host discards the run)
+    unsigned* cl_err;           //   raised when a bounded spin ran out: the latency-form kernel behind the cluster kernel then takes the list (device-side fallback)
+    unsigned cl_spin_ticks;     //   bound of every spin in ticks of the 100 MHz wall clock (CL_SPIN_TICKS_DEFAULT = 2 ms)
     double* cl_tiles_done;      //   optional: + the list's tile count when the cluster kernel takes it (dsp_stats.n_cluster_tiles)
     unsigned cl_epoch_base;     //   counter value this launch starts from (the host advances it by CL_EPOCH_STRIDE per launch)
     int cl_fault;               //   fault injection (tests): workgroup 3 of every cluster never publishes -> its siblings' bounded spins run out
@@ -100,6 +101,7 @@ struct MlpArgs {
     int split_min_tiles;        //   ... and the latency form (mlp_split_kernel<true>) lists of at least this many (0 = always)
     DirectTiles direct;         // one-object batches: no tile list (kind != 0)
 };
+constexpr unsigned CL_SPIN_TICKS_DEFAULT = 200000;   // 2 ms: ~500 healthy hand-offs of ~3.5 us
 constexpr int CL_EPOCH_STRIDE = 4096;      // exchanges a launch may count: 15 per tile and cluster
 constexpr int CL_XCH_UNITS = 16 * 3;         // tagged 16-byte units per lane in one parity of a cluster's global exchange buffer (mlp_cluster_kernel.hip)
 

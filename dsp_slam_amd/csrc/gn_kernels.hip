@@ -1057,8 +1057,10 @@ __global__ __launch_bounds__(WAVE_THREADS) void k_render_tail_wave(const ObjCons
     pre = 0; ktot = 0; mtot = 0;
 #pragma unroll
     for (int w = 0; w < WAVE_RAYS; ++w) { pre += part[0][w]; ktot += part[1][w]; mtot += part[2][w]; }
-    if (blockIdx.x == 0 && tid == 0) { st[b].K = ktot; st[b].m = mtot; }
-    if (st[b].status != DSP_STATUS_GOOD) return;
+    const int status = st[b].status;
+    // (an object that is not part of a partial re-run keeps its state untouched -- K and m included: launch_init_state, run_mask)
+    if (blockIdx.x == 0 && tid == 0 && status != DSP_STATUS_SKIP) { st[b].K = ktot; st[b].m = mtot; }
+    if (status != DSP_STATUS_GOOD) return;
     for (int q = 0; q < TAIL_RAYS / WAVE_RAYS; ++q) {
         const int rl = wave * (TAIL_RAYS / WAVE_RAYS) + q, r = r0 + rl;
         if (r >= c.n_rays) break;                               // wave-uniform

@@ -16,10 +16,18 @@
 //   followed by s_waitcnt vmcnt(0) + a flag store, and the readers polled the flag before fetching: one store acknowledgement and one
 //   L2 round trip more per hand-off, 16 hand-offs per tile.)
 //
-// Two exchange buffers alternate (a workgroup can only be one exchange ahead of its slowest sibling); counters, not flags: the epoch
-// base of a launch comes from the host, so nothing has to be cleared between launches (the host clears the buffers when its 32-bit
-// base wraps).  Every spin is bounded: a workgroup that gives up raises the error word, keeps publishing (so that nobody waits for it)
-// and the host falls back to the latency form for the run.
+// Two exchange buffers alternate.  EVERY exchange is a barrier of the whole cluster (round 5): a wave that has nothing to publish in an
+// exchange (the final hand-off of a tile, the forward passes of a narrower decoder) still stores ONE tagged "presence" unit, and every
+// workgroup waits for a tagged unit of every sibling -- so a workgroup is never more than one exchange ahead of its slowest sibling by
+// construction, and the buffer it is about to overwrite (the exchange before the previous one) has been read by everybody.  Counters,
+// not flags: the epoch base of a launch comes from the host, so nothing has to be cleared between launches (the host clears the
+// buffers when its 32-bit base wraps).
+// Every spin is bounded IN TIME (cl_spin_ticks of the 100 MHz wall clock, 2 ms by default: ~500 healthy hand-offs): a wave that gives up
+// raises the error word and keeps publishing (so that nobody waits for it).  The error word is the fallback's trigger ON THE DEVICE: the
+// latency-form kernel is launched behind this one in every iteration anyway (it normally returns at once for a list this short) and
+// takes the list when the word is set -- the same iteration's rows are recomputed one workgroup per tile, nothing is discarded or
+// repeated by the host, and the cluster launches of the run's remaining iterations return at entry.  A shared GPU (SLAM's detectors
+// run on it from another thread, Tracking_util.cc:31-57) that keeps a member from being scheduled therefore costs <= a few ms once.
 // Same k order, same bias seeding, same relu masks per output element as mlp_kernel<2> / mlp_split_kernel<true>: bit-identical
 // gradients (tests/test_gpu_round4.py::test_cluster_kernel_is_exact).
 //
@@ -39,7 +47,6 @@ constexpr int CL_MASK_BYTES = MASK_SLOTS * 256 * 2;         // [slot][tid] u16: 
 constexpr int CL_XCH_BYTES = 32 * 64 * 16;                  // one layer's output slab in LDS: 32 row tiles x 64 lanes x float4
 constexpr int CL_XCH_G_BYTES = CL_XCH_UNITS * 64 * 16;      // ... in the global exchange buffer: 16 wave slots x 3 tagged units x 64 lanes x 16 B
 constexpr int CL_RING_BYTES = 4 * CL_SNB * CL_MINI;
-constexpr unsigned CL_SPIN_LIMIT = 1u << 20;                // ~1 s of polling (one L2 round trip + s_sleep per poll): far beyond any healthy wait
 
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
@@ -54,10 +61,14 @@ __global__ __launch_bounds__(256, 1) void mlp_cluster_kernel(const MlpArgs a) {
     DirectList dl{0, 0, 0, 0};
     if (a.direct.kind) dl = direct_list(a.direct, SPLIT_TILE_PTS);
     const int n_tiles = a.direct.kind ? dl.n_tiles : *a.n_tiles;
-    // (a one-object batch without a list: this kernel records the counts when the list is its own -- an empty one included)
-    if (a.direct.kind && n_tiles <= a.cluster_max_tiles && blockIdx.x == 0 && tid == 0) direct_commit(a.direct, dl);
+    // (a one-object batch without a list: this kernel records the counts when the list is its own -- an empty one included; if this launch
+    // then loses a hand-off the latency form repeats the list and counts it again: the counters say what was computed)
+    if (a.direct.kind && n_tiles <= a.cluster_max_tiles && blockIdx.x == 0 && tid == 0 &&
+        (n_tiles <= 0 || *reinterpret_cast<const volatile unsigned*>(a.cl_err) == 0u)) direct_commit(a.direct, dl);
     // the launch sequence issues this kernel AND the latency form for the same list; the tile count (known on the device only) picks one
     if (n_tiles > a.cluster_max_tiles || n_tiles <= 0) return;
+    // an earlier launch of this run lost a hand-off: the latency form takes every list for the rest of the run (see above)
+    if (*reinterpret_cast<const volatile unsigned*>(a.cl_err) != 0u) return;
     // cluster = 4 workgroups 8 apart in launch order: workgroup b runs on XCD b % 8 (observed, MI355X_MICROARCH.md), so the members of a
     // cluster share an L2 -- a speed hint only, nothing below depends on it
     const int cl = ((int)blockIdx.x >> 5) * 8 + ((int)blockIdx.x & 7);
@@ -124,14 +135,21 @@ __global__ __launch_bounds__(256, 1) void mlp_cluster_kernel(const MlpArgs a) {
         if (publish) {
             xch[(2 * u) * 64 + lane] = pub[0];
             xch[(2 * u + 1) * 64 + lane] = pub[1];
-            if (!(a.cl_fault && rank == 3)) {             // (fault injection: a member that never publishes)
-                const unsigned ub = par + ((3 * u) * 64 + lane) * 16;
+        }
+        if (!(a.cl_fault && rank == 3)) {                 // (fault injection: a member that never publishes)
+            const unsigned ub = par + ((3 * u) * 64 + lane) * 16;
+            if (publish) {
                 const u32x4_t u0 = {__float_as_uint(pub[0].x), __float_as_uint(pub[0].y), __float_as_uint(pub[0].z), ep};
                 const u32x4_t u1 = {__float_as_uint(pub[0].w), __float_as_uint(pub[1].x), __float_as_uint(pub[1].y), ep};
                 const u32x4_t u2 = {__float_as_uint(pub[1].z), __float_as_uint(pub[1].w), 0u, ep};
                 __builtin_amdgcn_raw_buffer_store_b128(u0, xrs, ub, 0, 16);                 // aux 16 = sc1: write-through
                 __builtin_amdgcn_raw_buffer_store_b128(u1, xrs, ub + 64 * 16, 0, 16);
                 __builtin_amdgcn_raw_buffer_store_b128(u2, xrs, ub + 2 * 64 * 16, 0, 16);
+            } else {
+                // nothing to hand over in this exchange: ONE presence unit, so that the siblings know this workgroup has finished reading
+                // the previous exchange (every exchange is a cluster-wide barrier)
+                const u32x4_t u0 = {0u, 0u, 0u, ep};
+                __builtin_amdgcn_raw_buffer_store_b128(u0, xrs, ub, 0, 16);
             }
         }
         if (wave < 3) {                                    // this wave relays ONE remote workgroup's tiles into LDS
@@ -141,6 +159,7 @@ __global__ __launch_bounds__(256, 1) void mlp_cluster_kernel(const MlpArgs a) {
             for (int i = 0; i < 12; ++i) v[i] = (u32x4_t){0u, 0u, 0u, 0u};
             if (!dead) {
                 unsigned spins = 0;
+                unsigned long long t0 = 0;
                 for (;;) {
                     bool ok = true;
 #pragma unroll
@@ -150,6 +169,8 @@ __global__ __launch_bounds__(256, 1) void mlp_cluster_kernel(const MlpArgs a) {
 #pragma unroll
                             for (int k = 0; k < 3; ++k)
                                 v[3 * sl + k] = __builtin_amdgcn_raw_buffer_load_b128(xrs, par + ((3 * (4 * r + sl) + k) * 64 + lane) * 16, 0, 16);
+                        } else {                           // not part of this exchange: its presence unit only
+                            v[3 * sl] = __builtin_amdgcn_raw_buffer_load_b128(xrs, par + ((3 * (4 * r + sl)) * 64 + lane) * 16, 0, 16);
                         }
                     }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -157,9 +178,17 @@ __global__ __launch_bounds__(256, 1) void mlp_cluster_kernel(const MlpArgs a) {
                     for (int sl = 0; sl < 4; ++sl) {
                         const int tl = 8 * r + 2 * sl;
                         if (tl < n_lo || tl >= hi_from) ok = ok && v[3 * sl][3] == ep && v[3 * sl + 1][3] == ep && v[3 * sl + 2][3] == ep;
+                        else ok = ok && v[3 * sl][3] == ep;
                     }
                     if (__all(ok)) break;
-                    if (++spins > CL_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(a.cl_err, 1u); break; }
+                    // bounded in TIME, not in polls: the clock is read only once a poll has failed, and then on every 16th
+                    if (spins == 0) t0 = wall_clock64();
+                    if ((++spins & 15u) == 0u && wall_clock64() - t0 > (unsigned long long)a.cl_spin_ticks) {
+                        dead = true;
+                        if (lane == 0) atomicOr(a.cl_err, 1u);
+                        __threadfence();      // the word is out before anything this wave publishes from here on (stale data under a current tag)
+                        break;
+                    }
                     __builtin_amdgcn_s_sleep(1);
                 }
             }
@@ -383,6 +412,11 @@ __global__ __launch_bounds__(256, 1) void mlp_cluster_kernel(const MlpArgs a) {
 
         // d y / d code = first-layer rows (tiles 0..3, held by every wave after the final hand-off) + the latent_in skip rows (slots 4..8 of
         // the last exchange); wave 0 of workgroup 0 writes the row
+        // A wave of this launch has given up (the error word is set before it publishes anything else): this tile may have been computed from
+        // stale hand-offs.  Its rows are recomputed by the latency-form kernel behind this launch; what must NOT happen is that a wrong sdf
+        // replaces the prepass value (the recomputation's guard compares against it) or reaches the guard (a false trip would re-run the
+        // object without the prepass and widen the handle's margins).
+        const bool launch_ok = __hip_atomic_load(a.cl_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
         if (u == 0) {
             const int n_code_tiles = 31 - a.lat_tile;              // 4 (64-D codes) or 2 (32-D)
             const f32x4 sx = xch[a.lat_tile * 64 + lane];           // the xyz tile: rows 13..15 = lane group 3, components 1..3
@@ -405,7 +439,7 @@ __global__ __launch_bounds__(256, 1) void mlp_cluster_kernel(const MlpArgs a) {
             const float s2 = __shfl(sx.w, pl + 48);
             const float sk = (g == 0) ? s0 : (g == 1) ? s1 : s2;
             if (valid) orow[64 + g] = (g < 3) ? (gfirst + sk) : y;
-            if (a.sdf_scatter && tile >= (a.direct.kind ? dl.nt0 : *a.scatter_tile_begin)) {
+            if (launch_ok && a.sdf_scatter && tile >= (a.direct.kind ? dl.nt0 : *a.scatter_tile_begin)) {
                 const bool sc = valid && g == 3;
                 if (a.guard) prepass_guard(a, td.z, sc, sc ? a.sdf_scatter[__float_as_int(pt.w)] : 1.0f, y);
                 if (sc) a.sdf_scatter[__float_as_int(pt.w)] = y;

@@ -56,7 +56,9 @@ __global__ __launch_bounds__(256, 1) void mlp_split_kernel(const MlpArgs a) {
     DirectList dl{0, 0, 0, 0};
     if (a.direct.kind) dl = direct_list(a.direct, SPLIT_TILE_PTS);
     const int n_tiles = a.direct.kind ? dl.n_tiles : *a.n_tiles;
-    if (BWD && n_tiles < a.split_min_tiles) return;      // a list this short is the cluster kernel's (mlp_cluster_kernel.hip): both are launched
+    // a list this short is the cluster kernel's (mlp_cluster_kernel.hip): both are launched -- unless that kernel lost a hand-off in this
+    // run (error word set: it returns at entry from then on, and what it left of the launch that failed is recomputed here)
+    if (BWD && n_tiles < a.split_min_tiles && !(a.cl_err && *reinterpret_cast<const volatile unsigned*>(a.cl_err) != 0u)) return;
     if (a.direct.kind && blockIdx.x == 0 && tid == 0) direct_commit(a.direct, dl);       // (this kernel takes the list)
     if ((int)blockIdx.x >= n_tiles) return;
     for (int i = tid; i < a.n_bias_rows * WIDTH; i += 256) bias_l[i] = a.bias_tab[i];

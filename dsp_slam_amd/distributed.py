@@ -14,6 +14,44 @@ def object_cost(n_pts, n_rays, n_depth=50):
     return float(n_rays) * n_depth + 2.0 * float(n_pts)
 
 
+# Seconds of decoder time per point, from the rates the kernels reach on an MI355X in the 64-object batch (BENCH_r04: prepass 1347 TFLOP/s f16;
+# fp32 forward 0.889 and jacobian kernels 0.871 of 157.3 TFLOP/s): only their RATIOS matter to the partitioner.
+_F_FWD = 3671040.0
+_T_PREPASS = _F_FWD / 1347e12
+_T_FWD = _F_FWD / (0.889 * 157.3e12)
+_T_BWD = _F_FWD / (0.871 * 157.3e12)
+
+
+def measured_cost(n_pts, v, band, k, prepass=True):
+    """Work of one object per Gauss-Newton iteration from its MEASURED first-iteration set sizes: V in-sphere samples through the prepass
+    (or, prepass off, through the fp32 forward kernel), `band` samples through the fp32 forward kernel, n_pts surface points forward +
+    backward, K kept render rows backward only.  Replaces the static R*D + 2M, which cannot see that one 2500-ray object keeps 4.8 k render
+    rows and another 21 k (the bench batch)."""
+    fwd = float(v) * _T_PREPASS + float(band) * _T_FWD if prepass else float(v) * _T_FWD
+    return fwd + 2.0 * float(n_pts) * _T_BWD + float(k) * _T_BWD
+
+
+def measure_costs(engine, prm, objs, chunk=128):
+    """measured_cost of every object in `objs` from ONE Gauss-Newton iteration on `engine`'s GPU (a tenth of the job's work; the set sizes of
+    the later iterations follow the first one's closely enough to balance shards: profiles/r05_cfg4_balance.md).  In a multi-GPU job every
+    rank measures its equal-count slice and the costs are all-gathered before shard_objects runs (bench.py --config cfg4)."""
+    costs = []
+    for a in range(0, len(objs), chunk):
+        ol = objs[a:a + chunk]
+        bt = engine.batch(prm, [o["t_cam_obj_init"] for o in ol], [o["pts"] for o in ol], [o["rays"] for o in ol], [o["depth"] for o in ol], trace=True)
+        try:
+            bt.set_iterations(1)
+            bt.run()
+            tr = bt.trace(0)
+            pre = bt.stats()["prepass_mode"] != 0
+        finally:
+            bt.close()
+        for i, o in enumerate(ol):
+            # m counts |sdf| < th among the decoded samples; the widened band + guard samples the fp32 kernel really decodes is ~1.15 m
+            costs.append(measured_cost(len(o["pts"]), tr["V"][i], 1.15 * tr["m"][i], tr["K"][i], pre))
+    return costs
+
+
 def shard_objects(costs, world_size):
     """Contiguous block partition of objects 0..n-1 over ranks, balancing the summed cost.
     Returns a list of (start, stop) per rank; every object belongs to exactly one rank."""

@@ -142,7 +142,7 @@ class Batch(object):
         L.check(L.load().dsp_batch_set_direct_tiles(self._h, int(mode)), self.engine._h, "dsp_batch_set_direct_tiles")
 
     def set_solver(self, mode):
-        """0 = LDL^T (default), 1 = pivot-free Gauss-Jordan (the round-2/3 kernel, kept as the A/B reference)."""
+        """2 = blocked LDL^T with rows in lanes (default), 0 = packed LDL^T, 1 = pivot-free Gauss-Jordan (0 and 1: A/B references; dsp_gn.h)."""
         L.check(L.load().dsp_batch_set_solver(self._h, int(mode)), self.engine._h, "dsp_batch_set_solver")
 
     def set_mixed_reuse(self, mode):
@@ -393,6 +393,11 @@ class Engine(object):
         return (j7[:k.value].copy(), jc[:k.value, :self.code_len].copy(), r[:k.value].copy()), stats
 
     # -- optimiser ----------------------------------------------------------------------------------
+    def trim(self):
+        """Hand the handle's cached device blocks and pinned staging buffers back to the runtime (dsp_trim): for a process that shares the
+        GPU with torch / RCCL / another handle and has just finished a large one-shot batch."""
+        L.check(L.load().dsp_trim(self._h), self._h, "dsp_trim")
+
     def debug_lie(self, kind, x, n_depth=50):
         """Testing: exp_sim3 (kind 0, x[7]), exp_se3 (1, x[6]), the rotation prior + derived state (2, t_obj_cam 4x4) or the Sim(3) state
         update exp_sim3(dx) @ t_obj_cam (3, 16 + 7 floats) evaluated by the device functions the solve kernel calls.  Returns 16 floats."""

@@ -96,6 +96,10 @@ typedef struct dsp_stats {
     float prepass_guard_max_err; /* largest |sdf_lp - sdf_fp32| over the compared samples */
     int32_t prepass_guard_rerun; /* 1: the guard tripped; the objects it tripped on were run again with the prepass off (their results come from that run) */
     double n_cluster_tiles;      /* (ABI version 4) 16-point jacobian tiles that ran in the cluster form: four workgroups per tile (dsp_batch_set_cluster_tiles) */
+    int32_t cluster_fallback;    /* (ABI version 5) 1: a cluster-form launch of this run lost a hand-off within its time bound (2 ms: a busy shared GPU kept one of the
+                                  * four workgroups off its CU); the latency-form kernel recomputed that launch and took the run's remaining lists on the device --
+                                  * same results, a few ms later; the handle keeps the cluster form off for its next 64 runs */
+    int32_t reserved0;
 } dsp_stats;
 
 /* ---- lifetime --------------------------------------------------------------------------------- */
@@ -103,6 +107,10 @@ typedef struct dsp_stats {
  * different handles are independent.  Callers that release the GIL around these calls (ctypes, pybind11) may therefore call from any thread. */
 int dsp_create(const dsp_decoder_desc* decoder, int device, dsp_handle** out);
 void dsp_destroy(dsp_handle* h);
+/* A handle keeps device blocks (up to 1 GiB, size-classed) and pinned host staging of dropped one-shot batches for its next call.  dsp_trim
+ * hands all of it back to the runtime: for a process that shares the GPU with another allocator (torch, RCCL, a second handle).  Destroying
+ * a resident batch (dsp_batch_destroy) trims the cache to the footprint of one KITTI-size detection (64 MiB) on its own. */
+int dsp_trim(dsp_handle* h);
 const char* dsp_last_error(const dsp_handle* h);   /* h may be NULL: error of the last failed dsp_create */
 int dsp_abi_version(void);
 /* Which compiler produced this library (hipcc --version at build time, clang version, HIP header version) -- the decoder kernels rely on
@@ -289,7 +297,10 @@ int dsp_batch_set_mixed_reuse(dsp_batch* b, int mode);
 /* Latency form of the jacobian launch, one step further: a list of at most 128 tiles of 16 points (a detection of SLAM's real size has
  * 40-60) runs with FOUR workgroups per tile -- the rows of every layer split over their 16 waves, the layer's result handed round the
  * cluster through L2 after every pass -- so that a detection occupies ~240 CUs instead of ~60.  Longer lists keep one workgroup per tile.
- * -1 = automatic (on wherever the latency form is), 0 = off, 1 = on where applicable.  Results are identical for every setting. */
+ * -1 = automatic (on wherever the latency form is), 0 = off, 1 = on where applicable.  Results are identical for every setting.
+ * The four workgroups of a cluster wait for each other with spins bounded to 2 ms; on a GPU shared with other work (DSP-SLAM's detectors
+ * run on it from the Tracking thread, src/Tracking_util.cc:31-57) a member may be scheduled late: the launch then falls back to one
+ * workgroup per tile ON THE DEVICE (dsp_stats.cluster_fallback), results unchanged. */
 int dsp_batch_set_cluster_tiles(dsp_batch* b, int mode);
 /* A batch of ONE object in the wave-per-ray bookkeeping form: the decoder kernels derive their tile lists from the object's counters
  * themselves instead of reading lists a single-workgroup kernel built in front of them (two launches less per iteration of a

@@ -212,6 +212,8 @@ def test_batch64_first_iteration_and_chained_result_vs_reference(batch64):
     for i in full:
         gi = dict(t_cam_obj=g["all_t_cam_obj"][i], code=g["all_code"][i], ulp_t_cam_obj=g["tr%d_ulps_t_cam_obj" % i][0], ulp_code=g["tr%d_ulps_code" % i][0],
                   ulps_t_cam_obj=g["tr%d_ulps_t_cam_obj" % i], ulps_code=g["tr%d_ulps_code" % i])
+        if "tr%d_thr_t_cam_obj" % i in g.files:        # the reference's no-input-change (thread count) spread of this object, tools/make_golden_threads.py --bench
+            gi.update(thr_t_cam_obj=g["tr%d_thr_t_cam_obj" % i], thr_code=g["tr%d_thr_code" % i])
         m, sens, _ = P.end_to_end_differences(gi, t[i], code[i])
         per[str(i)] = dict(measured={q: m[q] for q in ("rot", "scale", "trans", "code")}, reference_spread={q: sens[q] for q in ("rot", "scale", "trans", "code")})
         for q in worst_spread:

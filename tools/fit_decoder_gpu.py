@@ -104,6 +104,83 @@ def rounded_box_sdf_t(p, code3, half, rnd):
     return outside + inside - rnd
 
 
+class _TorchXP(object):
+    """torch backend of synth.complex_car_sdf (the numpy one is synth._NP): the same expressions evaluate the fit's labels on the device."""
+    abs, sqrt, tanh, maximum, minimum = torch.abs, torch.sqrt, torch.tanh, torch.maximum, torch.minimum
+
+    @staticmethod
+    def clamp(x, lo, hi):
+        return torch.clamp(x, lo, hi)
+
+    @staticmethod
+    def stack(xs):
+        return torch.stack(xs, dim=-1)
+
+    @staticmethod
+    def norm(x):
+        return torch.sqrt((x * x).sum(-1))
+
+    @staticmethod
+    def amax(x):
+        return x.max(-1).values
+
+    @staticmethod
+    def zeros_like(x):
+        return torch.zeros_like(x)
+
+
+def complex_sdf_t(p, codes, P):
+    return synth.complex_car_sdf(p, torch.tanh(codes @ P.T), _TorchXP)
+
+
+def sample_batch_complex(gen, n, code_len, P, dev, code_sigma):
+    """Training samples of the complex family: codes N(0, sigma^2 I) on ALL dimensions; points one third uniform in the ball, one third
+    around the surface found by bisection from the centre, one third uniform in the boxes of the thin / small parts (wheels, spoiler,
+    cabin edge) which a centre-ray sampler hits rarely.  Labels are the analytic field at wherever the points end up."""
+    f64 = torch.float64
+    codes = torch.randn(n, code_len, generator=gen, dtype=f64, device=dev) * code_sigma
+    n_uni = n // 3
+    n_feat = n // 3
+    m = n - n_uni - n_feat
+    u = torch.randn(n_uni, 3, generator=gen, dtype=f64, device=dev)
+    u = u / u.norm(dim=-1, keepdim=True)
+    p_uni = u * (1.05 * torch.rand(n_uni, 1, generator=gen, dtype=f64, device=dev) ** (1.0 / 3.0))
+    d = torch.randn(m, 3, generator=gen, dtype=f64, device=dev)
+    d = d / d.norm(dim=-1, keepdim=True)
+    lo = torch.zeros(m, dtype=f64, device=dev)
+    hi = torch.full((m,), 1.6, dtype=f64, device=dev)
+    cs = codes[n_uni:n_uni + m]
+    for _ in range(16):
+        mid = 0.5 * (lo + hi)
+        inside = complex_sdf_t(d * mid[:, None], cs, P) < 0
+        lo = torch.where(inside, mid, lo)
+        hi = torch.where(inside, hi, mid)
+    p_surf = d * (0.5 * (lo + hi))[:, None]
+    r = torch.rand(m, 1, generator=gen, dtype=f64, device=dev)
+    sig = torch.where(r < 0.4, 0.005, torch.where(r < 0.8, 0.02, 0.08))
+    p_near = p_surf + torch.randn(m, 3, generator=gen, dtype=f64, device=dev) * sig
+    # feature boxes (centre, half size): four wheels (mirrored by random signs), the spoiler, the cabin / body seam
+    which = torch.randint(0, 4, (n_feat,), generator=gen, device=dev)
+    sx = torch.where(torch.rand(n_feat, generator=gen, device=dev) < 0.5, -1.0, 1.0).to(f64)
+    sz = torch.where(torch.rand(n_feat, generator=gen, device=dev) < 0.5, -1.0, 1.0).to(f64)
+    ctr = torch.zeros(n_feat, 3, dtype=f64, device=dev)
+    hs = torch.zeros(n_feat, 3, dtype=f64, device=dev)
+    wheel = which <= 1
+    ctr[wheel] = torch.stack([0.33 * sx[wheel], torch.full_like(sx[wheel], -0.20), 0.46 * sz[wheel]], -1)
+    hs[wheel] = torch.tensor([0.14, 0.20, 0.24], dtype=f64, device=dev)
+    sp = which == 2
+    ctr[sp] = torch.tensor([0.0, 0.20, 0.66], dtype=f64, device=dev)
+    hs[sp] = torch.tensor([0.36, 0.10, 0.12], dtype=f64, device=dev)
+    cb = which == 3
+    ctr[cb] = torch.tensor([0.0, 0.12, -0.08], dtype=f64, device=dev)
+    hs[cb] = torch.tensor([0.40, 0.22, 0.55], dtype=f64, device=dev)
+    p_feat = ctr + (2.0 * torch.rand(n_feat, 3, generator=gen, dtype=f64, device=dev) - 1.0) * hs
+    p = torch.cat([p_uni, p_near, p_feat], 0)
+    sdf = complex_sdf_t(p, codes, P)
+    x = torch.cat([codes, p], -1).to(torch.float32)
+    return x, sdf.to(torch.float32)
+
+
 def sample_batch(gen, n, code_len, half, dev, code_sigma):
     f64 = torch.float64
     codes = torch.zeros(n, code_len, dtype=f64, device=dev)
@@ -143,7 +220,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32768)
     ap.add_argument("--code-len", type=int, default=SPECS["CodeLength"])
     ap.add_argument("--half", type=float, nargs=3, default=None)
-    ap.add_argument("--code-sigma", type=float, default=0.45)
+    ap.add_argument("--code-sigma", type=float, default=None, help="default 0.45 (box: first three code dims) / 0.12 (complex: all dims)")
+    ap.add_argument("--shape", choices=("box", "complex"), default="box", help="complex: synth.complex_car_sdf, codes on all dimensions")
     ap.add_argument("--lr", type=float, default=1e-3)
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
@@ -153,6 +231,14 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(args.seed)
     half = torch.tensor(synth.BOX_HALF if args.half is None else np.asarray(args.half, np.float64), dtype=torch.float64, device=dev)
+    if args.code_sigma is None:
+        args.code_sigma = 0.12 if args.shape == "complex" else 0.45
+    P = torch.tensor(synth.complex_projection(args.code_len), dtype=torch.float64, device=dev)
+
+    def draw(n, sigma):
+        if args.shape == "complex":
+            return sample_batch_complex(gen, n, args.code_len, P, dev, sigma)
+        return sample_batch(gen, n, args.code_len, half, dev, sigma)
     dec = FixtureDecoder(args.code_len, SPECS["NetworkSpecs"]).to(dev)
     opt = torch.optim.Adam(dec.parameters(), lr=args.lr)
     sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=args.steps, eta_min=2e-6)
@@ -161,7 +247,7 @@ def main():
     for step in range(args.steps):
         if step == args.steps // 2:
             dec.set_quantised(True)
-        x, y = sample_batch(gen, args.batch, args.code_len, half, dev, args.code_sigma)
+        x, y = draw(args.batch, args.code_sigma)
         pred = dec(x).squeeze(-1)
         loss = (torch.clamp(pred, -clamp, clamp) - torch.clamp(y, -clamp, clamp)).abs().mean()
         opt.zero_grad(set_to_none=True)
@@ -182,7 +268,7 @@ def main():
                 lin.weight.copy_(bf16_round(lin.weight))
         # held-out check of what was saved
         gen.manual_seed(args.seed + 12345)
-        x, y = sample_batch(gen, 200000, args.code_len, half, dev, 0.3)
+        x, y = draw(200000, synth.COMPLEX_CODE_SIGMA if args.shape == "complex" else 0.3)
         pred = dec(x).squeeze(-1)
         err = (pred - y)
         near = y.abs() < 0.02

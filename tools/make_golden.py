@@ -326,6 +326,30 @@ def main():
         obj = synth.make_object(31, n_surface=4000, n_background=500, code_len=32, half=synth.CHAIR_HALF)
         recon("golden_recon_cfg5.npz", obj, cfg_ch, dec=dec_ch)
 
+    # ---- C4. a decoder of realistic geometric complexity: fitted to synth.complex_car_sdf -- body + cabin + four wheels + a
+    #          thin spoiler plate, shape parameters driven by ALL 64 code dimensions (tools/fit_decoder_gpu.py --shape complex) -- one
+    #          cfg2-size object under the KITTI hyper-parameters, full per-iteration trace
+    if want("complex") and os.path.exists(fixtures.fixture_path("complex")):
+        cx_dir = fixtures.materialize_decoder_dir("complex", os.path.join(tmp, "complex_64"))
+        cfg_cx = make_cfg(cx_dir, KITTI)
+        with open(os.path.join(tmp, "cfg_cx.json"), "w") as f:
+            json.dump(cfg_cx, f)
+        dec_cx = get_decoder(get_configs(os.path.join(tmp, "cfg_cx.json")))
+        for p_ in dec_cx.parameters():
+            p_.requires_grad_(False)
+        n = 96
+        obj = synth.make_object(41, n_surface=2000, n_background=500, shape="complex")
+        code = (obj["code_gt"] * 0.8).astype(np.float32)
+        pts = rng.uniform(-0.9, 0.9, size=(n, 3)).astype(np.float32)
+        yj, gj = rlu.get_batch_sdf_jacobian(dec_cx, torch.from_numpy(code), torch.from_numpy(pts), 1)
+        sdf = rlu.decode_sdf(dec_cx, torch.from_numpy(code), torch.from_numpy(pts)).numpy()
+        truth = synth.complex_sdf(pts, code)
+        print("complex decoder vs the analytic field at 96 points: max |d| %.3e (clamped to +-0.1: %.3e)" % (
+            np.abs(sdf - truth).max(), np.abs(np.clip(sdf, -0.1, 0.1) - np.clip(truth, -0.1, 0.1)).max()))
+        np.savez_compressed(os.path.join(GOLD, "golden_decoder_complex.npz"), code=code, pts=pts, y_jac=yj.reshape(-1).numpy(),
+                            grad=gj.reshape(n, 67).numpy(), sdf=sdf)
+        recon("golden_recon_complex.npz", obj, cfg_cx, dec=dec_cx)
+
     # ---- D. pose-only optimiser --------------------------------------------------------------
     if want("pose"):
         obj = synth.make_object(14, n_surface=300, n_background=0)

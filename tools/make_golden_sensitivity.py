@@ -48,7 +48,10 @@ def main():
         if not bool(g["is_good"]):
             continue
         cfg_d = json.loads(str(g["cfg_json"]))
-        cfg_d["DeepSDF_DIR"] = dirs[cfg_d["optimizer"]["code_len"]]      # 64-D goldens use the cars fixture, 32-D ones chairs32
+        # 64-D goldens use the cars fixture, 32-D ones chairs32 -- unless the recorded directory names another fixture (complex_64)
+        if os.path.basename(cfg_d["DeepSDF_DIR"]).startswith("complex") and "complex" not in dirs:
+            dirs["complex"] = fixtures.materialize_decoder_dir("complex", os.path.join(tmp, "complex_64"))
+        cfg_d["DeepSDF_DIR"] = dirs["complex"] if os.path.basename(cfg_d["DeepSDF_DIR"]).startswith("complex") else dirs[cfg_d["optimizer"]["code_len"]]
         with open(os.path.join(tmp, "cfg.json"), "w") as f:
             json.dump(cfg_d, f)
         cfg = get_configs(os.path.join(tmp, "cfg.json"))
