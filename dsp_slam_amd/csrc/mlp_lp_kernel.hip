@@ -4,25 +4,31 @@
 // clamp(sdf, -th, th) (reconstruct/loss_utils.py:40-48, reconstruct/loss.py:84-96): occupancy is exactly 0 for sdf >= th
 // and exactly 1 for sdf <= -th.  A sample whose low-precision sdf is farther than a calibrated margin delta from the band
 // |sdf| < th is therefore classified for good, bit-exactly, and only the samples inside the widened band are decoded in
-// fp32 (dsp_gn.hip, "prepass").  v_mfma_f32_32x32x16_{f16,bf16} runs at 16x the fp32 MFMA rate.
+// fp32 (dsp_gn.hip, "prepass").
 //
-// Structure (DESIGN.md "K0"): one workgroup = 4 waves = one 128-point tile, one wave per SIMD.  A wave owns 32 points and
-// keeps its [512 rows x 32 points] activation slab in registers as packed 16-bit pairs (128 registers): the D layout of
-// v_mfma_f32_32x32x16 (lane = point + 32 hh holds rows 8 i + 4 hh + r of each 32-row tile) IS, after v_cvt_pk, the B-operand
-// layout of two k-steps of the next layer if that layer's weights are packed with the k order
-// krow(s, hh, e) = 16 s + 8 (e >> 2) + 4 hh + (e & 3).  Two slabs (X, Y) ping-pong between layers.  Weights stream through
-// an 8-slot LDS ring of 16 KiB chunks (8 k-steps x 2 row tiles x 1 KiB A fragment) by LDS-DMA, one piece per k-step behind
-// an MFMA, counted vmcnt + one s_barrier per chunk -- the protocol of mlp_kernel.hip at 4x the chunk rate.  The relu /
-// v_cvt_pk epilogue of output group g-1 is interleaved with the MFMAs of group g (two accumulator sets).  xyz enters
-// layer 0 and the latent_in layer through one or two extra k-steps as split-precision products (LP_XYZ_TERMS), the code
-// through the fp32 per-object bias (k_code_bias), biases are the fp32 C operand of each tile's first MFMA, and the final
-// 512 -> 1 layer + tanh is an fp32 VALU dot product on the un-rounded accumulators of the last hidden layer.
+// Structure (DESIGN.md "K0"): one workgroup = 4 waves = one 128-point tile, one wave per SIMD.  A wave owns 32 points as TWO column
+// blocks of 16 and keeps its [512 rows x 32 points] activation slab in registers as packed 16-bit pairs (128 registers; two slabs X, Y
+// ping-pong between layers).  Round 5: the matrix instruction is v_mfma_f32_16x16x32_{f16,bf16} (rounds 2-4: 32x32x16).  A register-only
+// probe with live (random) operand data holds 2.13 GHz on the 16x16x32 form and 1.78 GHz on the 32x32x16 form (same FLOP per cycle:
+// tools/probes/mfma16_probe.hip, profiles/r05_k0_clock.md) -- the chip's clock under dense 16-bit MFMA follows the switching power, and the
+// 16x16 form switches less per FLOP.  One A fragment (16 output rows x 32 k, one ds_read_b128 per lane) feeds both column blocks: the
+// LDS duty is what it was (1 KiB per 32 matrix-pipe cycles and wave).
+//
+// Lane maps: A lane l = row l & 15, k slots 8 (l >> 4) + e; B lane l = point l & 15, the same k slots (the pairing of A and B slots is all
+// that matters); D lane l = point l & 15, rows 4 (l >> 4) + r of the 16-row tile.  After v_cvt_pk the D registers of row tiles 2q, 2q + 1
+// ARE the B operand of the next layer's 32-k step q if that layer's weights are packed with the slot order
+// krow(q, gq, e) = 32 q + 16 (e >> 2) + 4 gq + (e & 3)  (pack_decoder_lp_host; tests/lp_emulator.py pins it on the CPU).
+// Weights stream through an 8-slot LDS ring of 16 KiB chunks (4 steps of 32 k x 4 row tiles x 1 KiB A fragment) by LDS-DMA, one piece
+// behind an MFMA, counted vmcnt + one s_barrier per chunk -- the protocol of mlp_kernel.hip at 4x the chunk rate.  The relu / v_cvt_pk
+// epilogue of output group g-1 is interleaved with the MFMAs of group g (two accumulator sets).  xyz enters layer 0 and the latent_in
+// layer through one 32-k step of split-precision products (LP_XYZ_TERMS), the code through the fp32 per-object bias (k_code_bias),
+// biases are the fp32 C operand of each tile's first MFMA, and the final 512 -> 1 layer + tanh is an fp32 VALU dot product on the
+// un-rounded accumulators of the last hidden layer.
 #include "dsp_internal.h"
 #include "mlp_common.h"
 
 namespace dsp {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -30,22 +36,19 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef __bf16 b8 __attribute__((ext_vector_type(8)));
 typedef __bf16 b2 __attribute__((ext_vector_type(2)));
 
-#ifndef LP_PREFETCH_K
-#define LP_PREFETCH_K 2
-#endif
-constexpr int LP_PREFETCH = LP_PREFETCH_K;     // A fragments are read this many k-steps ahead of their MFMAs (4 rotating buffers: <= 3)
-static_assert(LP_PREFETCH >= 1 && LP_PREFETCH <= 3, "the A-fragment buffers rotate over 4 slots");
-constexpr int LP_KSTEP_BYTES = 2048;   // two 1 KiB A fragments (row tiles 2g, 2g+1) per k-step
-constexpr int LP_NCH = 4;              // chunks per output group of a hidden layer: 32 k-steps = 512 slab rows
+constexpr int LP_KQ = 4;               // 32-k steps per chunk (a chunk spans 128 slab rows)
+constexpr int LP_RT = 4;               // 16-row tiles per 64-row output group
+constexpr int LP_FRAG_BYTES = 1024;    // one A fragment: 16 rows x 32 k, 16 B per lane
+constexpr int LP_NCH = 4;              // chunks per output group of a hidden layer: 16 steps of 32 k = 512 slab rows
 constexpr int LP_NOG = 8;              // 64-row output groups per layer
 constexpr int LP_ZERO_BYTES = WIDTH * 4;
 
 template <bool BF>
-__device__ __forceinline__ f32x16 lp_mfma(u32x4 a, u32x4 b, f32x16 c) {
+__device__ __forceinline__ f32x4 lp_mfma(u32x4 a, u32x4 b, f32x4 c) {
     if constexpr (BF)
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, a), __builtin_bit_cast(b8, b), c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8, a), __builtin_bit_cast(b8, b), c, 0, 0, 0);
     else
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
 }
 
 // two fp32 -> one register holding two 16-bit values (element 0 in the low half), round to nearest even:
@@ -97,74 +100,83 @@ __device__ __forceinline__ void lp_issue_next(LpRing& rg) {
     rg.idst = rg.ring0 + rg.issue_slot * CHUNK_BYTES;
 }
 
-// rows 64 g + 32 j + 8 i + 4 hh + r of a fp32 table, in accumulator (D) order: acc[j][4 i + r]
-__device__ __forceinline__ void lp_load_rows(const float* tab, int g, int hh, f32x16 (&dst)[2]) {
+// rows 64 g + 16 rt + 4 gq + r of a fp32 table, in accumulator (D) order: dst[rt][r]
+__device__ __forceinline__ void lp_load_rows(const float* tab, int g, int gq, f32x4 (&dst)[LP_RT]) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(tab + 64 * g + 32 * j + 8 * i + 4 * hh);
-            dst[j][4 * i + 0] = v.x; dst[j][4 * i + 1] = v.y; dst[j][4 * i + 2] = v.z; dst[j][4 * i + 3] = v.w;
-        }
+    for (int rt = 0; rt < LP_RT; ++rt) dst[rt] = *reinterpret_cast<const f32x4*>(tab + 64 * g + 16 * rt + 4 * gq);
 }
 
-// relu + round + pack accumulator pairs [q0, q1) of output group g into the next layer's input slab, and the same values
-// times the rows of `w` into the final-layer dot product (w = 0 except in the last hidden layer):
-// pair q of row tile j = registers (2 q, 2 q + 1) -> k-step 2 (2 g + j) + (q >> 2), component q & 3.
-// (g, q0, q1 are compile-time constants after the callers' loops are unrolled; the loop bounds here are literal so that
-// every register index folds.)
+// relu + round + pack the accumulators of row tiles [rt0, rt1) of output group g into the next layer's input slab, and the same values
+// times the rows of `dp` into the final-layer dot product (LAST: the last hidden layer writes no slab):
+// row tile T = 4 g + rt is half (T & 1) of the next layer's 32-k step T >> 1: registers 2 (T & 1), 2 (T & 1) + 1 of out[2 (T >> 1) + blk].
+// (g, rt0, rt1 are compile-time constants after the callers' loops are unrolled; the loop bounds here are literal so that every register
+// index folds.)
 template <bool BF, bool LAST>
-__device__ __forceinline__ void lp_epilogue(int g, int q0, int q1, const f32x16 (&acc)[2], const float* dp, int hh, u32x4 (&out)[32], float& part) {
-    // quad qd = 4 consecutive accumulator registers of row tile j = rows 64 g + 32 j + 8 i + 4 hh + 0..3 = one float4 of the dot row
+__device__ __forceinline__ void lp_epilogue(int g, int rt0, int rt1, const f32x4 (&acc)[LP_RT][2], const float* dp, int gq, u32x4 (&out)[32], float (&part)[2]) {
 #pragma unroll
-    for (int qd = 0; qd < 8; ++qd) {
-        if (qd >= q0 && qd < q1) {
-            const int j = qd >> 2, i = qd & 3;
+    for (int rt = 0; rt < LP_RT; ++rt) {
+        if (rt >= rt0 && rt < rt1) {
             if (LAST) {
                 // last hidden layer: nothing reads its slab; only the final 512 -> 1 layer's dot product on the un-rounded values
-                const f32x4 w = *reinterpret_cast<const f32x4*>(dp + 64 * g + 32 * j + 8 * i + 4 * hh);
-                part = fmaf(relu1(acc[j][4 * i + 0]), w.x, part);
-                part = fmaf(relu1(acc[j][4 * i + 1]), w.y, part);
-                part = fmaf(relu1(acc[j][4 * i + 2]), w.z, part);
-                part = fmaf(relu1(acc[j][4 * i + 3]), w.w, part);
+                const f32x4 w = *reinterpret_cast<const f32x4*>(dp + 64 * g + 16 * rt + 4 * gq);
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) {
+                    part[blk] = fmaf(relu1(acc[rt][blk].x), w.x, part[blk]);
+                    part[blk] = fmaf(relu1(acc[rt][blk].y), w.y, part[blk]);
+                    part[blk] = fmaf(relu1(acc[rt][blk].z), w.z, part[blk]);
+                    part[blk] = fmaf(relu1(acc[rt][blk].w), w.w, part[blk]);
+                }
             } else {
-                // (no dot-product FMAs here: only the last hidden layer feeds the final layer)
-                out[2 * (2 * g + j) + (i >> 1)][2 * (i & 1) + 0] = lp_relu_pack<BF>(acc[j][4 * i + 0], acc[j][4 * i + 1]);
-                out[2 * (2 * g + j) + (i >> 1)][2 * (i & 1) + 1] = lp_relu_pack<BF>(acc[j][4 * i + 2], acc[j][4 * i + 3]);
+                const int T = 4 * g + rt;
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) {
+                    out[2 * (T >> 1) + blk][2 * (T & 1) + 0] = lp_relu_pack<BF>(acc[rt][blk].x, acc[rt][blk].y);
+                    out[2 * (T >> 1) + blk][2 * (T & 1) + 1] = lp_relu_pack<BF>(acc[rt][blk].z, acc[rt][blk].w);
+                }
             }
         }
     }
 }
 
 // One dense layer: out = relu(W . in + bias) for this wave's 32 points; part += relu(.) . dot row.  `in` / `out` are the two
-// register slabs.  A pass is 8 output groups x NCH chunks of straight-line code: everything that differs between layers is
-// data (bias / dot-row pointers, prologue selects) -- hipcc answers run-time control flow inside this body with hundreds of
-// register moves at every join.  NCH = 1 for the first layer (its K is the xyz k-steps only), LP_NCH for the others.
+// register slabs, indexed [2 ks + blk]: 32-k step ks, column block blk.  A pass is 8 output groups x NCH chunks of straight-line code:
+// everything that differs between layers is data (bias / dot-row pointers, prologue selects) -- hipcc answers run-time control flow inside
+// this body with hundreds of register moves at every join.  NCH = 1 for the first layer (its K is the xyz step only), LP_NCH for the others.
 template <bool BF, int NCH, bool LAST>
-__device__ __forceinline__ void lp_pass(const LpPass pd, u32x4 (&in)[32], u32x4 (&out)[32], f32x16 (&acc)[2][2],
-                                        u32x4 (&abuf)[4][2], LpRing& rg, const u32x4 (&xb)[LP_XYZ_KSTEPS], const float* bp,
-                                        const float* dp, int lane, int hh, float& part) {
-    // ---- prologue: place the xyz B operands at their fixed k-steps ---------------------------------------------------
-    // first layer: k-steps 0, 1 (the rest of its single chunk is padding); latent_in layer: the last two k-steps, behind the
-    // slab rows and pd.npad padding k-steps.  Padding k-steps meet zero A fragments: clear them so that no stale inf / nan
-    // of an earlier layer does.  (Selects, not branches: hipcc sinks the stores of two branches into one store through a
-    // pointer phi, which pins the whole slab in scratch memory.)
+__device__ __forceinline__ void lp_pass(const LpPass pd, u32x4 (&in)[32], u32x4 (&out)[32], f32x4 (&acc)[2][LP_RT][2],
+                                        u32x4 (&abuf)[2][LP_RT], LpRing& rg, const u32x4 (&xb)[2], const float* bp,
+                                        const float* dp, int lane, int gq, float (&part)[2]) {
+    // ---- prologue: place the xyz B operands at their fixed step -------------------------------------------------------
+    // first layer: step 0 (the rest of its single chunk is padding); latent_in layer: the last step (15), behind the slab rows and
+    // pd.npad padding 16-row tiles.  Padding meets zero A fragments: clear it so that no stale inf / nan of an earlier layer does.
+    // (Selects, not branches: hipcc sinks the stores of two branches into one store through a pointer phi, which pins the whole slab
+    // in scratch memory.)
     {
         const u32x4 zero = (u32x4){0u, 0u, 0u, 0u};
         if (NCH == 1) {
 #pragma unroll
-            for (int s = 0; s < LP_KSTEPS_PER_CHUNK; ++s) in[s] = s < LP_XYZ_KSTEPS ? xb[s < LP_XYZ_KSTEPS ? s : 0] : zero;
+            for (int ks = 0; ks < LP_KQ; ++ks)
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) in[2 * ks + blk] = ks == 0 ? xb[blk] : zero;
         } else {
             const bool lat = pd.kind == 2;
+            constexpr int KX = LP_KQ * NCH - 1;          // the xyz step of the latent_in layer
 #pragma unroll
-            for (int u = 0; u < LP_XYZ_KSTEPS; ++u) in[8 * NCH - LP_XYZ_KSTEPS + u] = lat ? xb[u] : in[8 * NCH - LP_XYZ_KSTEPS + u];
+            for (int blk = 0; blk < 2; ++blk) in[2 * KX + blk] = lat ? xb[blk] : in[2 * KX + blk];
 #pragma unroll
-            for (int t = 1; t <= 3; ++t)
-                in[8 * NCH - LP_XYZ_KSTEPS - t] = (lat && pd.npad >= t) ? zero : in[8 * NCH - LP_XYZ_KSTEPS - t];
+            for (int t = 1; t <= 3; ++t) {               // padding 16-row tile 2 KX - t = half (t & 1 ? 1 : 0) of step (2 KX - t) >> 1
+                const int T = 2 * KX - t;
+                const bool z = lat && pd.npad >= t;
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) {
+                    in[2 * (T >> 1) + blk][2 * (T & 1) + 0] = z ? 0u : in[2 * (T >> 1) + blk][2 * (T & 1) + 0];
+                    in[2 * (T >> 1) + blk][2 * (T & 1) + 1] = z ? 0u : in[2 * (T >> 1) + blk][2 * (T & 1) + 1];
+                }
+            }
         }
     }
-    f32x16 bias[2];
-    lp_load_rows(bp, 0, hh, bias);
+    f32x4 bias[LP_RT];
+    lp_load_rows(bp, 0, gq, bias);
 
 #pragma unroll
     for (int g = 0; g < LP_NOG; ++g) {
@@ -174,63 +186,43 @@ __device__ __forceinline__ void lp_pass(const LpPass pd, u32x4 (&in)[32], u32x4 
             const int nx_slot = (rg.rd_slot + 1 == LP_NBUF) ? 0 : rg.rd_slot + 1;
             // This lane's LDS byte address inside the chunk being read and inside the next one, each as ONE opaque 32-bit register: every
             // A-fragment read below is then `ds_read_b128 v, base offset:imm`.  Left to itself hipcc materialises a separate address for
-            // every (slot, k-step, row tile), parks them in AGPRs and pays a v_accvgpr_read (often two) per ds_read -- 1.0-1.9 extra
-            // instructions per MFMA in a one-wave-per-SIMD kernel where every issued instruction costs matrix-pipe time.
+            // every (slot, step, row tile), parks them in AGPRs and pays a v_accvgpr_read (often two) per ds_read.
             typedef const __attribute__((address_space(3))) char* lds_cptr;
             unsigned cb_a = rg.ring_lane + (unsigned)rg.rd_slot * CHUNK_BYTES, nb_a = rg.ring_lane + (unsigned)nx_slot * CHUNK_BYTES;
             asm volatile("" : "+v"(cb_a), "+v"(nb_a));
             const lds_cptr cbp = (lds_cptr)(size_t)cb_a, nbp = (lds_cptr)(size_t)nb_a;
 #pragma unroll
-            for (int sl = 0; sl < LP_KSTEPS_PER_CHUNK; ++sl) {
-                const int s = LP_KSTEPS_PER_CHUNK * c + sl;
-                if (sl == LP_KSTEPS_PER_CHUNK / 2) {
+            for (int kq = 0; kq < LP_KQ; ++kq) {
+                const int ks = LP_KQ * c + kq;
+                if (kq == LP_KQ / 2) {
                     // chunk q+1 has landed for this wave once <= LP_NBUF-3 younger chunks are in flight; the barrier
                     // publishes every wave's quarter and proves all reads of chunk q-1 retired (mlp_kernel.hip)
                     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(GLDS_PER_CHUNK * (LP_NBUF - 3)) : "memory");
                 }
-#if defined(LP_PAIR_READS)   // measured (round 3, no spills in either form): 0.5248 vs 0.5284 of peak -- no gain; the kernel is clock-governed, not issue-bound
-                // A fragments of two k-steps per group, one lgkmcnt wait per group (mlp_common.h: every instruction between MFMAs costs)
-                if ((sl & 1) == 0) {
-                    __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0), vmcnt / expcnt untouched
-                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const int sp = sl + 2 + q;
-                        const lds_cptr src = (sp < LP_KSTEPS_PER_CHUNK) ? cbp + sp * LP_KSTEP_BYTES : nbp + (sp - LP_KSTEPS_PER_CHUNK) * LP_KSTEP_BYTES;
-                        abuf[sp % 4][0] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(src);
-                        abuf[sp % 4][1] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(src + 1024);
-                    }
+                for (int rt = 0; rt < LP_RT; ++rt) {
+                    // the A fragment of (step kq + 1, row tile rt): one step = four fragments = eight MFMAs (128 cycles) ahead of its use
+                    const lds_cptr src = (kq + 1 < LP_KQ) ? cbp + ((kq + 1) * LP_RT + rt) * LP_FRAG_BYTES : nbp + rt * LP_FRAG_BYTES;
+                    abuf[(kq + 1) & 1][rt] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(src);
+                    const u32x4 av = abuf[kq & 1][rt];
+                    acc[par][rt][0] = lp_mfma<BF>(av, in[2 * ks + 0], ks == 0 ? bias[rt] : acc[par][rt][0]);
+                    // refill of the slot freed by the barrier above: one DMA piece behind an MFMA, four per chunk
+                    if (kq == LP_KQ / 2 && rt == 0) { glds_set_dst(rg.idst); glds_piece_m0<0>(rg.isrc, rg.lane_off, rg.idst); }
+                    if (kq == LP_KQ / 2 && rt == 2) glds_piece_m0<1>(rg.isrc, rg.lane_off, rg.idst);
+                    if (kq == LP_KQ / 2 + 1 && rt == 0) glds_piece_m0<2>(rg.isrc, rg.lane_off, rg.idst);
+                    if (kq == LP_KQ / 2 + 1 && rt == 2) { glds_piece_m0<3>(rg.isrc, rg.lane_off, rg.idst); lp_issue_next(rg); }
+                    acc[par][rt][1] = lp_mfma<BF>(av, in[2 * ks + 1], ks == 0 ? bias[rt] : acc[par][rt][1]);
+                    // epilogue of the previous group, one row tile (both column blocks) behind each of this group's first MFMA pairs
+                    if (g > 0 && ks == 1) lp_epilogue<BF, LAST>(g - 1, rt, rt + 1, acc[par ^ 1], dp, gq, out, part);
                 }
-#else
-                const int sp = sl + LP_PREFETCH;
-                const lds_cptr src = (sp < LP_KSTEPS_PER_CHUNK) ? cbp + sp * LP_KSTEP_BYTES : nbp + (sp - LP_KSTEPS_PER_CHUNK) * LP_KSTEP_BYTES;
-                abuf[sp % 4][0] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(src);
-                abuf[sp % 4][1] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(src + 1024);
-#endif
-                const u32x4 a0 = abuf[sl % 4][0], a1 = abuf[sl % 4][1];
-                const u32x4 b = in[s];
-                acc[par][0] = lp_mfma<BF>(a0, b, s == 0 ? bias[0] : acc[par][0]);
-                // refill of the slot freed by the barrier above: one DMA piece per k-step, behind an MFMA
-                if (sl == LP_KSTEPS_PER_CHUNK / 2 + 0) { glds_set_dst(rg.idst); glds_piece_m0<0>(rg.isrc, rg.lane_off, rg.idst); };
-                if (sl == LP_KSTEPS_PER_CHUNK / 2 + 1) glds_piece_m0<1>(rg.isrc, rg.lane_off, rg.idst);
-                if (sl == LP_KSTEPS_PER_CHUNK / 2 + 2) glds_piece_m0<2>(rg.isrc, rg.lane_off, rg.idst);
-                if (sl == LP_KSTEPS_PER_CHUNK / 2 + 3) { glds_piece_m0<3>(rg.isrc, rg.lane_off, rg.idst); lp_issue_next(rg); }
-                acc[par][1] = lp_mfma<BF>(a1, b, s == 0 ? bias[1] : acc[par][1]);
-                if (s == LP_KSTEPS_PER_CHUNK * NCH - 2 && g + 1 < LP_NOG) lp_load_rows(bp, g + 1, hh, bias);   // the next group's bias, two k-steps ahead
-                // epilogue of the previous group, two accumulator quads per k-step behind this group's MFMAs
-                if (g > 0) {
-                    if (s == 2) lp_epilogue<BF, LAST>(g - 1, 0, 2, acc[par ^ 1], dp, hh, out, part);
-                    if (s == 3) lp_epilogue<BF, LAST>(g - 1, 2, 4, acc[par ^ 1], dp, hh, out, part);
-                    if (s == 4) lp_epilogue<BF, LAST>(g - 1, 4, 6, acc[par ^ 1], dp, hh, out, part);
-                    if (s == 5) lp_epilogue<BF, LAST>(g - 1, 6, 8, acc[par ^ 1], dp, hh, out, part);
-                }
+                if (ks == LP_KQ * NCH - 1 && g + 1 < LP_NOG) lp_load_rows(bp, g + 1, gq, bias);   // the next group's bias
                 __builtin_amdgcn_sched_barrier(0);
             }
             rg.rd_slot = nx_slot;
         }
     }
     // the last group's epilogue has no MFMAs of its own pass to hide behind
-    lp_epilogue<BF, LAST>(LP_NOG - 1, 0, 8, acc[(LP_NOG - 1) & 1], dp, hh, out, part);
+    lp_epilogue<BF, LAST>(LP_NOG - 1, 0, LP_RT, acc[(LP_NOG - 1) & 1], dp, gq, out, part);
 }
 
 template <bool BF>
@@ -239,8 +231,8 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hh = lane >> 5;    // which half of each 8-row block / of each k-step's 16 k indices this lane holds
-    const int pl = lane & 31;    // point of this lane inside the wave
+    const int gq = lane >> 4;    // which 4-row block of each 16-row tile / which 8 of each step's 32 k slots this lane holds
+    const int pl = lane & 15;    // this lane's point inside each of the wave's two 16-point column blocks
 
     float* bias_l = reinterpret_cast<float*>(smem);
     float* cb_l = reinterpret_cast<float*>(smem + BIAS_BYTES);
@@ -275,41 +267,50 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpArgs a) {
         lp_issue_next(rg);
     }
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(GLDS_PER_CHUNK * (LP_NBUF - 2)) : "memory");
-    u32x4 abuf[4][2];
+    u32x4 abuf[2][LP_RT];        // A fragments of the current step and of the next one
 #pragma unroll
-    for (int i = 0; i < LP_PREFETCH; ++i) {
-        abuf[i][0] = *reinterpret_cast<const u32x4*>(ring_ptr + lane * 16 + i * LP_KSTEP_BYTES);
-        abuf[i][1] = *reinterpret_cast<const u32x4*>(ring_ptr + lane * 16 + i * LP_KSTEP_BYTES + 1024);
+    for (int rt = 0; rt < LP_RT; ++rt) {
+        abuf[0][rt] = *reinterpret_cast<const u32x4*>(ring_ptr + lane * 16 + rt * LP_FRAG_BYTES);
+        abuf[1][rt] = (u32x4){0u, 0u, 0u, 0u};
     }
 
     u32x4 X[32], Y[32];
-    f32x16 acc[2][2];
+    f32x4 acc[2][LP_RT][2];
 #pragma unroll
     for (int i = 0; i < 32; ++i) { X[i] = (u32x4){0u, 0u, 0u, 0u}; Y[i] = (u32x4){0u, 0u, 0u, 0u}; }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int rt = 0; rt < LP_RT; ++rt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int blk = 0; blk < 2; ++blk) acc[i][rt][blk] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float* wl = bias_l + a.wlast_row * WIDTH;
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int4 td = a.direct.kind ? direct_tile(a.direct, dl, tile, LP_TILE_PTS) : a.tiles[tile];
-        const int local = wave * LP_WAVE_PTS + pl;
-        const bool valid = local < td.y;
-        const int pidx = td.x + (valid ? local : 0);
-        const int src = a.index ? a.index[pidx] : pidx;
-        float4 pt = a.pts[src];
-        if (!valid) pt = make_float4(0.f, 0.f, 0.f, 0.f);
+        // this lane's two points: one per 16-point column block of the wave
+        bool valid[2];
+        int pidx[2], src[2];
+        float4 pt[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const int local = wave * LP_WAVE_PTS + 16 * blk + pl;
+            valid[blk] = local < td.y;
+            pidx[blk] = td.x + (valid[blk] ? local : 0);
+            src[blk] = a.index ? a.index[pidx[blk]] : pidx[blk];
+            pt[blk] = a.pts[src[blk]];
+            if (!valid[blk]) pt[blk] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         reinterpret_cast<float4*>(cb_l)[tid] = reinterpret_cast<const float4*>(a.code_bias + (size_t)td.z * a.code_bias_stride)[tid];
         __syncthreads();
 
-        // split-precision xyz operands (LP_XYZ_TERMS): MFMA k index 3 t + c of k-step u carries part xpart(t) of coordinate c
-        u32x4 xb[LP_XYZ_KSTEPS];
-        {
+        // split-precision xyz operands (LP_XYZ_TERMS): k slot 16 u + 3 t + c of the xyz step carries part xpart(u, t) of coordinate c
+        // (u = which of the table's two 16-slot halves); this lane holds slots 8 gq .. 8 gq + 7
+        u32x4 xb[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
             float xp[4][3];
-            const float xyz[3] = {pt.x, pt.y, pt.z};
+            const float xyz[3] = {pt[blk].x, pt[blk].y, pt[blk].z};
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 xp[0][c] = 0.f;
@@ -317,44 +318,48 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpArgs a) {
                 xp[2][c] = lp_round<BF>(xyz[c] - xp[1][c]);
                 xp[3][c] = lp_round<BF>(xyz[c] - xp[1][c] - xp[2][c]);
             }
+            float kv[32];
 #pragma unroll
-            for (int u = 0; u < LP_XYZ_KSTEPS; ++u) {
-                float kv[16];
+            for (int kk = 0; kk < 32; ++kk) {
+                const int u = kk >> 4, k16 = kk & 15, t = k16 / 3;
+                const int ent = (t < 5) ? LP_XYZ_TERMS[BF ? 1 : 0][u][t] : 0;
+                kv[kk] = ent ? xp[ent >> 2][k16 % 3] : 0.f;
+            }
 #pragma unroll
-                for (int kk = 0; kk < 16; ++kk) {
-                    const int t = kk / 3;
-                    const int ent = (t < 5) ? LP_XYZ_TERMS[BF ? 1 : 0][u][t] : 0;
-                    kv[kk] = ent ? xp[ent >> 2][kk % 3] : 0.f;
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const unsigned lo = lp_pack<BF>(kv[2 * q], kv[2 * q + 1]);
-                    const unsigned hi = lp_pack<BF>(kv[8 + 2 * q], kv[8 + 2 * q + 1]);
-                    xb[u][q] = hh ? hi : lo;
-                }
+            for (int q = 0; q < 4; ++q) {
+                const unsigned v0 = lp_pack<BF>(kv[2 * q], kv[2 * q + 1]), v1 = lp_pack<BF>(kv[8 + 2 * q], kv[8 + 2 * q + 1]);
+                const unsigned v2 = lp_pack<BF>(kv[16 + 2 * q], kv[16 + 2 * q + 1]), v3 = lp_pack<BF>(kv[24 + 2 * q], kv[24 + 2 * q + 1]);
+                xb[blk][q] = gq == 0 ? v0 : (gq == 1 ? v1 : (gq == 2 ? v2 : v3));
             }
         }
 
-        float part = 0.f;
-        // slabs ping-pong: the first layer reads Y (its xyz k-steps) and writes X, layer 1 reads X and writes Y, ...
+        float part[2] = {0.f, 0.f};
+        // slabs ping-pong: the first layer reads Y (its xyz step) and writes X, layer 1 reads X and writes Y, ...
         auto bias_of = [&](const LpPass& pd) { return pd.bias_row == -2 ? cb_l + WIDTH : (pd.bias_row == -3 ? cb_l : bias_l + pd.bias_row * WIDTH); };
         // Pass bodies: first layer (Y -> X), hidden layers X -> Y and Y -> X, and the LAST hidden layer, which reads X and writes no
         // slab (only the final layer's dot product on the un-rounded accumulators).  The pass count is even (pack_decoder_lp_host
         // refuses others: the prepass is then off), so the last layer's input is always in X and the loop has no conditional half --
         // a join there costs ~120 spilled registers per tile.
         const int n_mid = a.n_pass - 2;      // hidden layers between the first and the last one
-        lp_pass<BF, 1, false>(a.pass[0], Y, X, acc, abuf, rg, xb, bias_of(a.pass[0]), zero_l, lane, hh, part);
+        lp_pass<BF, 1, false>(a.pass[0], Y, X, acc, abuf, rg, xb, bias_of(a.pass[0]), zero_l, lane, gq, part);
         for (int ps = 1; ps < n_mid; ps += 2) {       // n_mid is even (the host refuses odd pass counts): always both halves, no join
-            lp_pass<BF, LP_NCH, false>(a.pass[ps], X, Y, acc, abuf, rg, xb, bias_of(a.pass[ps]), zero_l, lane, hh, part);
-            lp_pass<BF, LP_NCH, false>(a.pass[ps + 1], Y, X, acc, abuf, rg, xb, bias_of(a.pass[ps + 1]), zero_l, lane, hh, part);
+            lp_pass<BF, LP_NCH, false>(a.pass[ps], X, Y, acc, abuf, rg, xb, bias_of(a.pass[ps]), zero_l, lane, gq, part);
+            lp_pass<BF, LP_NCH, false>(a.pass[ps + 1], Y, X, acc, abuf, rg, xb, bias_of(a.pass[ps + 1]), zero_l, lane, gq, part);
         }
-        lp_pass<BF, LP_NCH, true>(a.pass[a.n_pass - 1], X, Y, acc, abuf, rg, xb, bias_of(a.pass[a.n_pass - 1]), wl, lane, hh, part);
-        part += __shfl_xor(part, 32);
-        float y = tanhf(part + a.b_last);
+        lp_pass<BF, LP_NCH, true>(a.pass[a.n_pass - 1], X, Y, acc, abuf, rg, xb, bias_of(a.pass[a.n_pass - 1]), wl, lane, gq, part);
+        // a point's 512 rows are spread over the four lane groups: lanes p, p + 16, p + 32, p + 48
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            part[blk] += __shfl_xor(part[blk], 16);
+            part[blk] += __shfl_xor(part[blk], 32);
+        }
+        // lane group 0 stores the point of column block 0, lane group 1 that of column block 1
+        const int sb = gq & 1;
+        float y = tanhf((sb ? part[1] : part[0]) + a.b_last);
         // exactly 1.0f is the optimiser's "never decoded" placeholder (gn_kernels.hip: sample_write_ray): a prepass value never takes it.
         // (tanh saturates to 1.0f above ~9 -- or after an f16 overflow upstream.)  NaN stays NaN: the band kernels send it to the fp32 kernel.
         if (y >= 1.0f) y = 0x1.fffffep-1f;
-        if (valid && hh == 0) a.out_sdf[a.index ? src : pidx + td.w] = y;
+        if (gq < 2 && (sb ? valid[1] : valid[0])) a.out_sdf[a.index ? (sb ? src[1] : src[0]) : (sb ? pidx[1] : pidx[0]) + td.w] = y;
         // stores and LDS-DMA share vmcnt and may retire out of order: drain before counting again
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }

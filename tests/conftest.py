@@ -75,3 +75,19 @@ def chairs32_decoder():
     from dsp_slam_amd import fixtures
     from oracle import dsp_oracle
     return dsp_oracle.fold_decoder(fixtures.load_decoder_npz(fixtures.fixture_path("chairs32")), fixtures.fixture_specs("chairs32"))
+
+
+def have_complex_fixture():
+    from dsp_slam_amd import fixtures
+    return os.path.exists(fixtures.fixture_path("complex")) and os.path.exists(os.path.join(GOLDEN, "golden_recon_complex.npz"))
+
+
+@pytest.fixture(scope="session")
+def complex_decoder():
+    """The third fixture decoder (round 5): fitted to a non-convex multi-part shape family whose parameters depend on all 64 code dimensions
+    (synth.complex_car_sdf; tools/fit_decoder_gpu.py --shape complex); oracle form."""
+    from dsp_slam_amd import fixtures
+    from oracle import dsp_oracle
+    if not have_complex_fixture():
+        pytest.skip("tests/golden/decoder_complex.npz not generated")
+    return dsp_oracle.fold_decoder(fixtures.load_decoder_npz(fixtures.fixture_path("complex")), fixtures.fixture_specs("complex"))

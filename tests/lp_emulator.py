@@ -1,12 +1,14 @@
-"""Numpy model of ONE WAVE of dsp_slam_amd/csrc/mlp_lp_kernel.hip (32 points, 64 lanes): the low-precision prepass.
+"""Numpy model of ONE WAVE of dsp_slam_amd/csrc/mlp_lp_kernel.hip (32 points as two 16-point column blocks, 64 lanes): the low-precision
+prepass.
 
 Test infrastructure.  It consumes the exact packed 16-bit weight stream / pass table the library uploads
 (dsp_debug_pack_prepass, host-only) and replays the kernel's register-level data flow: slabs indexed
-[k-step][lane][8 halves], v_mfma_f32_32x32x16 operand / result lane maps, the split-precision xyz k-steps,
+[32-k step][column block][lane][8 halves], v_mfma_f32_16x16x32 operand / result lane maps, the split-precision xyz step,
 fp32 bias as accumulator seed, relu + round-to-nearest-even packing into the next layer's slab, the final
-fp32 dot product.  Lane maps (cdna_hip_programming.md section 3):
-  A[i = l & 31][k = 8 (l >> 5) + e],  B[k = 8 (l >> 5) + e][j = l & 31],
-  D[row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][col = l & 31]  for accumulator register r in [0, 16).
+fp32 dot product.  Lane maps (cdna_hip_programming.md section 3; round 5: 16x16x32, rounds 2-4 used 32x32x16):
+  A[i = l & 15][k slot = 8 (l >> 4) + e],  B[k slot = 8 (l >> 4) + e][j = l & 15],
+  D[row = 4 (l >> 4) + r][col = l & 15]  for accumulator register r in [0, 4).
+(The hardware's k index of a slot is irrelevant: A and B use the same slot -> k map, and the sum over k does not care.)
 """
 import ctypes as C
 
@@ -15,10 +17,10 @@ import numpy as np
 from dsp_slam_amd import _lib as L
 
 LANES = np.arange(64)
-HH = LANES >> 5
-PL = LANES & 31
+GQ = LANES >> 4
+PL = LANES & 15
 NCH = 4
-XYZ_KSTEPS = 2
+KQ = 4              # 32-k steps per chunk
 # dsp_internal.h LP_XYZ_TERMS: [dtype][k-step][term] = 4 * xpart + wpart, 0 = unused
 XYZ_TERMS = {
     L.PREPASS_F16: [[5, 9, 6, 10, 0], [0, 0, 0, 0, 0]],
@@ -53,29 +55,29 @@ def debug_pack(holder, dtype):
     passes = np.zeros((meta[0], 8), np.int32)
     L.check(lib.dsp_debug_pack_prepass(C.byref(holder.desc), dtype, stream.ctypes.data_as(C.POINTER(C.c_uint16)), C.byref(slen),
                                        L.ptr(passes, L.c_i32p), L.ptr(meta, L.c_i32p)), None, "dsp_debug_pack_prepass")
-    # [chunk][k-step 8][row tile 2][lane 64][8 halves]
-    return dict(stream=lp_decode(stream, dtype).reshape(-1, 8, 2, 64, 8), passes=passes, n_pass=int(meta[0]), chunks=int(meta[1]))
+    # [chunk][step of 32 k: 4][16-row tile: 4][lane 64][8 halves]
+    return dict(stream=lp_decode(stream, dtype).reshape(-1, KQ, 4, 64, 8), passes=passes, n_pass=int(meta[0]), chunks=int(meta[1]))
 
 
-def mfma32(a, b, acc):
-    """a, b: (64, 8) per-lane operands; acc (16, 64) [reg][lane] fp32.  D = A @ B + C in the lane maps above (fp64 sum, rounded once)."""
-    A = np.zeros((32, 16), np.float64)
-    B = np.zeros((16, 32), np.float64)
+def mfma16(a, b, acc):
+    """a, b: (64, 8) per-lane operands; acc (4, 64) [reg][lane] fp32.  D = A @ B + C in the lane maps above (fp64 sum, rounded once)."""
+    A = np.zeros((16, 32), np.float64)
+    B = np.zeros((32, 16), np.float64)
     for e in range(8):
-        A[PL, 8 * HH + e] = a[:, e]
-        B[8 * HH + e, PL] = b[:, e]
+        A[PL, 8 * GQ + e] = a[:, e]
+        B[8 * GQ + e, PL] = b[:, e]
     D = A @ B
     out = acc.astype(np.float64).copy()
-    for r in range(16):
-        out[r] += D[(r & 3) + 8 * (r >> 2) + 4 * HH, PL]
+    for r in range(4):
+        out[r] += D[4 * GQ + r, PL]
     return out.astype(np.float32)
 
 
-def rows_in_d_order(tab512, g, j):
-    """fp32 table rows of group g, row tile j as [reg][lane]."""
-    out = np.zeros((16, 64), np.float32)
-    for r in range(16):
-        out[r] = tab512[64 * g + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * HH]
+def rows_in_d_order(tab512, g, rt):
+    """fp32 table rows of group g, 16-row tile rt as [reg][lane]."""
+    out = np.zeros((4, 64), np.float32)
+    for r in range(4):
+        out[r] = tab512[64 * g + 16 * rt + 4 * GQ + r]
     return out
 
 
@@ -85,51 +87,61 @@ def run_wave(pk_fp32, pk_lp, code, pts32, dtype):
     bias = pk_fp32["bias"]
     cb = pk_fp32["code_bias"](code)               # [0:512] layer 0, [512:1024] latent_in layer
     wl = bias[pk_fp32["wlast_row"]]
-    p = np.asarray(pts32, np.float32)[PL]          # (64, 3): both half-lanes of a point hold it
-    xp = np.zeros((4, 64, 3), np.float32)
-    xp[1] = lp_round(p, dtype)
-    xp[2] = lp_round(p - xp[1], dtype)
-    xp[3] = lp_round(p - xp[1] - xp[2], dtype)
-    xb = np.zeros((XYZ_KSTEPS, 64, 8), np.float32)
-    for u in range(XYZ_KSTEPS):
+    pts32 = np.asarray(pts32, np.float32)
+    xb = np.zeros((2, 64, 8), np.float32)          # [column block][lane][8 slots]
+    for blk in range(2):
+        p = pts32[16 * blk + PL]                   # (64, 3): the four lane groups of a point hold it
+        xp = np.zeros((4, 64, 3), np.float32)
+        xp[1] = lp_round(p, dtype)
+        xp[2] = lp_round(p - xp[1], dtype)
+        xp[3] = lp_round(p - xp[1] - xp[2], dtype)
         for e in range(8):
-            kk = 8 * HH + e
+            kk = 8 * GQ + e                        # slot 0..31 = 16 u + 3 t + c
             for lane in range(64):
-                t = kk[lane] // 3
+                u, k16 = kk[lane] >> 4, kk[lane] & 15
+                t = k16 // 3
                 ent = XYZ_TERMS[dtype][u][t] if t < 5 else 0
-                xb[u, lane, e] = xp[ent >> 2, lane, kk[lane] % 3] if ent else 0.0
-    slabs = [np.zeros((32, 64, 8), np.float32), np.zeros((32, 64, 8), np.float32)]   # X, Y
-    part = np.zeros(64, np.float32)
+                xb[blk, lane, e] = xp[ent >> 2, lane, k16 % 3] if ent else 0.0
+    slabs = [np.zeros((16, 2, 64, 8), np.float32), np.zeros((16, 2, 64, 8), np.float32)]   # X, Y: [step][block][lane][slot]
+    part = np.zeros((2, 64), np.float32)
     for ps in range(pk_lp["n_pass"]):
         nog, nchunks, bias_row, kind, npad, last, chunk_base, _ = [int(v) for v in pk_lp["passes"][ps]]
         src, dst = (slabs[1], slabs[0]) if ps % 2 == 0 else (slabs[0], slabs[1])      # even passes read Y, write X
         if kind == 0:
-            src[:8] = 0.0
-            src[:XYZ_KSTEPS] = xb
+            src[:KQ] = 0.0
+            src[0] = xb
         elif kind == 2:
-            src[8 * NCH - XYZ_KSTEPS:8 * NCH] = xb
-            for t in range(1, npad + 1):
-                src[8 * NCH - XYZ_KSTEPS - t] = 0.0
+            kx = KQ * NCH - 1
+            src[kx] = xb
+            for t in range(1, npad + 1):           # padding 16-row tile 2 kx - t = half (T & 1) of step T >> 1
+                T = 2 * kx - t
+                src[T >> 1, :, :, 4 * (T & 1):4 * (T & 1) + 4] = 0.0
         tab = cb[512:] if bias_row == -2 else (cb[:512] if bias_row == -3 else bias[bias_row])
         for g in range(nog):
-            acc = [rows_in_d_order(tab, g, 0), rows_in_d_order(tab, g, 1)]
+            acc = [[rows_in_d_order(tab, g, rt) for _ in range(2)] for rt in range(4)]
             for c in range(nchunks):
                 chunk = pk_lp["stream"][chunk_base + g * nchunks + c]
-                for sl in range(8):
-                    s = 8 * c + sl
-                    for j in range(2):
-                        acc[j] = mfma32(chunk[sl, j], src[s], acc[j])
-            for j in range(2):
-                if last:
-                    w = rows_in_d_order(wl, g, j)
-                    for r in range(16):
-                        part = (part + np.maximum(acc[j][r], 0) * w[r]).astype(np.float32)
-                else:
-                    v = lp_round(np.maximum(acc[j], 0.0), dtype)           # (16, 64)
-                    for r in range(16):
-                        dst[4 * g + 2 * j + (r >> 3), :, r & 7] = v[r]
-    tot = part[:32] + part[32:]
-    return np.tanh(tot + np.float32(pk_fp32["b_last"])).astype(np.float32)
+                for kq in range(KQ):
+                    ks = KQ * c + kq
+                    for rt in range(4):
+                        for blk in range(2):
+                            acc[rt][blk] = mfma16(chunk[kq, rt], src[ks, blk], acc[rt][blk])
+            for rt in range(4):
+                T = 4 * g + rt
+                for blk in range(2):
+                    if last:
+                        w = rows_in_d_order(wl, g, rt)
+                        for r in range(4):
+                            part[blk] = (part[blk] + np.maximum(acc[rt][blk][r], 0) * w[r]).astype(np.float32)
+                    else:
+                        v = lp_round(np.maximum(acc[rt][blk], 0.0), dtype)           # (4, 64)
+                        for r in range(4):
+                            dst[T >> 1, blk, :, 4 * (T & 1) + r] = v[r]
+    out = np.zeros(32, np.float32)
+    for blk in range(2):
+        tot = part[blk][:16] + part[blk][16:32] + part[blk][32:48] + part[blk][48:]
+        out[16 * blk:16 * blk + 16] = tot
+    return np.tanh(out + np.float32(pk_fp32["b_last"])).astype(np.float32)
 
 
 def reference_forward(dec, code, pts, dtype):

@@ -1,0 +1,120 @@
+"""GPU: does the headline survive a decoder of realistic geometric complexity?  
+
+Every number of rounds 1-4 came from two decoders fitted to a rounded box whose shape depends on 3 of the 64 code dimensions.  The third
+fixture (tests/golden/decoder_complex.npz; tools/fit_decoder_gpu.py --shape complex) is fitted to synth.complex_car_sdf -- body + cabin
+(smooth union), four wheel cylinders, a thin floating spoiler plate -- with codes drawn N(0, 0.1^2 I) on ALL 64 dimensions.  Goldens:
+golden_decoder_complex.npz and golden_recon_complex.npz (one cfg2-size object, KITTI hyper-parameters, full per-iteration trace),
+recorded from the unmodified reference by tools/make_golden.py complex.
+
+Here: the decoder kernels against the reference's values; the prepass calibration table of THIS decoder (largest f16 error per code
+magnitude); the prepass exact on a batch of such objects (bit-identical to prepass off, audit finds nothing, guard silent); the numbers
+the bench would print for 64 of them, prepass on / off.  The at-reference-state forensics of the recorded run is the
+`golden_recon_complex.npz` case of tests/test_gpu_forensics.py.
+"""
+import json
+import time
+
+import numpy as np
+import pytest
+
+from conftest import golden, have_complex_fixture, parity_log
+from dsp_slam_amd import engine as E, synth, _lib as L
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not have_complex_fixture(), reason="complex fixture not generated")]
+
+F_FWD, F_JAC = 3671040.0, 7342080.0
+
+
+@pytest.fixture(scope="module")
+def eng(complex_decoder):
+    e = E.Engine(complex_decoder.layers, complex_decoder.latent_in, complex_decoder.code_len, device=0)
+    yield e
+    e.close()
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def test_complex_decoder_vs_reference_golden(eng):
+    g = golden("golden_decoder_complex.npz")
+    assert np.abs(eng.decode_sdf(g["code"], g["pts"]) - g["sdf"]).max() < 5e-6
+    sdf, grad = eng.sdf_jacobian(g["code"], g["pts"])
+    assert np.abs(sdf - g["y_jac"]).max() < 5e-6 and rel(grad, g["grad"]) < 2e-5
+    # the code gradient is spread over all 64 dimensions on this decoder (the rounded-box fixtures: three)
+    strong = (np.abs(g["grad"][:, :64]).max(0) > 0.05 * np.abs(g["grad"][:, :64]).max()).sum()
+    assert strong >= 32, strong
+
+
+def test_complex_prepass_calibration_table(eng):
+    tab = eng.prepass_calibration_table(L.PREPASS_F16)
+    mags, err, delta, guard = tab["mags"], tab["max_err"], tab["delta"], tab["guard_err"]
+    print("complex decoder, f16 prepass calibration: |z|inf %s  max err %s  margin %s" % (np.round(mags, 3), err, delta))
+    parity_log(kind="complex_calibration", case="decoder_complex f16 prepass calibration (dsp_create)", mags=mags, max_err=err, delta=delta, guard_err=float(guard))
+    assert np.all(np.diff(delta) >= 0) and delta[0] >= 5e-4 and np.all(err > 0)
+    # the optimiser's codes on this family have |z|inf ~ 0.3: the margin there
+    assert delta[2] < 0.01, "a margin as wide as the cut-off itself would send every sample to the fp32 kernel"
+
+
+def test_complex_prepass_is_exact_and_pays(eng):
+    """A batch of cfg2-size objects of the complex family: prepass on == prepass off, bit for bit; the audit (every in-sphere sample also
+    decoded in fp32) finds no misclassified sample; the guard stays silent; and the prepass still removes most of the fp32 forward work."""
+    n_obj = 64
+    objs = [synth.make_object(9000 + i, n_surface=2000, n_background=500, shape="complex") for i in range(n_obj)]
+    prm = E.gn_params()
+    args = ([o["t_cam_obj_init"] for o in objs], [o["pts"] for o in objs], [o["rays"] for o in objs], [o["depth"] for o in objs])
+    out = {}
+    for mode in ("on", "off"):
+        b = eng.batch(prm, *args)
+        b.set_kernel_timing(1)
+        if mode == "off":
+            b.set_prepass(0)
+        b.run()
+        ts = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            b.run()
+            ts.append(time.perf_counter() - t0)
+        out[mode] = (b.results(), b.stats(), min(ts))
+        b.close()
+    (r_on, st_on, t_on), (r_off, st_off, t_off) = out["on"], out["off"]
+    for x, y in zip(r_on, r_off):
+        assert np.array_equal(x, y, equal_nan=True), "prepass on differs from prepass off on the complex decoder"
+    good = int((r_on[3] == 0).sum())
+    assert good >= n_obj - 4, r_on[3]
+    assert st_on["prepass_guard_trips"] == 0 and st_on["prepass_guard_rerun"] == 0
+    ba = eng.batch(prm, *[a[:16] for a in args])
+    ba.set_prepass_audit(True)
+    ba.run()
+    sa = ba.stats()
+    ba.close()
+    assert sa["prepass_audited"] > 1e6 and sa["prepass_misclassified"] == 0, sa
+    frac = st_on["n_fwd_points"] / st_on["n_insphere_points"]
+    rec = dict(objects=n_obj, objects_good=good, objects_per_s_prepass_on=n_obj / t_on, objects_per_s_prepass_off=n_obj / t_off,
+               fwd_points_evaluated_over_insphere=frac, prepass_delta_zero_code=st_on["prepass_delta"], guard_max_err=st_on["prepass_guard_max_err"],
+               audit_max_err=sa["prepass_max_err"], audited=sa["prepass_audited"],
+               fwd_fp32_frac=st_on["n_fwd_points"] * F_FWD / (st_on["ms_mlp_fwd"] * 1e-3) / 157.3e12,
+               prepass_tflops=st_on["n_prepass_points"] * F_FWD / (st_on["ms_mlp_prepass"] * 1e-3) / 1e12,
+               prepass_off_fwd_fp32_frac=st_off["n_fwd_points"] * F_FWD / (st_off["ms_mlp_fwd"] * 1e-3) / 157.3e12,
+               sum_V=st_on["n_insphere_points"], sum_K=st_on["n_render_rows"])
+    print("complex decoder, 64 cfg2-size objects:", json.dumps(rec))
+    parity_log(kind="complex_bench", case="64 cfg2-size objects of the complex shape family on decoder_complex", **rec)
+    assert frac < 0.5, "the prepass classifies less than half of the samples on this decoder: %.3f go to the fp32 kernel" % frac
+    assert n_obj / t_on > 1.3 * n_obj / t_off
+
+
+def test_complex_reconstruct_end_to_end(eng):
+    """The recorded cfg2-size object of the complex family, all ten iterations chained, against the reference's result inside the
+    reference's own spread (1-ulp inputs and thread counts: golden ulps_* / thr_*)."""
+    import test_gpu_parity as P
+    g = golden("golden_recon_complex.npz")
+    prm = E.params_from_configs(json.loads(str(g["cfg_json"])))
+    t, code, loss, status = eng.reconstruct_batch(prm, [g["in_t_cam_obj_init"]], [g["in_pts"]], [g["in_rays"]], [g["in_depth"]])
+    assert status[0] == 0 and bool(g["is_good"])
+    m, sens, n_draws = P.end_to_end_differences(g, t[0], code[0])
+    parity_log(kind="end_to_end", case="golden_recon_complex.npz", n_draws=n_draws, **{k: v for k, v in m.items() if k != "thread_spread"},
+               **{k + "_sens": v for k, v in sens.items()})
+    print("complex: rot %.2e (%.2e) scale %.2e (%.2e) trans %.2e (%.2e) code %.2e (%.2e)" % (
+        m["rot"], sens["rot"], m["scale"], sens["scale"], m["trans"], sens["trans"], m["code"], sens["code"]))
+    for q in ("rot", "scale", "trans", "code"):
+        assert m[q] <= max(1e-4, P.E2E_SPREAD_FACTOR * sens[q]), (q, m[q], sens[q])

@@ -28,6 +28,9 @@ pytestmark = pytest.mark.gpu
 # Redwood hyper-parameters) -- and a fixture on which the reference's OWN 1-ulp spread is below 1e-4 (9.3e-5 pose / 4.4e-5 code)
 CASES = ["golden_recon_small.npz", "golden_recon_cfg1.npz", "golden_recon_redwood.npz", "golden_recon_freiburg.npz", "golden_recon_cfg2.npz",
          "golden_recon_chairs32.npz", "golden_recon_cfg5.npz"]
+# round 5: one cfg2-size object on the decoder fitted to the complex (non-convex, all-64-dims) shape family
+if os.path.exists(os.path.join(ROOT, "tests", "golden", "golden_recon_complex.npz")) and os.path.exists(os.path.join(ROOT, "tests", "golden", "decoder_complex.npz")):
+    CASES.append("golden_recon_complex.npz")
 
 
 class _Engines(object):
@@ -39,6 +42,8 @@ class _Engines(object):
     def __call__(self, code_len):
         if code_len not in self.engines:
             d = self.decoders[code_len]
+            if callable(d):                  # created on first use (the complex fixture may be absent)
+                d = self.decoders[code_len] = d()
             self.engines[code_len] = E.Engine(d.layers, d.latent_in, d.code_len, device=0)
         return self.engines[code_len], self.decoders[code_len]
 
@@ -49,7 +54,10 @@ class _Engines(object):
 
 @pytest.fixture(scope="module")
 def eng(oracle_decoder, chairs32_decoder):
-    es = _Engines({64: oracle_decoder, 32: chairs32_decoder})
+    def complex_dec():
+        from dsp_slam_amd import fixtures
+        return O.fold_decoder(fixtures.load_decoder_npz(fixtures.fixture_path("complex")), fixtures.fixture_specs("complex"))
+    es = _Engines({64: oracle_decoder, 32: chairs32_decoder, "complex": complex_dec})
     yield es
     es.close()
 
@@ -57,7 +65,7 @@ def eng(oracle_decoder, chairs32_decoder):
 def _setup(engines, g):
     cfg = json.loads(str(g["cfg_json"]))
     prm, oprm = E.params_from_configs(cfg), O.GNParams.from_configs(cfg)
-    e, dec = engines(cfg["optimizer"]["code_len"])
+    e, dec = engines("complex" if os.path.basename(cfg["DeepSDF_DIR"]).startswith("complex") else cfg["optimizer"]["code_len"])
     code0 = [g["in_code"]] if "in_code" in g.files else None
     b = e.batch(prm, [g["in_t_cam_obj_init"]], [g["in_pts"]], [g["in_rays"]], [g["in_depth"]], code0, trace=True)
     return cfg, prm, oprm, b, dec

@@ -102,3 +102,26 @@ def test_more_ranks_than_objects(tmp_path):
     assert sorted(b - a for a, b in shards) == [0, 1, 1]
     torch.set_num_threads(2)
     assert np.array_equal(got, _solve(_objects()[:2]))
+
+
+def test_measured_cost_partitioner_balances_uneven_objects():
+    """distributed.measured_cost / shard_objects (round 5): objects of identical (M, R) but very different kept-row counts K -- the bench
+    batch spans 4.8 k ... 21 k -- get shards of equal summed cost, not of equal count; every object lands in exactly one shard, in order;
+    the static cost R*D + 2M (identical for all of them) would cut equal counts."""
+    rng = np.random.default_rng(3)
+    n = 1024
+    V = rng.integers(80000, 110000, size=n)
+    K = np.where(np.arange(n) < n // 2, rng.integers(4000, 7000, size=n), rng.integers(15000, 21000, size=n))      # the heavy half at the end
+    costs = [D.measured_cost(2000, V[i], 0.14 * V[i], K[i]) for i in range(n)]
+    for world in (2, 3, 8):
+        shards = D.shard_objects(costs, world)
+        assert shards[0][0] == 0 and shards[-1][1] == n and all(shards[r][1] == shards[r + 1][0] for r in range(world - 1))
+        per = np.array([sum(costs[a:b]) for a, b in shards])
+        assert per.max() / per.mean() < 1.02, (world, per / per.mean())
+        counts = np.array([b - a for a, b in shards])
+        assert counts.max() > counts.min()                   # equal cost, not equal count
+        static = D.shard_objects([D.object_cost(2000, 2500)] * n, world)
+        per_static = np.array([sum(costs[a:b]) for a, b in static])
+        assert per_static.max() / per_static.mean() > per.max() / per.mean()
+    # the model's terms: prepass on -> V is cheap (f16 rate), the band and the rows dominate; prepass off -> V at the fp32 rate
+    assert D.measured_cost(2000, 100000, 14000, 5000, prepass=False) > 2.0 * D.measured_cost(2000, 100000, 14000, 5000, prepass=True)

@@ -57,7 +57,9 @@ def table_only(name):
 
 
 def main():
-    b, boff, b4, b5 = bench("bench.json"), bench("bench_prepass_off.json"), bench("bench_cfg4.json"), bench("bench_cfg5.json")
+    b, b4, b5 = bench("bench.json"), bench("bench_cfg4.json"), bench("bench_cfg5.json")
+    boff = bench("bench_prepass_off.json") if os.path.exists(os.path.join(SRC, "bench_prepass_off.json")) else None
+    cmd = "python bench.py --steps %d --warmup %d" % (b["steps"], b["warmup"])
 
     # ---- bench lines -------------------------------------------------------------------------------------------------------------
     def row(label, d):
@@ -65,56 +67,52 @@ def main():
         return "| %s | %.1f | %.1f | %.3f | %.3f | %s |" % (label, d["value"], d["ms_per_step"], r["frac"], r["jac_kernel_frac"],
                                                          "%.0f (%.3f)" % (p["achieved"], p["frac"]) if p else "-")
     lines = ["# Round %s -- bench lines" % ROUND + " as printed on an MI355X (one gpurun call, `tools/run_profiles.sh`; this file by `tools/make_profiles.py`)",
-             "", "`python bench.py --steps 5 --warmup 1 [--config ...] [--prepass off]`", "",
+             "", "`%s [--config ...]` (cfg2x64: the driver's own command)" % cmd, "",
              "| config | objects/s | ms per step | fp32 forward kernel frac of 157.3 TFLOP/s | jacobian kernels frac | prepass kernel TFLOP/s (frac of 2500) |", "|---|---|---|---|---|---|",
-             row("cfg2x64", b), row("cfg2x64, prepass off", boff), row("cfg4", b4), row("cfg5", b5), ""]
-    for title, d in (("cfg2x64 (the headline configuration), f16 prepass", b), ("cfg2x64, --prepass off (round 1 behaviour)", boff),
-                     ("cfg4: 128 objects per GPU through shard_objects", b4), ("cfg5: 4000-point objects, Redwood hyper-parameters, cars + chairs32 decoders", b5)):
-        lines += ["## " + title, "", "```json", json.dumps(d), "```", ""]
+             row("cfg2x64 (dtype `%s`)" % b["dtype"], b)]
+    if "prepass_off" in b:
+        po = b["prepass_off"]
+        lines += ["| cfg2x64, prepass off = `value_fp32_only` (same process, %d steps) | %.1f | %.1f | %.3f | %.3f | - |" % (
+            po["steps"], po["value"], po["ms_per_step"], po["roofline_frac"], po["jac_kernel_frac"])]
+    if boff:
+        lines += [row("cfg2x64, --prepass off (own process)", boff)]
+    lines += [row("cfg4 (%s scaling: %d objects on this GPU)" % (b4["scaling"], b4["config"]["objects_per_gpu"]), b4), row("cfg5", b5), ""]
+    for title, d in (("cfg2x64 (the headline configuration), f16 prepass", b), ("cfg2x64, --prepass off (own process)", boff),
+                     ("cfg4: the 1024-object job (strong scaling; on one GPU the whole job is one shard)", b4),
+                     ("cfg5: 4000-point objects, Redwood hyper-parameters, cars + chairs32 decoders", b5)):
+        if d:
+            lines += ["## " + title, "", "```json", json.dumps(d), "```", ""]
     open(os.path.join(DST, TAG + "_bench_lines.md"), "w").write("\n".join(lines))
 
     # ---- kernel stats ------------------------------------------------------------------------------------------------------------
-    st = stats_rows("kernel_stats.md")
+    # rocprofv3 --kernel-trace --stats of the DRIVER'S command, split into the legs bench.py marks (tools/rocpd_legs.py): each population of a
+    # kernel -- one launch per iteration of 64 objects in the headline leg, ten shorter ones in the prepass-off leg, sub-millisecond ones
+    # in the one-object legs -- is compared with its own HIP-event figure.  (Round 4 averaged them all and printed a fraction above 1.)
     r = b["roofline"]
     by = r["ms_per_step_by_kernel"]
-    k1, k2, k2r, k0 = st[K1], st[K2], st[K2R], st[K0]
-    pts_per_launch = r["alg_flop_per_launch"] / F_FWD
     lp = b["prepass"]
-    others = sum(v["total_ms"] for k, v in st.items() if k not in (K1, K2, K2R, K0) and "mlp_" not in k)
-    n_steps = 6.0
-    text = ["# Round %s -- rocprofv3 kernel stats of the bench command" % ROUND, "",
-            "`cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --latency-runs 1 --no-prepass-off`",
-            "(64 cfg2 objects per step, f16 prepass on; 6 steps incl. the warm-up + the two latency probes).  Table by `tools/rocpd_stats.py`, this file by",
-            "`tools/make_profiles.py`.  The bench line of the same build, un-profiled: `profiles/" + TAG + "_bench_lines.md` (%.1f objects/s, %.1f ms per step)." % (b["value"], b["ms_per_step"]),
-            "", table_only("kernel_stats.md"), "", "Reading (per step of 64 objects x 10 iterations):", "",
-            "* `mlp_kernel<1>` (fp32 forward over the samples the prepass could not classify, relu masks exported): 10 launches, **%.2f ms average**"
-            % (k1["avg_us"] / 1e3),
-            "  (HIP events inside `bench.py`, un-profiled: %.2f ms) -- %.0f k points each = %.2f TFLOP per launch = **%.1f TFLOP/s = %.3f of the 157.3 TFLOP/s fp32 MFMA peak**"
-            % (r["avg_launch_ms"], pts_per_launch / 1e3, r["alg_flop_per_launch"] / 1e12, r["alg_flop_per_launch"] / (k1["avg_us"] * 1e-6) / 1e12,
-               r["alg_flop_per_launch"] / (k1["avg_us"] * 1e-6) / 1e12 / PEAK32),
-            "  (bench: %.3f).  Round 3: 20.95 ms (0.893); round 1: 100 launches x 10.2 ms." % r["frac"],
-            "* `mlp_kernel<3>` (render rows, backward sweep only from those masks): 10 launches x %.2f ms; `mlp_kernel<2>` (surface points, forward + backward):"
-            % (k2r["avg_us"] / 1e3),
-            "  10 x %.2f ms (the %d calls include the latency probes); together %.3f of peak in the bench." % (k2["avg_us"] / 1e3, k2["calls"], r["jac_kernel_frac"]),
-            "* `mlp_lp_kernel<f16>` (the prepass, `v_mfma_f32_32x32x16_f16`): 100 launches x %.2f ms = %.0f ms per step, %.0f k points per launch ="
-            % (lp["avg_launch_ms"], by["prepass"], lp["alg_flop_per_launch"] / F_FWD / 1e3),
-            "  %.2f TFLOP -> **%.2f PFLOP/s = %.3f of the 2.5 PFLOP/s dense 16-bit peak** (priced separately from the fp32 fraction)."
-            % (lp["alg_flop_per_launch"] / 1e12, lp["achieved"] / 1e3, lp["frac"]),
-            "* everything else (sampling, band selection, occupancy scan, compaction, Gram, solve, tile lists): %.1f ms per step = %.1f %%."
+    pts_per_launch = r["alg_flop_per_launch"] / F_FWD
+    prof = bench("bench_under_rocprof_full.txt")
+    text = ["# Round %s -- rocprofv3 kernel trace of the driver's bench command, leg by leg" % ROUND, "",
+            "`cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -- %s`" % cmd,
+            "(64 cfg2 objects per step; every leg of the process opens with one dispatch of the marker kernel `k_debug_lie`: headline warm-up / timed,",
+            "prepass-off warm-up / timed, clock probe, three latency probes, pose-only).  Tables by `tools/rocpd_legs.py` and `tools/rocpd_stats.py`, this file by",
+            "`tools/make_profiles.py`.  The JSON line printed by THIS profiled process: %.1f objects/s, %.1f ms per step, `roofline.frac` %.4f;" % (
+                prof["value"], prof["ms_per_step"], prof["roofline"]["frac"]),
+            "un-profiled, same build: `profiles/" + TAG + "_bench_lines.md` (%.1f objects/s, %.1f ms per step, `roofline.frac` %.4f)." % (b["value"], b["ms_per_step"], r["frac"]),
+            "", "## Per leg: trace vs the bench line's `roofline.rocprof_check`", "", read("legs.md").rstrip(), "",
+            "## Whole process, per kernel (`rocprofv3 --stats` view)", "",
+            "Averages in this table run over EVERY launch of a kernel in the process -- for `mlp_kernel<1>`, `<2>`, `<3>` and `mlp_lp_kernel` that mixes the legs above",
+            "(launches of 21 ms, 10 ms and < 1 ms): it is the per-leg table, not this one, that prices a kernel.", "",
+            table_only("kernel_stats_full.md"), "",
+            "Reading (headline leg, per step of 64 objects x 10 iterations): `mlp_kernel<1>` 10 launches of %.0f k points = %.2f TFLOP each; `mlp_kernel<2>` + `<3>`"
+            % (pts_per_launch / 1e3, r["alg_flop_per_launch"] / 1e12),
+            "together %.3f of the fp32 peak; `mlp_lp_kernel<f16>` 100 launches x %.2f ms = %.0f ms per step, %.2f PFLOP/s = %.3f of the 2.5 PFLOP/s dense 16-bit peak (priced"
+            % (r["jac_kernel_frac"], lp["avg_launch_ms"], by["prepass"], lp["achieved"] / 1e3, lp["frac"]),
+            "separately from the fp32 fraction); everything else (sampling, band selection, occupancy scan, compaction, Gram, solve, tile lists) %.1f ms per step = %.1f %%."
             % (by["other"], 100 * by["other"] / b["ms_per_step"]), ""]
-    # the command exactly as the driver runs it (default flags): its JSON line, printed under the profiler, carries roofline.rocprof_check
-    if os.path.exists(os.path.join(SRC, "kernel_stats_full.md")):
-        full = stats_rows("kernel_stats_full.md")
-        js = [ln for ln in read("bench_under_rocprof_full.txt").splitlines() if ln.startswith('{"metric"')]
-        if js and K1 in full:
-            chk = json.loads(js[-1])["roofline"]["rocprof_check"]
-            text += ["## The default command (`python bench.py --steps 5 --warmup 1 --no-cpu-baseline --latency-runs 1`: prepass-off leg included), same profiler", "",
-                     "rocprofv3: `mlp_kernel<1>` **%d calls, %.3f ms average**; the JSON line of that very process (`roofline.rocprof_check`, HIP events on the library's stream): "
-                     "%d launches, %.3f ms average -- difference %.2f %%.  (The average mixes the headline leg's one launch per iteration with the prepass-off leg's ten shorter ones;"
-                     % (full[K1]["calls"], full[K1]["avg_us"] / 1e3, chk["launches_in_this_process"], chk["avg_launch_ms_over_all_of_them"],
-                        100.0 * abs(full[K1]["avg_us"] / 1e3 - chk["avg_launch_ms_over_all_of_them"]) / chk["avg_launch_ms_over_all_of_them"]),
-                     "the table above profiles the headline leg alone.)", "", table_only("kernel_stats_full.md"), ""]
     open(os.path.join(DST, TAG + "_kernel_stats.md"), "w").write("\n".join(text))
+    st = stats_rows("kernel_stats_full.md")
 
     # ---- PMC ---------------------------------------------------------------------------------------------------------------------
     mf, dm = pmc("pmc_mfma.md")
@@ -128,20 +126,19 @@ def main():
     def clk(k):
         return mf[(k, "GRBM_GUI_ACTIVE")][1] / 8 / (dm[k][1] * 1e-3) / 1e9
 
-    n1 = 20        # 2 steps x 10 iterations of the bench batch; the cfg2-size latency probes add small mlp_kernel<1> launches (mixed mask reuse) on top
+    n1 = dm[K1][0]      # the PMC tables hold the headline leg only (rocpd_pmc.py --between 1 3: warm-up + timed step = 2 steps x 10 iterations)
+    assert n1 % 10 == 0, n1
     # points per launch from the un-profiled bench of the same run (same workload, same seeds)
     k1_pts = pts_per_launch * n1
     k1_fetch = fe[(K1, "FETCH_SIZE")][1] * 1024 * 2
-    k0_pts = lp["alg_flop_per_launch"] / F_FWD * 10 * (dm[K0][0] // 100) * 10     # 100 launches per step
-    steps_in_pmc = n1 / 10.0
-    k0_pts = lp["alg_flop_per_launch"] / F_FWD * 100 * steps_in_pmc
+    k0_pts = lp["alg_flop_per_launch"] / F_FWD * dm[K0][0]
     k0_fetch = fe[(K0, "FETCH_SIZE")][1] * 1024 * 2
     wave1 = mf[(K1, "SQ_WAVE_CYCLES")][1]
     wave0 = ld[(K0, "SQ_ACTIVE_INST_ANY")][1] + 0.0
     txt = ["# Round %s -- rocprofv3 PMC passes" % ROUND + " at the bench configuration", "",
            "Four separate `--pmc` passes (no `--stats`, no tracing; one counter group per run) over",
            "`python bench.py --steps 1 --warmup 1 --no-cpu-baseline --latency-runs 1` -- **64 objects per GPU, the bench configuration** (round 1's pass was",
-           "taken at 32).  2 steps = %d launches of the fp32 forward kernel `mlp_kernel<1>` (+ %d small ones from the cfg2-size latency probe, whose forward launch now exports masks too: < 2 %% of the counters), 200 of the prepass kernel (+ ~80 from the latency probes)." % (n1, dm[K1][0] - n1),
+           "taken at 32).  The tables hold the HEADLINE LEG only (`tools/rocpd_pmc.py ... --between 1 3`: the dispatches between bench.py's first and third marker): 2 steps = %d launches of the fp32 forward kernel `mlp_kernel<1>`, %d of the prepass kernel." % (n1, dm[K0][0]),
            "Tables by `tools/rocpd_pmc.py` (kernels matching `mlp_`), this file by `tools/make_profiles.py`.", "",
            "## FETCH_SIZE (KiB)", "", table_only("pmc_fetch.md"), "", "## WRITE_SIZE (KiB)", "", table_only("pmc_write.md"), "",
            "## MFMA / busy counters", "", table_only("pmc_mfma.md"), "", "## LDS / wait counters", "", table_only("pmc_lds.md"), "", "## Reading", "",
