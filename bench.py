@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--config", choices=("cfg2x64", "cfg4", "cfg5"), default="cfg2x64")
     ap.add_argument("--objects-per-gpu", type=int, default=0)   # 0 = the config's own size
     ap.add_argument("--total-objects", type=int, default=1024)  # cfg4: the fixed job size (strong scaling)
+    ap.add_argument("--partition", choices=("static", "measured"), default="static")   # cfg4: object costs for distributed.shard_objects
     ap.add_argument("--prepass", choices=sorted(PREPASS), default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prepass-off", action="store_true")     # skip the prepass-off sub-record
@@ -152,30 +153,36 @@ def main():
         total = args.objects_per_gpu * world if args.objects_per_gpu else args.total_objects
         strong = not args.objects_per_gpu
         prm = E.gn_params()
-        # the production partitioner on MEASURED costs: every rank runs one GN iteration over its equal-count slice (a tenth of a step, outside
-        # the timed region), the per-object costs are all-gathered, shard_objects cuts the list where the summed cost balances
+        # Partition: the static cost R*D + 2M by default -- for a list of same-sized objects that is equal counts, which the one-GPU experiment
+        # with 8 simulated shards (profiles/r05_cfg4_balance.md) shows balanced to 1.2 % (slowest / mean 1.012): the work of an object is
+        # driven by its kept-row count K summed over the TEN iterations, of which a one-iteration measurement predicts only half the
+        # variance (correlation 0.51), so --partition measured (every rank measures its equal-count slice with one GN iteration, costs
+        # all-gathered, distributed.measure_costs) is for lists whose objects differ in SIZE, not for this one (it measured 1.051 here)
         sa, sb = rank * total // world, (rank + 1) * total // world
         made = {i: synth.make_object(1 + i, n_surface=2000, n_background=500) for i in range(sa, sb)}
-        mine_costs = D.measure_costs(eng, prm, [made[i] for i in range(sa, sb)])
-        if dist is not None:
-            n_max = -(-total // world)
-            tt = torch.zeros(n_max, dtype=torch.float64, device=coll_device)
-            tt[:len(mine_costs)] = torch.tensor(mine_costs, dtype=torch.float64)
-            allc = [torch.empty_like(tt) for _ in range(world)]
-            dist.all_gather(allc, tt)
-            costs = []
-            for r in range(world):
-                costs += [float(x) for x in allc[r][:(r + 1) * total // world - r * total // world].tolist()]
+        if args.partition == "measured":
+            mine_costs = D.measure_costs(eng, prm, [made[i] for i in range(sa, sb)])
+            if dist is not None:
+                n_max = -(-total // world)
+                tt = torch.zeros(n_max, dtype=torch.float64, device=coll_device)
+                tt[:len(mine_costs)] = torch.tensor(mine_costs, dtype=torch.float64)
+                allc = [torch.empty_like(tt) for _ in range(world)]
+                dist.all_gather(allc, tt)
+                costs = []
+                for r in range(world):
+                    costs += [float(x) for x in allc[r][:(r + 1) * total // world - r * total // world].tolist()]
+            else:
+                costs = mine_costs
         else:
-            costs = mine_costs
+            costs = [D.object_cost(2000, 2500)] * total
         shards = D.shard_objects(costs, world)            # uneven shards are padded in the gather
         a, b = shards[rank]
         objs = [made[i] if i in made else synth.make_object(1 + i, n_surface=2000, n_background=500) for i in range(a, b)]
         del made
         B = b - a
         groups = [(eng, objs)]
-        workload = ("cfg4: %d cfg2 objects block-sharded over %d GPU(s) by measured first-iteration cost (distributed.measure_costs -> shard_objects: "
-                    "shards %s), one RCCL gather of codes + poses per step" % (total, world, [y - x for x, y in shards]))
+        workload = ("cfg4: %d cfg2 objects block-sharded over %d GPU(s) by %s cost (distributed.shard_objects: shards %s), one RCCL gather of "
+                    "codes + poses per step" % (total, world, args.partition, [y - x for x, y in shards]))
     else:
         half = (args.objects_per_gpu or 64) // 2
         B = 2 * half

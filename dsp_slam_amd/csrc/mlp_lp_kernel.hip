@@ -112,7 +112,8 @@ __device__ __forceinline__ void lp_load_rows(const float* tab, int g, int gq, f3
 // (g, rt0, rt1 are compile-time constants after the callers' loops are unrolled; the loop bounds here are literal so that every register
 // index folds.)
 template <bool BF, bool LAST>
-__device__ __forceinline__ void lp_epilogue(int g, int rt0, int rt1, const f32x4 (&acc)[LP_RT][2], const float* dp, int gq, u32x4 (&out)[32], float (&part)[2]) {
+__device__ __forceinline__ void lp_epilogue(int g, int rt0, int rt1, const f32x4 (&acc)[LP_RT][2], const float* dp, int gq, u32x4 (&out)[32], float (&part)[2],
+                                            int blk0 = 0, int blk1 = 2) {
 #pragma unroll
     for (int rt = 0; rt < LP_RT; ++rt) {
         if (rt >= rt0 && rt < rt1) {
@@ -121,17 +122,21 @@ __device__ __forceinline__ void lp_epilogue(int g, int rt0, int rt1, const f32x4
                 const f32x4 w = *reinterpret_cast<const f32x4*>(dp + 64 * g + 16 * rt + 4 * gq);
 #pragma unroll
                 for (int blk = 0; blk < 2; ++blk) {
-                    part[blk] = fmaf(relu1(acc[rt][blk].x), w.x, part[blk]);
-                    part[blk] = fmaf(relu1(acc[rt][blk].y), w.y, part[blk]);
-                    part[blk] = fmaf(relu1(acc[rt][blk].z), w.z, part[blk]);
-                    part[blk] = fmaf(relu1(acc[rt][blk].w), w.w, part[blk]);
+                    if (blk >= blk0 && blk < blk1) {
+                        part[blk] = fmaf(relu1(acc[rt][blk].x), w.x, part[blk]);
+                        part[blk] = fmaf(relu1(acc[rt][blk].y), w.y, part[blk]);
+                        part[blk] = fmaf(relu1(acc[rt][blk].z), w.z, part[blk]);
+                        part[blk] = fmaf(relu1(acc[rt][blk].w), w.w, part[blk]);
+                    }
                 }
             } else {
                 const int T = 4 * g + rt;
 #pragma unroll
                 for (int blk = 0; blk < 2; ++blk) {
-                    out[2 * (T >> 1) + blk][2 * (T & 1) + 0] = lp_relu_pack<BF>(acc[rt][blk].x, acc[rt][blk].y);
-                    out[2 * (T >> 1) + blk][2 * (T & 1) + 1] = lp_relu_pack<BF>(acc[rt][blk].z, acc[rt][blk].w);
+                    if (blk >= blk0 && blk < blk1) {
+                        out[2 * (T >> 1) + blk][2 * (T & 1) + 0] = lp_relu_pack<BF>(acc[rt][blk].x, acc[rt][blk].y);
+                        out[2 * (T >> 1) + blk][2 * (T & 1) + 1] = lp_relu_pack<BF>(acc[rt][blk].z, acc[rt][blk].w);
+                    }
                 }
             }
         }
@@ -199,24 +204,56 @@ __device__ __forceinline__ void lp_pass(const LpPass pd, u32x4 (&in)[32], u32x4 
                     // publishes every wave's quarter and proves all reads of chunk q-1 retired (mlp_kernel.hip)
                     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(GLDS_PER_CHUNK * (LP_NBUF - 3)) : "memory");
                 }
+                // One step = eight MFMAs of 16 cycles (row tile m >> 1, column block m & 1).  A 16-cycle MFMA leaves this one wave THREE issue
+                // slots, so everything else is dealt out over the eight gaps and pinned there (sched_barrier after every MFMA):
+                //   gap 0: ONE lgkmcnt(0) -- the four A fragments of this step were read in gaps 0, 1 of the previous step, seven MFMAs ago --
+                //          then the reads of fragments 0, 1 of the NEXT step;   gap 1: fragments 2, 3;
+                //   gaps 1, 2 of steps 2, 3: the chunk's four LDS-DMA pieces;
+                //   gaps 4 .. 7: one (row tile, column block) unit of the PREVIOUS output group's relu / v_cvt_pk epilogue, two instructions
+                //          a gap (steps 1 .. 8 carry the eight units).  hipcc left alone sinks the reads behind the sixth MFMA and bunches the
+                //          epilogue behind one step: measured 0.65 duty against 0.74 for the 32x32x16 form.
+                const bool epi = NCH > 1 && g > 0 && ks >= 1 && ks <= 8;
+                const int ert = (ks - 1) >> 1, eblk = (ks - 1) & 1;       // this step's epilogue unit
+                float e0 = 0.f, e1 = 0.f;
 #pragma unroll
-                for (int rt = 0; rt < LP_RT; ++rt) {
-                    // the A fragment of (step kq + 1, row tile rt): one step = four fragments = eight MFMAs (128 cycles) ahead of its use
-                    const lds_cptr src = (kq + 1 < LP_KQ) ? cbp + ((kq + 1) * LP_RT + rt) * LP_FRAG_BYTES : nbp + rt * LP_FRAG_BYTES;
-                    abuf[(kq + 1) & 1][rt] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(src);
-                    const u32x4 av = abuf[kq & 1][rt];
-                    acc[par][rt][0] = lp_mfma<BF>(av, in[2 * ks + 0], ks == 0 ? bias[rt] : acc[par][rt][0]);
-                    // refill of the slot freed by the barrier above: one DMA piece behind an MFMA, four per chunk
-                    if (kq == LP_KQ / 2 && rt == 0) { glds_set_dst(rg.idst); glds_piece_m0<0>(rg.isrc, rg.lane_off, rg.idst); }
-                    if (kq == LP_KQ / 2 && rt == 2) glds_piece_m0<1>(rg.isrc, rg.lane_off, rg.idst);
-                    if (kq == LP_KQ / 2 + 1 && rt == 0) glds_piece_m0<2>(rg.isrc, rg.lane_off, rg.idst);
-                    if (kq == LP_KQ / 2 + 1 && rt == 2) { glds_piece_m0<3>(rg.isrc, rg.lane_off, rg.idst); lp_issue_next(rg); }
-                    acc[par][rt][1] = lp_mfma<BF>(av, in[2 * ks + 1], ks == 0 ? bias[rt] : acc[par][rt][1]);
-                    // epilogue of the previous group, one row tile (both column blocks) behind each of this group's first MFMA pairs
-                    if (g > 0 && ks == 1) lp_epilogue<BF, LAST>(g - 1, rt, rt + 1, acc[par ^ 1], dp, gq, out, part);
+                for (int m = 0; m < 2 * LP_RT; ++m) {
+                    const int rt = m >> 1, blk = m & 1;
+#if !defined(LP_WAIT_PER_USE)
+                    if (m == 0) __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0), vmcnt / expcnt untouched
+#endif
+                    if (m < 2) {
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int f = 2 * m + q;        // fragment (= row tile) of step kq + 1
+                            const lds_cptr src = (kq + 1 < LP_KQ) ? cbp + ((kq + 1) * LP_RT + f) * LP_FRAG_BYTES : nbp + f * LP_FRAG_BYTES;
+                            abuf[(kq + 1) & 1][f] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(src);
+                        }
+                    }
+                    acc[par][rt][blk] = lp_mfma<BF>(abuf[kq & 1][rt], in[2 * ks + blk], ks == 0 ? bias[rt] : acc[par][rt][blk]);
+                    // refill of the slot freed by the barrier above: four DMA pieces per chunk
+                    if (kq == LP_KQ / 2 && m == 1) { glds_set_dst(rg.idst); glds_piece_m0<0>(rg.isrc, rg.lane_off, rg.idst); }
+                    if (kq == LP_KQ / 2 && m == 2) glds_piece_m0<1>(rg.isrc, rg.lane_off, rg.idst);
+                    if (kq == LP_KQ / 2 + 1 && m == 1) glds_piece_m0<2>(rg.isrc, rg.lane_off, rg.idst);
+                    if (kq == LP_KQ / 2 + 1 && m == 2) { glds_piece_m0<3>(rg.isrc, rg.lane_off, rg.idst); lp_issue_next(rg); }
+#if defined(LP_EPILOGUE_BURST)
+                    if (g > 0 && ks == 1 && blk == 1) lp_epilogue<BF, LAST>(g - 1, rt, rt + 1, acc[par ^ 1], dp, gq, out, part);
+#else
+                    if (NCH == 1) {          // first layer: four steps in all, one row tile behind every second MFMA of step 1
+                        if (g > 0 && ks == 1 && blk == 1) lp_epilogue<BF, LAST>(g - 1, rt, rt + 1, acc[par ^ 1], dp, gq, out, part);
+                    } else if (epi && !LAST) {
+                        const int T = 4 * (g - 1) + ert;
+                        if (m == 4) { e0 = acc[par ^ 1][ert][eblk].x; e1 = acc[par ^ 1][ert][eblk].y; asm volatile("" : "+v"(e0), "+v"(e1)); }
+                        if (m == 5) out[2 * (T >> 1) + eblk][2 * (T & 1) + 0] = lp_relu_pack<BF>(e0, e1);
+                        if (m == 6) { e0 = acc[par ^ 1][ert][eblk].z; e1 = acc[par ^ 1][ert][eblk].w; asm volatile("" : "+v"(e0), "+v"(e1)); }
+                        if (m == 7) out[2 * (T >> 1) + eblk][2 * (T & 1) + 1] = lp_relu_pack<BF>(e0, e1);
+                    } else if (epi && m == 4) {      // last hidden layer (one pass in eight): the unit's dot-product terms in one piece
+                        lp_epilogue<BF, LAST>(g - 1, ert, ert + 1, acc[par ^ 1], dp, gq, out, part, eblk, eblk + 1);
+                    }
+#endif
+                    // the next group's bias: behind the second MFMA of the group's last step, six MFMAs ahead of the lgkmcnt(0) that follows
+                    if (ks == LP_KQ * NCH - 1 && m == 1 && g + 1 < LP_NOG) lp_load_rows(bp, g + 1, gq, bias);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                if (ks == LP_KQ * NCH - 1 && g + 1 < LP_NOG) lp_load_rows(bp, g + 1, gq, bias);   // the next group's bias
-                __builtin_amdgcn_sched_barrier(0);
             }
             rg.rd_slot = nx_slot;
         }

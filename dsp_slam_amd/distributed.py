@@ -14,21 +14,22 @@ def object_cost(n_pts, n_rays, n_depth=50):
     return float(n_rays) * n_depth + 2.0 * float(n_pts)
 
 
-# Seconds of decoder time per point, from the rates the kernels reach on an MI355X in the 64-object batch (BENCH_r04: prepass 1347 TFLOP/s f16;
-# fp32 forward 0.889 and jacobian kernels 0.871 of 157.3 TFLOP/s): only their RATIOS matter to the partitioner.
-_F_FWD = 3671040.0
-_T_PREPASS = _F_FWD / 1347e12
-_T_FWD = _F_FWD / (0.889 * 157.3e12)
-_T_BWD = _F_FWD / (0.871 * 157.3e12)
+# Seconds per in-sphere sample and per kept render row over a whole run, REGRESSED on an MI355X from the step times of sixteen 119..133-object
+# shards of the cfg4 job (profiles/r05_cfg4_balance.md: time = 1.25 ms per 1e6 sum-V + 81 ms per 1e6 sum-K, rms residual 0.4 %): the kept rows
+# drive the band the fp32 forward kernel decodes and the backward-only launch; only the RATIO of the two matters to the partitioner.
+_T_V = 1.25e-9
+_T_K = 81e-9
+_T_SURFACE = 2.0 * 3671040.0 / (0.871 * 157.3e12)      # forward + backward of one surface point at the jacobian kernels' rate
 
 
 def measured_cost(n_pts, v, band, k, prepass=True):
-    """Work of one object per Gauss-Newton iteration from its MEASURED first-iteration set sizes: V in-sphere samples through the prepass
-    (or, prepass off, through the fp32 forward kernel), `band` samples through the fp32 forward kernel, n_pts surface points forward +
-    backward, K kept render rows backward only.  Replaces the static R*D + 2M, which cannot see that one 2500-ray object keeps 4.8 k render
-    rows and another 21 k (the bench batch)."""
-    fwd = float(v) * _T_PREPASS + float(band) * _T_FWD if prepass else float(v) * _T_FWD
-    return fwd + 2.0 * float(n_pts) * _T_BWD + float(k) * _T_BWD
+    """Work of one object per Gauss-Newton iteration from its MEASURED set sizes: V in-sphere samples, K kept render rows (`band`, the
+    samples the fp32 forward kernel decodes, follows K and is folded into its coefficient), n_pts surface points.  For objects of
+    different SIZE (M, R) this separates them far better than the static R*D + 2M; among same-sized objects the first iteration's K
+    predicts only half of the variance of the ten-iteration sum (correlation 0.51 over the 64 bench objects), and equal counts balance
+    better (profiles/r05_cfg4_balance.md: 1.012 static against 1.051 measured)."""
+    fwd = float(v) * _T_V * (1.0 if prepass else 9.6)       # prepass off: every in-sphere sample at the fp32 rate (1347 vs 140 TFLOP/s)
+    return fwd + float(n_pts) * _T_SURFACE + float(k) * _T_K
 
 
 def measure_costs(engine, prm, objs, chunk=128):

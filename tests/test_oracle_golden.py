@@ -277,3 +277,27 @@ def test_lie_maps_against_the_extended_reference_vectors():
         assert abs(float(ro) - float(r)) <= 2 * ulp and np.abs(jo - j).max() <= 2 * ulp
     for t, dx, ref in zip(g["upd_t"], g["upd_dx"], g["upd_out"]):
         assert u((O.exp_sim3(dx) @ t).astype(np.float32), ref) <= 2.0
+
+
+def test_complex_decoder_linearisation_at_reference_states():
+    """golden_recon_complex.npz (round 5): one cfg2-size object of the non-convex, all-64-dimensions shape family on its own decoder
+    fixture (tools/fit_decoder_gpu.py --shape complex), KITTI hyper-parameters.  The oracle at the reference's recorded states of the
+    first, a middle and the last iteration: identical sets, H / b to 1e-4 (the GPU tier does all ten, tests/test_gpu_forensics.py)."""
+    import forensics as F
+    from conftest import have_complex_fixture
+    if not have_complex_fixture():
+        pytest.skip("complex fixture not generated")
+    from dsp_slam_amd import fixtures
+    dec = O.fold_decoder(fixtures.load_decoder_npz(fixtures.fixture_path("complex")), fixtures.fixture_specs("complex"))
+    gd = golden("golden_decoder_complex.npz")
+    assert np.abs(O.decode_sdf(dec, gd["code"], gd["pts"]) - gd["sdf"]).max() < 2e-6
+    y, grad = O.get_batch_sdf_jacobian(dec, gd["code"], gd["pts"])
+    assert rel(grad.reshape(-1, 67), gd["grad"]) < 2e-5
+    g = golden("golden_recon_complex.npz")
+    prm = O.GNParams.from_configs(json.loads(str(g["cfg_json"])))
+    mask = np.ones(71, bool)
+    mask[3:6] = False
+    for e in (0, 5, 9):
+        it = F.oracle_linearisation(dec, prm, g["in_pts"], g["in_rays"], g["in_depth"], g["it_t_obj_cam"][e], g["it_code"][e], g["it_depths"][e])
+        assert (it["V"], it["K"]) == (int(g["it_V"][e]), int(g["it_K"][e])), (e, it["V"], it["K"], int(g["it_V"][e]), int(g["it_K"][e]))
+        assert rel(it["H"], g["it_H"][e]) < 1e-4 and rel(it["b"][mask], g["it_b"][e][mask]) < 1e-4
