@@ -27,10 +27,13 @@ def read_map_objects(path):
 
 
 def write_map_objects(path, objects):
-    """objects: iterable of dict(id, pose (4,4) or (3,4), code).  Written as System::SaveMapCurrentFrame does (src/System_util.cc:123-146):
-    `fixed`, setprecision(9); the pose as twelve `<<`-streamed scalars separated by single spaces; the code as an Eigen row vector streamed
-    with Eigen's default IOFormat, which right-aligns every coefficient to the width of the widest one (so values are separated by one OR
-    MORE spaces -- the reason the reference's reader skips empty items, extract_map_objects.py:59-61)."""
+    """objects: iterable of dict(id, pose (4,4) or (3,4), code).  Laid out after System::SaveMapCurrentFrame (src/System_util.cc:123-146):
+    `fixed`, setprecision(9); the pose as twelve scalars separated by single spaces; the code right-aligned to the width of the widest
+    coefficient, as Eigen's default IOFormat streams a row vector (values separated by one OR MORE spaces -- the reason the reference's
+    reader skips empty items, extract_map_objects.py:59-61).
+    PARITY: reader-level only.  The reference's writer is C++ / Eigen and cannot be run in this image, so the exact bytes it emits are
+    not pinned; what is pinned is that the reference's own parse loop (extract_map_objects.py:46-63, run through `runpy` in
+    tests/test_gpu_map_tools.py) reads these files back to the values written."""
     with open(path, "w") as f:
         for o in sorted(objects, key=lambda x: x["id"]):
             f.write("%d\n" % int(o["id"]))

@@ -498,3 +498,27 @@ def test_a_batch_may_be_dropped_after_its_engine_was_closed(oracle_decoder):
     b.close()
     del b
     gc.collect()
+
+
+def test_trim_hands_the_pools_back_and_the_handle_keeps_working(eng):
+    """dsp_trim (round 5): a handle parks up to 1 GiB of device blocks and its pinned staging for the next one-shot call; a process
+    that shares the GPU with another allocator hands them back.  The next call allocates afresh and returns the same bits."""
+    import torch
+    prm = E.gn_params(num_iterations=2)
+    det = synth.make_object(4244, n_surface=250, n_background=200)
+    want = eng.reconstruct_batch(prm, *_args([det]))
+    free0 = torch.cuda.mem_get_info(0)[0]
+    big = synth.make_batch(8, first_seed=4300, n_surface=2000, n_background=500)
+    eng.reconstruct_batch(prm, *_args(big))                 # a one-shot call of ~0.8 GiB: its blocks stay parked in the handle's pool
+    parked = free0 - torch.cuda.mem_get_info(0)[0]
+    eng.trim()
+    after = free0 - torch.cuda.mem_get_info(0)[0]
+    assert parked > (64 << 20) and after < parked // 4, (parked, after)
+    got = eng.reconstruct_batch(prm, *_args([det]))
+    for x, y in zip(got, want):
+        assert np.array_equal(x, y)
+    # a destroyed RESIDENT batch trims the pool to a detection's footprint on its own
+    b = eng.batch(prm, *_args(big))
+    b.run()
+    b.close()
+    assert free0 - torch.cuda.mem_get_info(0)[0] < (192 << 20)
