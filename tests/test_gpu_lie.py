@@ -53,7 +53,7 @@ def test_exp_maps_on_the_device(eng, name):
     # every branch of exp_sim3 was executed on the device: theta <= 1e-8 (s == 0 / s != 0), theta > 0 with s > eps / s == 0 / s <= eps
     if name == "golden_lie.npz":
         assert {"theta0_s0", "theta0_s", "theta0_quirk", "theta_s", "theta_s0", "theta_quirk"} <= branches, branches
-    parity_log(case="lie_exp_" + name, n=int(len(g["exp_x"])), exp_sim3_ulp=worst7, exp_se3_ulp=worst6, branches=sorted(branches))
+    parity_log(kind="lie", case="lie_exp_" + name, n=int(len(g["exp_x"])), exp_sim3_ulp=worst7, exp_se3_ulp=worst6, branches=sorted(branches))
 
 
 def test_exp_sim3_quirk_is_reproduced_on_the_device(eng):
@@ -100,7 +100,7 @@ def test_rotation_prior_on_the_device(eng, name):
             rng_ = g["rot_range"][i]
             assert np.abs(out[9:11] - rng_).max() <= 2.0 * ULP1 * float(np.abs(rng_).max())
     assert n_zero >= 1                                       # the zero branch ran on the device
-    parity_log(case="lie_rot_" + name, n=int(len(g["rot_t"])), res_ulp=worst_r, j_ulp=worst_j, zero_branch=n_zero, threshold_edge=n_edge)
+    parity_log(kind="lie", case="lie_rot_" + name, n=int(len(g["rot_t"])), res_ulp=worst_r, j_ulp=worst_j, zero_branch=n_zero, threshold_edge=n_edge)
 
 
 def test_sim3_state_update_on_the_device(eng):
@@ -112,7 +112,7 @@ def test_sim3_state_update_on_the_device(eng):
         u = ulps(d, ref)
         assert u <= 4.0, (u, d, ref)       # a 4-term float32 dot product of entries up to |t| ~ 25: 2 ulp of the factor + 2 of the sum
         worst = max(worst, u)
-    parity_log(case="lie_update", n=int(len(g["upd_t"])), ulp=worst)
+    parity_log(kind="lie", case="lie_update", n=int(len(g["upd_t"])), ulp=worst)
 
 
 def test_debug_lie_rejects_bad_arguments(eng):

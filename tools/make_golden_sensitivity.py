@@ -23,7 +23,7 @@ from oracle import ref_shim  # noqa: E402
 from dsp_slam_amd import fixtures  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
-N_DRAWS = 8
+N_DRAWS = int(os.environ.get("DSP_SENS_DRAWS", "8"))      # the chaotic full-size fixtures (cfg2, complex) carry 32: eight draws do not bound a heavy-tailed spread
 
 
 def jiggle(a, rng):

@@ -28,7 +28,7 @@ def read(name):
 
 
 def bench(name):
-    return json.loads(read(name).strip().splitlines()[-1])
+    return json.loads([ln for ln in read(name).splitlines() if ln.startswith('{"metric"')][-1])
 
 
 def pmc(name):
@@ -165,8 +165,8 @@ def main():
            "  512 rows and the xyz k-steps carry split-precision products).",
            "* Matrix pipe busy: **%.1f %%** (first round-2 profile: 53.8 %%); shader clock averaged over launches of very different length %.2f GHz (the long"
            % (100 * busy(K0), clk(K0)),
-           "  ones run at 1.7-1.8 GHz: `tools/probes/gpu_prepass_probe.py`) -- the chip clocks down under 16-bit MFMA load, so part of every cycle saved comes back",
-           "  as clock, not throughput (MI355X_MICROARCH.md, DVFS).",
+           "  ones run at 1.75-1.9 GHz: `tools/probes/gpu_prepass_probe.py`) -- the clock this chip grants a dense 16-bit MFMA stream follows the switching power of",
+           "  live operands: 1.78 GHz for a register-only 32x32x16 stream, 2.13 GHz for the 16x16x32 form this kernel uses since round 5 (`profiles/r05_k0_clock.md`).",
            "* Fabric reads: %.4g KiB x 2 = %.1f GB over %.1f M points = **%.0f B per point**: the 3.6 MB f16 weight stream fits the 4 MiB L2."
            % (fe[(K0, "FETCH_SIZE")][1], k0_fetch / 1e9, k0_pts / 1e6, k0_fetch / k0_pts),
            "  `WRITE_SIZE` %.4g KiB = %.0f B per point (4 B of sdf per point + write-allocate granularity; the kernel has no scratch any more)."
