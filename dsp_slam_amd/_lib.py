@@ -101,6 +101,7 @@ SYMBOLS = [
     ("dsp_batch_set_kernel_timing", C.c_int, [_VP, C.c_int]),
     ("dsp_prepass_reset_guard", C.c_int, [_VP]),
     ("dsp_trim", C.c_int, [_VP]),
+    ("dsp_set_stream_priority", C.c_int, [_VP, C.c_int]),
     ("dsp_debug_lie", C.c_int, [_VP, C.c_int, c_f32p, C.c_int32, c_f32p]),
     ("dsp_batch_enable_trace", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_trace", C.c_int, [_VP, C.c_int32, c_f32p, c_f32p, c_f32p, c_i64p, c_i64p, c_i64p, c_f32p, c_f32p, C.POINTER(C.c_uint32), c_f32p]),

@@ -398,6 +398,10 @@ class Engine(object):
         GPU with torch / RCCL / another handle and has just finished a large one-shot batch."""
         L.check(L.load().dsp_trim(self._h), self._h, "dsp_trim")
 
+    def set_stream_priority(self, priority):
+        """1 = highest, 0 = default, -1 = lowest queue priority of the handle's HIP stream (dsp_set_stream_priority): who yields on a shared GPU."""
+        L.check(L.load().dsp_set_stream_priority(self._h, int(priority)), self._h, "dsp_set_stream_priority")
+
     def debug_lie(self, kind, x, n_depth=50):
         """Testing: exp_sim3 (kind 0, x[7]), exp_se3 (1, x[6]), the rotation prior + derived state (2, t_obj_cam 4x4) or the Sim(3) state
         update exp_sim3(dx) @ t_obj_cam (3, 16 + 7 floats) evaluated by the device functions the solve kernel calls.  Returns 16 floats."""

@@ -111,6 +111,12 @@ void dsp_destroy(dsp_handle* h);
  * hands all of it back to the runtime: for a process that shares the GPU with another allocator (torch, RCCL, a second handle).  Destroying
  * a resident batch (dsp_batch_destroy) trims the cache to the footprint of one KITTI-size detection (64 MiB) on its own. */
 int dsp_trim(dsp_handle* h);
+/* Priority of the handle's HIP stream among the queues of the device: 1 = highest, 0 = default, -1 = lowest the device offers.  Where the GPU
+ * is shared -- DSP-SLAM runs its detectors on it from the Tracking thread (src/Tracking_util.cc:31-57) while this path runs in the
+ * LocalMapping thread (src/LocalMapping_util.cc:165-203) -- the integrator decides who yields: -1 lets the detectors' kernels go first,
+ * 1 shortens a detection's ~110 dependent kernels beside them.  The stream is re-created (after a synchronisation); batches of the handle
+ * pick the new one up at their next run.  Results do not depend on it. */
+int dsp_set_stream_priority(dsp_handle* h, int priority);
 const char* dsp_last_error(const dsp_handle* h);   /* h may be NULL: error of the last failed dsp_create */
 int dsp_abi_version(void);
 /* Which compiler produced this library (hipcc --version at build time, clang version, HIP header version) -- the decoder kernels rely on

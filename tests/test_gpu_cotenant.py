@@ -27,9 +27,11 @@ def _args(o):
     return ([o["t_cam_obj_init"]], [o["pts"]], [o["rays"]], [o["depth"]])
 
 
-@pytest.mark.parametrize("co_points", [16384, 100000])
-def test_detections_beside_a_cu_saturating_cotenant(oracle_decoder, co_points):
+@pytest.mark.parametrize("co_points,priority", [(16384, 0), (16384, 1), (100000, 0)])
+def test_detections_beside_a_cu_saturating_cotenant(oracle_decoder, co_points, priority):
     eng = E.Engine(oracle_decoder.layers, oracle_decoder.latent_in, oracle_decoder.code_len, device=0)
+    if priority:
+        eng.set_stream_priority(priority)       # dsp_set_stream_priority: this handle's kernels go first when a CU frees up
     co = E.Engine(oracle_decoder.layers, oracle_decoder.latent_in, oracle_decoder.code_len, device=0)
     prm = E.gn_params()
     dets = [synth.make_object(5000 + i, n_surface=250, n_background=200) for i in range(10)]
@@ -80,9 +82,9 @@ def test_detections_beside_a_cu_saturating_cotenant(oracle_decoder, co_points):
         th.join()
     solo_p50 = float(np.median(solo))
     p50, p99, worst = float(np.median(shared)), float(np.percentile(shared, 99)), float(np.max(shared))
-    print("co-tenant %d points/launch (%d launches meanwhile): solo p50 %.2f ms; shared p50 %.2f p99 %.2f max %.2f ms; %d of %d runs fell back, %d used the cluster form" % (
-        co_points, launches[0], solo_p50, p50, p99, worst, fallbacks, len(shared), cluster_runs))
-    parity_log(kind="cotenant", case="KITTI-size detections beside back-to-back dsp_decode_sdf(%d points) from a second handle / thread" % co_points,
+    print("co-tenant %d points/launch, stream priority %d (%d launches meanwhile): solo p50 %.2f ms; shared p50 %.2f p99 %.2f max %.2f ms; %d of %d runs fell back, %d used the cluster form" % (
+        co_points, priority, launches[0], solo_p50, p50, p99, worst, fallbacks, len(shared), cluster_runs))
+    parity_log(kind="cotenant", case="KITTI-size detections beside back-to-back dsp_decode_sdf(%d points) from a second handle / thread%s" % (co_points, ", this handle's stream at the highest priority" if priority else ""),
                solo_p50_ms=solo_p50, shared_p50_ms=p50, shared_p99_ms=p99, shared_max_ms=worst, runs=len(shared), fallback_runs=int(fallbacks),
                runs_with_cluster_tiles=int(cluster_runs), cotenant_launches=int(launches[0]))
     assert launches[0] > 0
