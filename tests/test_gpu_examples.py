@@ -61,3 +61,31 @@ def test_bench_launch_path_with_two_ranks_on_one_gpu(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and len(d["ms_per_step_by_rank"]) == 2 and d["value"] > 0
     assert d["config"]["objects_good"] >= 2 and "PLUMBING TEST" in d["config"]["parallelism"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("partition", ["static", "measured"])
+def test_cfg4_strong_scaling_job_with_two_ranks_on_one_gpu(partition):
+    """BASELINE configs[3] as bench.py runs it under the driver's launch command: a FIXED object list (here 10 objects instead of 1024) cut
+    into per-rank shards by distributed.shard_objects -- by the static cost (default) or by the measured first-iteration cost, whose per-rank
+    measurements are all-gathered before the cut -- then one gather of the result rows per step.  Both ranks on device 0, gloo (plumbing
+    switches: the numbers mean nothing): `scaling` is "strong", the shards cover the list, every object comes back good."""
+    import json
+    import socket
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, DSP_BENCH_SHARE_GPU="1", DSP_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--config", "cfg4", "--total-objects", "10", "--partition", partition]
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["name"] == "cfg4"
+    assert sum(r["objects"] for r in d["by_rank"]) == 10 and d["config"]["objects_good"] == 10
+    assert partition in d["config"]["workload"]
+    assert all(r["sum_V_per_step"] > 0 for r in d["by_rank"])
