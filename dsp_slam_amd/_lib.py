@@ -20,6 +20,7 @@ GRAD_DIM = 67
 
 OBJ_GOOD, OBJ_FEW_SAMPLES, OBJ_NAN = 0, 1, 2
 PREPASS_OFF, PREPASS_F16, PREPASS_BF16 = 0, 1, 2
+PREPASS_SMALL_TILES = 0x100
 
 
 class DecoderDesc(C.Structure):
@@ -88,6 +89,7 @@ SYMBOLS = [
     ("dsp_prepass_calibration", C.c_int, [_VP, C.c_int, c_f32p, c_f32p]),
     ("dsp_prepass_calibration_table", C.c_int, [_VP, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p]),
     ("dsp_batch_set_prepass_audit", C.c_int, [_VP, C.c_int]),
+    ("dsp_batch_set_prepass_tile", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_set_prepass_guard", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_set_start_state", C.c_int, [_VP, c_f32p, c_f32p, c_f32p]),
     ("dsp_batch_set_iterations", C.c_int, [_VP, C.c_int32]),

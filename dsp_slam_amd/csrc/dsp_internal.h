@@ -110,6 +110,7 @@ constexpr int CL_XCH_UNITS = 16 * 3;         // tagged 16-byte units per lane in
 // Occupancy is exactly 0 for sdf >= th and exactly 1 for sdf <= -th (loss_utils.py:40-48), so a sample whose low-precision
 // sdf is farther than a calibrated margin from the band needs no fp32 decode at all (DESIGN.md "Prepass").
 constexpr int LP_TILE_PTS = 128;    // points per workgroup tile (4 waves x 32)
+constexpr int LP_TILE_PTS_SMALL = 64;   // ... of the latency form (4 waves x 16: one column block per wave), for lists that fill less than half the chip
 constexpr int LP_WAVE_PTS = 32;
 constexpr int LP_NBUF = 8;          // LDS ring depth in 16 KiB chunks
 constexpr int LP_KSTEPS_PER_CHUNK = 8;   // chunk = 8 k-steps (of 16 slab rows) x 2 row tiles (of 32 output rows) x 1 KiB
@@ -250,7 +251,7 @@ hipError_t launch_mlp_split(int mode, const MlpArgs& args, int n_blocks, hipStre
 hipError_t mlp_cluster_prepare_device();
 hipError_t launch_mlp_cluster(const MlpArgs& args, int n_clusters, hipStream_t stream);   // 16-point tiles, four workgroups each; grid = 4 x n_clusters (n_clusters a multiple of 8), all resident
 hipError_t mlp_lp_prepare_device();
-hipError_t launch_mlp_lp(bool bf16, const LpArgs& args, int n_blocks, hipStream_t stream);   // 128-point tiles, forward only
+hipError_t launch_mlp_lp(bool bf16, const LpArgs& args, int n_blocks, hipStream_t stream, int tile_pts = LP_TILE_PTS);   // 128- or 64-point tiles, forward only
 // run_mask (optional, B bytes): objects with a zero byte are left out of the run (status DSP_STATUS_SKIP, state and result row untouched);
 // summary: the run's counter words, zeroed here (summary_words of them)
 void launch_init_state(ObjState* st, const float* t, const float* codes, const float* scale, const float* depths /*optional B x 64*/, int B, int D, int pose_only,

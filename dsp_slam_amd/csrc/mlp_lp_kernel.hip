@@ -147,7 +147,10 @@ __device__ __forceinline__ void lp_epilogue(int g, int rt0, int rt1, const f32x4
 // register slabs, indexed [2 ks + blk]: 32-k step ks, column block blk.  A pass is 8 output groups x NCH chunks of straight-line code:
 // everything that differs between layers is data (bias / dot-row pointers, prologue selects) -- hipcc answers run-time control flow inside
 // this body with hundreds of register moves at every join.  NCH = 1 for the first layer (its K is the xyz step only), LP_NCH for the others.
-template <bool BF, int NCH, bool LAST>
+// NBLK = 2: the wave's 32 points as two column blocks (128-point tiles, the throughput form); NBLK = 1: ONE column block of 16 points
+// (64-point tiles: a detection-sized list -- ~117 tiles of 128 points on 256 CUs -- becomes ~235 tiles of half the length; the same
+// arithmetic per point, so the same values).
+template <bool BF, int NCH, bool LAST, int NBLK, int NW>
 __device__ __forceinline__ void lp_pass(const LpPass pd, u32x4 (&in)[32], u32x4 (&out)[32], f32x4 (&acc)[2][LP_RT][2],
                                         u32x4 (&abuf)[2][LP_RT], LpRing& rg, const u32x4 (&xb)[2], const float* bp,
                                         const float* dp, int lane, int gq, float (&part)[2]) {
@@ -162,18 +165,18 @@ __device__ __forceinline__ void lp_pass(const LpPass pd, u32x4 (&in)[32], u32x4 
 #pragma unroll
             for (int ks = 0; ks < LP_KQ; ++ks)
 #pragma unroll
-                for (int blk = 0; blk < 2; ++blk) in[2 * ks + blk] = ks == 0 ? xb[blk] : zero;
+                for (int blk = 0; blk < NBLK; ++blk) in[2 * ks + blk] = ks == 0 ? xb[blk] : zero;
         } else {
             const bool lat = pd.kind == 2;
             constexpr int KX = LP_KQ * NCH - 1;          // the xyz step of the latent_in layer
 #pragma unroll
-            for (int blk = 0; blk < 2; ++blk) in[2 * KX + blk] = lat ? xb[blk] : in[2 * KX + blk];
+            for (int blk = 0; blk < NBLK; ++blk) in[2 * KX + blk] = lat ? xb[blk] : in[2 * KX + blk];
 #pragma unroll
             for (int t = 1; t <= 3; ++t) {               // padding 16-row tile 2 KX - t = half (t & 1 ? 1 : 0) of step (2 KX - t) >> 1
                 const int T = 2 * KX - t;
                 const bool z = lat && pd.npad >= t;
 #pragma unroll
-                for (int blk = 0; blk < 2; ++blk) {
+                for (int blk = 0; blk < NBLK; ++blk) {
                     in[2 * (T >> 1) + blk][2 * (T & 1) + 0] = z ? 0u : in[2 * (T >> 1) + blk][2 * (T & 1) + 0];
                     in[2 * (T >> 1) + blk][2 * (T & 1) + 1] = z ? 0u : in[2 * (T >> 1) + blk][2 * (T & 1) + 1];
                 }
@@ -202,7 +205,7 @@ __device__ __forceinline__ void lp_pass(const LpPass pd, u32x4 (&in)[32], u32x4 
                 if (kq == LP_KQ / 2) {
                     // chunk q+1 has landed for this wave once <= LP_NBUF-3 younger chunks are in flight; the barrier
                     // publishes every wave's quarter and proves all reads of chunk q-1 retired (mlp_kernel.hip)
-                    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(GLDS_PER_CHUNK * (LP_NBUF - 3)) : "memory");
+                    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((16 / NW) * (LP_NBUF - 3)) : "memory");
                 }
                 // One step = eight MFMAs of 16 cycles (row tile m >> 1, column block m & 1).  A 16-cycle MFMA leaves this one wave THREE issue
                 // slots, so everything else is dealt out over the eight gaps and pinned there (sched_barrier after every MFMA):
@@ -212,12 +215,14 @@ __device__ __forceinline__ void lp_pass(const LpPass pd, u32x4 (&in)[32], u32x4 
                 //   gaps 4 .. 7: one (row tile, column block) unit of the PREVIOUS output group's relu / v_cvt_pk epilogue, two instructions
                 //          a gap (steps 1 .. 8 carry the eight units).  hipcc left alone sinks the reads behind the sixth MFMA and bunches the
                 //          epilogue behind one step: measured 0.65 duty against 0.74 for the 32x32x16 form.
-                const bool epi = NCH > 1 && g > 0 && ks >= 1 && ks <= 8;
-                const int ert = (ks - 1) >> 1, eblk = (ks - 1) & 1;       // this step's epilogue unit
+                constexpr int NM = NBLK * LP_RT;                          // MFMAs per step
+                const bool epi = NCH > 1 && g > 0 && ks >= 1 && ks <= 4 * NBLK;
+                const int ert = NBLK == 2 ? (ks - 1) >> 1 : ks - 1, eblk = NBLK == 2 ? (ks - 1) & 1 : 0;       // this step's epilogue unit
+                constexpr int E0 = NM - 4;                                // the unit's four micro-steps sit in the step's last four gaps
                 float e0 = 0.f, e1 = 0.f;
 #pragma unroll
-                for (int m = 0; m < 2 * LP_RT; ++m) {
-                    const int rt = m >> 1, blk = m & 1;
+                for (int m = 0; m < NM; ++m) {
+                    const int rt = NBLK == 2 ? m >> 1 : m, blk = NBLK == 2 ? m & 1 : 0;
 #if !defined(LP_WAIT_PER_USE)
                     if (m == 0) __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0), vmcnt / expcnt untouched
 #endif
@@ -231,22 +236,27 @@ __device__ __forceinline__ void lp_pass(const LpPass pd, u32x4 (&in)[32], u32x4 
                     }
                     acc[par][rt][blk] = lp_mfma<BF>(abuf[kq & 1][rt], in[2 * ks + blk], ks == 0 ? bias[rt] : acc[par][rt][blk]);
                     // refill of the slot freed by the barrier above: four DMA pieces per chunk
-                    if (kq == LP_KQ / 2 && m == 1) { glds_set_dst(rg.idst); glds_piece_m0<0>(rg.isrc, rg.lane_off, rg.idst); }
-                    if (kq == LP_KQ / 2 && m == 2) glds_piece_m0<1>(rg.isrc, rg.lane_off, rg.idst);
-                    if (kq == LP_KQ / 2 + 1 && m == 1) glds_piece_m0<2>(rg.isrc, rg.lane_off, rg.idst);
-                    if (kq == LP_KQ / 2 + 1 && m == 2) { glds_piece_m0<3>(rg.isrc, rg.lane_off, rg.idst); lp_issue_next(rg); }
+                    if constexpr (NW == 4) {        // this wave's quarter of the chunk: four 1 KiB pieces
+                        if (kq == LP_KQ / 2 && m == 1) { glds_set_dst(rg.idst); glds_piece_m0<0>(rg.isrc, rg.lane_off, rg.idst); }
+                        if (kq == LP_KQ / 2 && m == 2) glds_piece_m0<1>(rg.isrc, rg.lane_off, rg.idst);
+                        if (kq == LP_KQ / 2 + 1 && m == 1) glds_piece_m0<2>(rg.isrc, rg.lane_off, rg.idst);
+                        if (kq == LP_KQ / 2 + 1 && m == 2) { glds_piece_m0<3>(rg.isrc, rg.lane_off, rg.idst); lp_issue_next(rg); }
+                    } else {                        // eight waves: an eighth, two pieces
+                        if (kq == LP_KQ / 2 && m == 1) { glds_set_dst(rg.idst); glds_piece_m0<0>(rg.isrc, rg.lane_off, rg.idst); }
+                        if (kq == LP_KQ / 2 + 1 && m == 1) { glds_piece_m0<1>(rg.isrc, rg.lane_off, rg.idst); lp_issue_next(rg); }
+                    }
 #if defined(LP_EPILOGUE_BURST)
-                    if (g > 0 && ks == 1 && blk == 1) lp_epilogue<BF, LAST>(g - 1, rt, rt + 1, acc[par ^ 1], dp, gq, out, part);
+                    if (g > 0 && ks == 1 && blk == NBLK - 1) lp_epilogue<BF, LAST>(g - 1, rt, rt + 1, acc[par ^ 1], dp, gq, out, part, 0, NBLK);
 #else
-                    if (NCH == 1) {          // first layer: four steps in all, one row tile behind every second MFMA of step 1
-                        if (g > 0 && ks == 1 && blk == 1) lp_epilogue<BF, LAST>(g - 1, rt, rt + 1, acc[par ^ 1], dp, gq, out, part);
+                    if (NCH == 1) {          // first layer: four steps in all, one row tile behind the last MFMA of each row tile of step 1
+                        if (g > 0 && ks == 1 && blk == NBLK - 1) lp_epilogue<BF, LAST>(g - 1, rt, rt + 1, acc[par ^ 1], dp, gq, out, part, 0, NBLK);
                     } else if (epi && !LAST) {
                         const int T = 4 * (g - 1) + ert;
-                        if (m == 4) { e0 = acc[par ^ 1][ert][eblk].x; e1 = acc[par ^ 1][ert][eblk].y; asm volatile("" : "+v"(e0), "+v"(e1)); }
-                        if (m == 5) out[2 * (T >> 1) + eblk][2 * (T & 1) + 0] = lp_relu_pack<BF>(e0, e1);
-                        if (m == 6) { e0 = acc[par ^ 1][ert][eblk].z; e1 = acc[par ^ 1][ert][eblk].w; asm volatile("" : "+v"(e0), "+v"(e1)); }
-                        if (m == 7) out[2 * (T >> 1) + eblk][2 * (T & 1) + 1] = lp_relu_pack<BF>(e0, e1);
-                    } else if (epi && m == 4) {      // last hidden layer (one pass in eight): the unit's dot-product terms in one piece
+                        if (m == E0 + 0) { e0 = acc[par ^ 1][ert][eblk].x; e1 = acc[par ^ 1][ert][eblk].y; asm volatile("" : "+v"(e0), "+v"(e1)); }
+                        if (m == E0 + 1) out[2 * (T >> 1) + eblk][2 * (T & 1) + 0] = lp_relu_pack<BF>(e0, e1);
+                        if (m == E0 + 2) { e0 = acc[par ^ 1][ert][eblk].z; e1 = acc[par ^ 1][ert][eblk].w; asm volatile("" : "+v"(e0), "+v"(e1)); }
+                        if (m == E0 + 3) out[2 * (T >> 1) + eblk][2 * (T & 1) + 1] = lp_relu_pack<BF>(e0, e1);
+                    } else if (epi && m == E0) {      // last hidden layer (one pass in eight): the unit's dot-product terms in one piece
                         lp_epilogue<BF, LAST>(g - 1, ert, ert + 1, acc[par ^ 1], dp, gq, out, part, eblk, eblk + 1);
                     }
 #endif
@@ -259,11 +269,15 @@ __device__ __forceinline__ void lp_pass(const LpPass pd, u32x4 (&in)[32], u32x4 
         }
     }
     // the last group's epilogue has no MFMAs of its own pass to hide behind
-    lp_epilogue<BF, LAST>(LP_NOG - 1, 0, LP_RT, acc[(LP_NOG - 1) & 1], dp, gq, out, part);
+    lp_epilogue<BF, LAST>(LP_NOG - 1, 0, LP_RT, acc[(LP_NOG - 1) & 1], dp, gq, out, part, 0, NBLK);
 }
 
-template <bool BF>
-__global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpArgs a) {
+// NW = 4 waves (one per SIMD) or 8 (two per SIMD, NBLK = 1 only: 208 registers): with two waves on a SIMD one wave's A-fragment reads, DMA
+// issue and epilogue fill the slots the other's 16-cycle MFMAs leave, at the price of one fragment read per MFMA instead of one per two.
+template <bool BF, int NBLK, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void mlp_lp_kernel(const LpArgs a) {
+    constexpr int TILE = 16 * NBLK * NW, WAVE_PTS = 16 * NBLK;     // LP_TILE_PTS / LP_WAVE_PTS for NBLK = 2, NW = 4
+    constexpr int NT = 64 * NW, WAVE_BYTES = CHUNK_BYTES / NW, PIECES = 16 / NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -278,32 +292,37 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpArgs a) {
 
     DirectList dl{0, 0, 0, 0};
     if (a.direct.kind) {
-        dl = direct_list(a.direct, LP_TILE_PTS);
+        dl = direct_list(a.direct, TILE);
         if (blockIdx.x == 0 && tid == 0) direct_commit(a.direct, dl);
     }
     const int n_tiles = a.direct.kind ? dl.n_tiles : *a.n_tiles;
     if ((int)blockIdx.x >= n_tiles) return;
     if (a.clk && blockIdx.x == 0 && tid == 0) { a.clk[0] = clock64(); a.clk[1] = wall_clock64(); }
-    for (int i = tid; i < a.n_bias_rows * WIDTH; i += 256) bias_l[i] = a.bias_tab[i];
-    for (int i = tid; i < WIDTH; i += 256) zero_l[i] = 0.f;
+    for (int i = tid; i < a.n_bias_rows * WIDTH; i += NT) bias_l[i] = a.bias_tab[i];
+    for (int i = tid; i < WIDTH; i += NT) zero_l[i] = 0.f;
     __syncthreads();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     LpRing rg;
     rg.issue_pos = 0; rg.issue_slot = 0; rg.rd_slot = 0; rg.total_chunks = a.total_chunks;
-    rg.wbase = reinterpret_cast<const char*>(a.wstream) + wave * 4096;   // wave-uniform; the lane part is rg.lane_off
+    rg.wbase = reinterpret_cast<const char*>(a.wstream) + wave * WAVE_BYTES;   // wave-uniform; the lane part is rg.lane_off
     rg.lane_off = lane * 16;
     rg.isrc = rg.wbase;
-    rg.ring0 = lds_addr(ring_ptr) + wave * 4096;
+    rg.ring0 = lds_addr(ring_ptr) + wave * WAVE_BYTES;
     rg.idst = rg.ring0;
     rg.ring_ptr = ring_ptr;
     rg.ring_lane = lds_addr(ring_ptr) + lane * 16;
 #pragma unroll
     for (int i = 0; i < LP_NBUF - 1; ++i) {
-        glds_quarter(rg.isrc, rg.lane_off, rg.idst);
+        if constexpr (NW == 4) {
+            glds_quarter(rg.isrc, rg.lane_off, rg.idst);
+        } else {
+            glds_piece<0>(rg.isrc, rg.lane_off, rg.idst);
+            glds_piece<1>(rg.isrc, rg.lane_off, rg.idst);
+        }
         lp_issue_next(rg);
     }
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(GLDS_PER_CHUNK * (LP_NBUF - 2)) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PIECES * (LP_NBUF - 2)) : "memory");
     u32x4 abuf[2][LP_RT];        // A fragments of the current step and of the next one
 #pragma unroll
     for (int rt = 0; rt < LP_RT; ++rt) {
@@ -324,21 +343,21 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpArgs a) {
     const float* wl = bias_l + a.wlast_row * WIDTH;
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int4 td = a.direct.kind ? direct_tile(a.direct, dl, tile, LP_TILE_PTS) : a.tiles[tile];
+        const int4 td = a.direct.kind ? direct_tile(a.direct, dl, tile, TILE) : a.tiles[tile];
         // this lane's two points: one per 16-point column block of the wave
         bool valid[2];
         int pidx[2], src[2];
         float4 pt[2];
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
-            const int local = wave * LP_WAVE_PTS + 16 * blk + pl;
-            valid[blk] = local < td.y;
+            const int local = wave * WAVE_PTS + 16 * blk + pl;
+            valid[blk] = blk < NBLK && local < td.y;
             pidx[blk] = td.x + (valid[blk] ? local : 0);
             src[blk] = a.index ? a.index[pidx[blk]] : pidx[blk];
             pt[blk] = a.pts[src[blk]];
             if (!valid[blk]) pt[blk] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        reinterpret_cast<float4*>(cb_l)[tid] = reinterpret_cast<const float4*>(a.code_bias + (size_t)td.z * a.code_bias_stride)[tid];
+        if (tid < 256) reinterpret_cast<float4*>(cb_l)[tid] = reinterpret_cast<const float4*>(a.code_bias + (size_t)td.z * a.code_bias_stride)[tid];
         __syncthreads();
 
         // split-precision xyz operands (LP_XYZ_TERMS): k slot 16 u + 3 t + c of the xyz step carries part xpart(u, t) of coordinate c
@@ -378,12 +397,12 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpArgs a) {
         // refuses others: the prepass is then off), so the last layer's input is always in X and the loop has no conditional half --
         // a join there costs ~120 spilled registers per tile.
         const int n_mid = a.n_pass - 2;      // hidden layers between the first and the last one
-        lp_pass<BF, 1, false>(a.pass[0], Y, X, acc, abuf, rg, xb, bias_of(a.pass[0]), zero_l, lane, gq, part);
+        lp_pass<BF, 1, false, NBLK, NW>(a.pass[0], Y, X, acc, abuf, rg, xb, bias_of(a.pass[0]), zero_l, lane, gq, part);
         for (int ps = 1; ps < n_mid; ps += 2) {       // n_mid is even (the host refuses odd pass counts): always both halves, no join
-            lp_pass<BF, LP_NCH, false>(a.pass[ps], X, Y, acc, abuf, rg, xb, bias_of(a.pass[ps]), zero_l, lane, gq, part);
-            lp_pass<BF, LP_NCH, false>(a.pass[ps + 1], Y, X, acc, abuf, rg, xb, bias_of(a.pass[ps + 1]), zero_l, lane, gq, part);
+            lp_pass<BF, LP_NCH, false, NBLK, NW>(a.pass[ps], X, Y, acc, abuf, rg, xb, bias_of(a.pass[ps]), zero_l, lane, gq, part);
+            lp_pass<BF, LP_NCH, false, NBLK, NW>(a.pass[ps + 1], Y, X, acc, abuf, rg, xb, bias_of(a.pass[ps + 1]), zero_l, lane, gq, part);
         }
-        lp_pass<BF, LP_NCH, true>(a.pass[a.n_pass - 1], X, Y, acc, abuf, rg, xb, bias_of(a.pass[a.n_pass - 1]), wl, lane, gq, part);
+        lp_pass<BF, LP_NCH, true, NBLK, NW>(a.pass[a.n_pass - 1], X, Y, acc, abuf, rg, xb, bias_of(a.pass[a.n_pass - 1]), wl, lane, gq, part);
         // a point's 512 rows are spread over the four lane groups: lanes p, p + 16, p + 32, p + 48
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
@@ -396,7 +415,7 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpArgs a) {
         // exactly 1.0f is the optimiser's "never decoded" placeholder (gn_kernels.hip: sample_write_ray): a prepass value never takes it.
         // (tanh saturates to 1.0f above ~9 -- or after an f16 overflow upstream.)  NaN stays NaN: the band kernels send it to the fp32 kernel.
         if (y >= 1.0f) y = 0x1.fffffep-1f;
-        if (gq < 2 && (sb ? valid[1] : valid[0])) a.out_sdf[a.index ? (sb ? src[1] : src[0]) : (sb ? pidx[1] : pidx[0]) + td.w] = y;
+        if (gq < NBLK && (sb ? valid[1] : valid[0])) a.out_sdf[a.index ? (sb ? src[1] : src[0]) : (sb ? pidx[1] : pidx[0]) + td.w] = y;
         // stores and LDS-DMA share vmcnt and may retire out of order: drain before counting again
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -404,25 +423,37 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpArgs a) {
     if (a.clk && blockIdx.x == 0 && tid == 0) { a.clk[2] = clock64(); a.clk[3] = wall_clock64(); }
 }
 
-template __global__ void mlp_lp_kernel<false>(const LpArgs);
-template __global__ void mlp_lp_kernel<true>(const LpArgs);
+template __global__ void mlp_lp_kernel<false, 2, 4>(const LpArgs);
+template __global__ void mlp_lp_kernel<true, 2, 4>(const LpArgs);
+template __global__ void mlp_lp_kernel<false, 1, 4>(const LpArgs);
+template __global__ void mlp_lp_kernel<true, 1, 4>(const LpArgs);
+// (NW = 8 -- 128-point tiles as eight waves of one column block, two waves per SIMD -- was measured in round 5 and dropped: the matrix pipe's
+// duty rises from 0.67 to 0.71, the second fragment read per MFMA pair costs 150 MHz of granted clock, K0 1.105 ms per launch against 1.032:
+// profiles/r05_k0_clock.md.  The template parameter stays for that experiment.)
 
 static size_t mlp_lp_lds_bytes() { return BIAS_BYTES + CODEBIAS_BYTES + LP_ZERO_BYTES + LP_NBUF * CHUNK_BYTES; }
 
 hipError_t mlp_lp_prepare_device() {
-    const void* fns[2] = {reinterpret_cast<const void*>(&mlp_lp_kernel<false>), reinterpret_cast<const void*>(&mlp_lp_kernel<true>)};
-    for (int i = 0; i < 2; ++i) {
+    const void* fns[4] = {reinterpret_cast<const void*>(&mlp_lp_kernel<false, 2, 4>), reinterpret_cast<const void*>(&mlp_lp_kernel<true, 2, 4>),
+                          reinterpret_cast<const void*>(&mlp_lp_kernel<false, 1, 4>), reinterpret_cast<const void*>(&mlp_lp_kernel<true, 1, 4>)};
+    for (int i = 0; i < 4; ++i) {
         const hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlp_lp_lds_bytes());
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
 }
 
-hipError_t launch_mlp_lp(bool bf16, const LpArgs& args, int n_blocks, hipStream_t stream) {
-    if (bf16)
-        hipLaunchKernelGGL((mlp_lp_kernel<true>), dim3(n_blocks), dim3(256), mlp_lp_lds_bytes(), stream, args);
-    else
-        hipLaunchKernelGGL((mlp_lp_kernel<false>), dim3(n_blocks), dim3(256), mlp_lp_lds_bytes(), stream, args);
+// tile_pts: LP_TILE_PTS (128: two column blocks per wave) or LP_TILE_PTS_SMALL (64: one); the tile list must have been built for it
+hipError_t launch_mlp_lp(bool bf16, const LpArgs& args, int n_blocks, hipStream_t stream, int tile_pts) {
+    const bool small = tile_pts == LP_TILE_PTS_SMALL;
+    const size_t lds = mlp_lp_lds_bytes();
+    if (small) {
+        if (bf16) hipLaunchKernelGGL((mlp_lp_kernel<true, 1, 4>), dim3(n_blocks), dim3(256), lds, stream, args);
+        else hipLaunchKernelGGL((mlp_lp_kernel<false, 1, 4>), dim3(n_blocks), dim3(256), lds, stream, args);
+    } else {
+        if (bf16) hipLaunchKernelGGL((mlp_lp_kernel<true, 2, 4>), dim3(n_blocks), dim3(256), lds, stream, args);
+        else hipLaunchKernelGGL((mlp_lp_kernel<false, 2, 4>), dim3(n_blocks), dim3(256), lds, stream, args);
+    }
     return hipGetLastError();
 }
 

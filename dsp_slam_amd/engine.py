@@ -81,6 +81,10 @@ class Batch(object):
         Results are bit-identical for every setting whose delta exceeds the decoder's prepass error."""
         L.check(L.load().dsp_batch_set_prepass(self._h, int(mode), float(delta)), self.engine._h, "dsp_batch_set_prepass")
 
+    def set_prepass_tile(self, points=-1):
+        """-1 = automatic, 128 or 64 points per prepass tile (dsp_batch_set_prepass_tile).  Results are identical for either."""
+        L.check(L.load().dsp_batch_set_prepass_tile(self._h, int(points)), self.engine._h, "dsp_batch_set_prepass_tile")
+
     def set_prepass_audit(self, on=True):
         L.check(L.load().dsp_batch_set_prepass_audit(self._h, int(bool(on))), self.engine._h, "dsp_batch_set_prepass_audit")
 

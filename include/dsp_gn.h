@@ -136,6 +136,7 @@ int dsp_decode_sdf(dsp_handle* h, const float* code, const float* pts, int64_t n
 #define DSP_PREPASS_OFF 0
 #define DSP_PREPASS_F16 1
 #define DSP_PREPASS_BF16 2
+#define DSP_PREPASS_SMALL_TILES 0x100   /* or-ed into dtype: run the kernel's 64-point-tile form (one 16-point column block per wave) */
 int dsp_decode_sdf_prepass(dsp_handle* h, int dtype, const float* code, const float* pts, int64_t n, float* sdf_out);
 /* The same point set decoded for n_codes shape codes in ONE launch: sdf_out[c * n + i].  Batched form of the
  * MeshExtractor grid decode (reconstruct/optimizer.py:217-218) / the per-object loop of extract_map_objects.py:46-63. */
@@ -227,6 +228,11 @@ int dsp_batch_set_ray_pass_bounds(dsp_batch* b, const int32_t* bounds, int n_pas
  * measures the error on the actual workload; results are then identical, bit for bit, to prepass off.
  * mode: -1 automatic (f16 when the decoder geometry is supported), DSP_PREPASS_OFF / _F16 / _BF16; delta < 0 = default. */
 int dsp_batch_set_prepass(dsp_batch* b, int mode, float delta);
+/* Points per workgroup tile of the prepass kernel: 128 (a wave decodes two 16-point column blocks that share every weight fragment: the
+ * throughput form) or 64 (one column block: half the tile time).  -1 / 0 = automatic: 64 where an iteration's 128-point tiles would leave
+ * more than ~40 % of the CUs without one (one detection of SLAM's real size: ~117 tiles on 256 CUs).  Same arithmetic per point: results
+ * are identical for either setting. */
+int dsp_batch_set_prepass_tile(dsp_batch* b, int points);
 /* The calibration dsp_create made for this decoder at a ZERO code: largest |sdf_lp - sdf_fp32| it measured and the margin it derived
  * (DSP_E_STATE when the decoder's geometry has no prepass kernel); the full table follows. */
 int dsp_prepass_calibration(dsp_handle* h, int dtype, float* max_err, float* delta);

@@ -308,3 +308,50 @@ def test_guard_fires_on_a_margin_that_is_too_small_and_the_rerun_is_exact(oracle
     parity_log(kind="prepass_guard", case="forced margin 2e-5 (bf16)", dtype="bf16", guard_max_err=st["prepass_guard_max_err"],
                delta_zero_code=2e-5, trips=int(st["prepass_guard_trips"]), identical=True, rerun=True)
     own.close()
+
+
+@pytest.mark.parametrize("dtype", [L.PREPASS_F16, L.PREPASS_BF16])
+def test_small_prepass_tiles_give_the_same_values(eng, dtype):
+    """The prepass kernel's 64-point-tile form (round 5: one 16-point column block per wave instead of two; chosen automatically where an
+    iteration's 128-point tiles would leave most CUs idle -- one detection of SLAM's real size) runs the same arithmetic per point: every
+    prepass value is bit-identical to the 128-point form's, for ragged tile ends too."""
+    rng = np.random.default_rng(31)
+    code = (rng.normal(size=64) * 0.2).astype(np.float32)
+    for n in (1, 15, 16, 17, 63, 64, 65, 127, 129, 5000, 16387):
+        pts = rng.uniform(-1.0, 1.0, size=(n, 3)).astype(np.float32)
+        a = eng.decode_sdf_prepass(code, pts, dtype)
+        b = eng.decode_sdf_prepass(code, pts, dtype | L.PREPASS_SMALL_TILES)
+        assert np.array_equal(a, b), (n, np.abs(a - b).max())
+
+
+def test_detection_with_small_prepass_tiles_is_exact_and_faster(eng):
+    """One KITTI-size detection: 64-point prepass tiles (automatic for a list this short) against 128-point tiles -- every bit of every
+    iteration equal, the same work counters; the timing goes to the log."""
+    import time
+    det = synth.make_object(4242, n_surface=250, n_background=200)
+    prm = E.gn_params()
+    out, ms = {}, {}
+    for tile in (128, 64, -1):
+        b = eng.batch(prm, [det["t_cam_obj_init"]], [det["pts"]], [det["rays"]], [det["depth"]], trace=True)
+        b.set_prepass_tile(tile)
+        b.run()
+        ts = []
+        for _ in range(9):
+            t0 = time.perf_counter()
+            b.run()
+            b.results()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        out[tile] = (b.results(), [b.trace(e) for e in range(10)], b.stats())
+        ms[tile] = float(np.median(ts))
+        b.close()
+    for tile in (64, -1):
+        for x, y in zip(out[128][0], out[tile][0]):
+            assert np.array_equal(x, y), tile
+        for ta, tb in zip(out[128][1], out[tile][1]):
+            for k in ("H", "b", "dx", "V", "m", "K", "set_sums", "t_obj_cam", "code"):
+                assert np.array_equal(ta[k], tb[k]), (tile, k)
+        for k in ("n_prepass_points", "n_jac_points", "n_insphere_points", "n_cluster_tiles"):
+            assert out[128][2][k] == out[tile][2][k], (tile, k)
+    print("KITTI-size detection p50 (traced batch): 128-point prepass tiles %.3f ms, 64-point %.3f ms, automatic %.3f ms" % (ms[128], ms[64], ms[-1]))
+    parity_log(kind="prepass_tile", case="KITTI-size detection, prepass tile 128 vs 64 points", ms_128=ms[128], ms_64=ms[64], ms_auto=ms[-1])
+    assert ms[-1] <= ms[128] * 1.02
