@@ -20,7 +20,7 @@ PEAK32, PEAK16 = 157.3, 2500.0
 K1 = "_ZN3dsp10mlp_kernelILi1ELb0EEEvNS_7MlpArgsE.kd"
 K2 = "_ZN3dsp10mlp_kernelILi2ELb0EEEvNS_7MlpArgsE.kd"
 K2R = "_ZN3dsp10mlp_kernelILi3ELb0EEEvNS_7MlpArgsE.kd"
-K0 = "_ZN3dsp13mlp_lp_kernelILb0EEEvNS_6LpArgsE.kd"
+K0 = "_ZN3dsp13mlp_lp_kernelILb0ELi2ELi4EEEvNS_6LpArgsE.kd"      # f16, two column blocks per wave, four waves: the 128-point-tile form
 
 
 def read(name):
