@@ -1390,7 +1390,7 @@ __device__ __forceinline__ double fast_recip(double d) {
 // SOLVER 2: LDL^T, rows in lanes, eight columns per wave (default).  SOLVER 0: LDL^T with the packed triangle in the registers of eight waves (first
 // round-4 form).  SOLVER 1: the round-2/3 pivot-free Gauss-Jordan.  Both kept as A/B references (dsp_batch_set_solver).
 template <int SOLVER>
-__global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, ObjState* st, const double* gsum, GnParamsDev prm, int iter,
+__global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, ObjState* st, const double* gsum, const float* partials, int n_slices, GnParamsDev prm, int iter,
                                                          const float* codew, const float* cb0, const float* cblat, float* cbias,
                                                float* trace /*nullable*/, const float* depths_next /*nullable: forensics*/, int n_obj) {
     __shared__ double A[NS1][NS1 + 1];          // [H | b] in rows 0..n-1 (b = column n); the LDL^T form also keeps b as ROW n
@@ -1400,16 +1400,33 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
     const ObjConst c = oc[b];
     ObjState& s = st[b];
     if (s.status != DSP_STATUS_GOOD) return;
-    const double* G0 = gsum + ((size_t)b * 2 + 0) * (72 * 72);
-    const double* G1 = gsum + ((size_t)b * 2 + 1) * (72 * 72);
+    // The 72 x 72 Gram matrices of the two terms, reduced over the Gram kernel's slices by k_gram_reduce.  (Round 5 tried summing the
+    // per-slice partials HERE -- same slice order, bit-identical, one launch and one kernel boundary less per iteration: 3.01 ms per
+    // detection against 2.94, because 786 KB of partials through ONE CU's load path take longer than the 41-workgroup reduce kernel and
+    // the boundary together.  -DSOLVE_FUSED_REDUCE rebuilds that form.)
+#if !defined(SOLVE_FUSED_REDUCE)
+    const double* G0p = gsum + ((size_t)b * 2 + 0) * (72 * 72);
+    const double* G1p = gsum + ((size_t)b * 2 + 1) * (72 * 72);
+    auto gram = [=](int term, int idx) -> double { return (term ? G1p : G0p)[idx]; };
+#else
+    const float* P0 = partials + (((size_t)b * 2 + 0) * n_slices) * (72 * 72);
+    const float* P1 = partials + (((size_t)b * 2 + 1) * n_slices) * (72 * 72);
+    auto gram = [=](int term, int idx) -> double {
+        const float* p = (term ? P1 : P0) + idx;
+        double a = 0.0;
+#pragma unroll 8
+        for (int sl = 0; sl < n_slices; ++sl) a += (double)p[(size_t)sl * 72 * 72];
+        return a;
+    };
+#endif
     const int M = c.n_pts, K = s.K;
     const int pd = prm.pose_only ? 6 : 7;
     const int n = prm.pose_only ? 6 : NSOLVE;
     if (!prm.pose_only) {
         // losses (optimizer.py:134-155): mean of robust residual^2; an empty set gives NaN in the reference
         if (M == 0 || K == 0) { if (tid == 0) s.status = DSP_STATUS_NAN; return; }
-        const float sdf_loss = (float)G0[71 * 72 + 71] / (float)M;
-        const float ren_loss = (float)G1[71 * 72 + 71] / (float)K;
+        const float sdf_loss = (float)gram(0, 71 * 72 + 71) / (float)M;
+        const float ren_loss = (float)gram(1, 71 * 72 + 71) / (float)K;
         if (isnan(sdf_loss) || isnan(ren_loss)) { if (tid == 0) s.status = DSP_STATUS_NAN; return; }
         if (tid == 0) s.loss = prm.k1 * ren_loss + prm.k2 * sdf_loss;
         float jrot[7], res_rot;
@@ -1427,8 +1444,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
             const int i = tr0 + RG * q;
             const bool live = tr0 < RG && i < n;
             const int col = (j < n) ? j : 71;            // the augmented column is b = -J^T r~ (Gram column 71)
-            g0[q] = live ? G0[i * 72 + col] : 0.0;
-            g1[q] = live ? G1[i * 72 + col] : 0.0;
+            g0[q] = live ? gram(0, i * 72 + col) : 0.0;
+            g1[q] = live ? gram(1, i * 72 + col) : 0.0;
         }
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
@@ -1459,8 +1476,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
         for (int e = tid; e < n * (n + 1); e += SOLVE_THREADS) {
             const int i = e / (n + 1), j = e % (n + 1);
             double v;
-            if (j < n) { v = G0[i * 72 + j] / (double)Ma; if (i == j) v += 1e-2; }
-            else v = -G0[i * 72 + 71] / (double)Ma;
+            if (j < n) { v = gram(0, i * 72 + j) / (double)Ma; if (i == j) v += 1e-2; }
+            else v = -gram(0, i * 72 + 71) / (double)Ma;
             A[i][j] = v;
         }
     }
@@ -1964,13 +1981,15 @@ void launch_jrows(const ObjConst* oc, const ObjState* st, const float4* jpts, co
 void launch_solve(const ObjConst* oc, ObjState* st, const float* partials, double* gsum, int n_slices, const GnParamsDev& prm, int iter,
                   float* trace, const float* codew, const float* b0, const float* blat, float* cbias, const float* depths_next, int B, hipStream_t s,
                   int solver) {
+#if !defined(SOLVE_FUSED_REDUCE)
     hipLaunchKernelGGL(k_gram_reduce, dim3((72 * 72 + 255) / 256, B, prm.pose_only ? 1 : 2), dim3(256), 0, s, st, partials, n_slices, gsum);
+#endif
     if (solver == 1)
-        hipLaunchKernelGGL(k_solve<1>, dim3(B), dim3(SOLVE_THREADS), 0, s, oc, st, gsum, prm, iter, codew, b0, blat, cbias, trace, depths_next, B);
+        hipLaunchKernelGGL(k_solve<1>, dim3(B), dim3(SOLVE_THREADS), 0, s, oc, st, gsum, partials, n_slices, prm, iter, codew, b0, blat, cbias, trace, depths_next, B);
     else if (solver == 2)
-        hipLaunchKernelGGL(k_solve<2>, dim3(B), dim3(SOLVE_THREADS), 0, s, oc, st, gsum, prm, iter, codew, b0, blat, cbias, trace, depths_next, B);
+        hipLaunchKernelGGL(k_solve<2>, dim3(B), dim3(SOLVE_THREADS), 0, s, oc, st, gsum, partials, n_slices, prm, iter, codew, b0, blat, cbias, trace, depths_next, B);
     else
-        hipLaunchKernelGGL(k_solve<0>, dim3(B), dim3(SOLVE_THREADS), 0, s, oc, st, gsum, prm, iter, codew, b0, blat, cbias, trace, depths_next, B);
+        hipLaunchKernelGGL(k_solve<0>, dim3(B), dim3(SOLVE_THREADS), 0, s, oc, st, gsum, partials, n_slices, prm, iter, codew, b0, blat, cbias, trace, depths_next, B);
 }
 void launch_inlier_filter(const ObjConst* oc, ObjState* st, const float* jgrad, unsigned char* alive, int maxM, int B, hipStream_t s) {
     hipLaunchKernelGGL(k_inlier_filter, GRID2(maxM, B), dim3(256), 0, s, oc, st, jgrad, alive);
