@@ -2,6 +2,7 @@
 (tools/make_golden.py).  CPU only.  Tolerances: the oracle and the reference differ only in sgemm
 summation order / LAPACK call path, i.e. float32 round-off."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -301,3 +302,20 @@ def test_complex_decoder_linearisation_at_reference_states():
         it = F.oracle_linearisation(dec, prm, g["in_pts"], g["in_rays"], g["in_depth"], g["it_t_obj_cam"][e], g["it_code"][e], g["it_depths"][e])
         assert (it["V"], it["K"]) == (int(g["it_V"][e]), int(g["it_K"][e])), (e, it["V"], it["K"], int(g["it_V"][e]), int(g["it_K"][e]))
         assert rel(it["H"], g["it_H"][e]) < 1e-4 and rel(it["b"][mask], g["it_b"][e][mask]) < 1e-4
+
+
+def test_lie_goldens_regenerate_bit_for_bit(tmp_path):
+    """tests/golden/golden_lie.npz IS the unmodified reference's output: re-running tools/make_golden_lie.py here (build container only: it
+    imports /root/reference) reproduces every array bit for bit."""
+    import subprocess
+    import sys
+    from oracle import ref_shim
+    if not ref_shim.reference_available():
+        pytest.skip("no reference checkout on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DSP_GOLDEN_OUT=str(tmp_path))
+    subprocess.run([sys.executable, os.path.join(root, "tools", "make_golden_lie.py")], check=True, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+    a, b = golden("golden_lie.npz"), np.load(os.path.join(str(tmp_path), "golden_lie.npz"))
+    assert sorted(a.files) == sorted(b.files)
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k

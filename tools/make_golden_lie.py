@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import ref_shim  # noqa: E402
 
-GOLD = os.path.join(ROOT, "tests", "golden")
+GOLD = os.environ.get("DSP_GOLDEN_OUT", os.path.join(ROOT, "tests", "golden"))      # (tests regenerate into a scratch directory)
 
 
 def main():
