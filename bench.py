@@ -13,7 +13,8 @@ ranks shard them with no other collective: weak scaling, value = objects of all 
 Workloads (BASELINE.json configs):
   cfg2x64 (default; the configuration the metric is quoted on): 64 cfg2 objects per GPU -- 2000 surface points + 500
           background rays x 50 depth samples, 64-D code, 10 iterations, KITTI hyper-parameters;
-  cfg4    1024 cfg2 objects over 8 GPUs = 128 x N objects block-sharded by estimated cost (distributed.shard_objects);
+  cfg4    BASELINE configs[3] as written: a FIXED job of 1024 cfg2 objects (--total-objects) block-sharded over the N GPUs by
+          distributed.shard_objects (--partition static | measured): "scaling": "strong"; --objects-per-gpu makes it a weak-scaling run;
   cfg5    4000-point objects, Redwood hyper-parameters (5 iterations), a mixed batch on two resident decoders (cars, 64-D codes +
           chairs32, 32-D codes and its own weights), 32 + 32 objects per GPU.
 
@@ -23,8 +24,14 @@ The JSON line also carries
                 of those launches;
   prepass       the low-precision classification kernel in front of it (mlp_lp_kernel, f16 MFMA), priced SEPARATELY
                 against the dense 16-bit MFMA peak -- never mixed into the fp32 fraction;
-  prepass_off   the same batch timed in the same run with the prepass OFF (every in-sphere sample through the fp32 kernel, as the
-                reference evaluates it): objects/s, ms_per_step and the fp32 kernel's roofline fraction of THAT run;
+  prepass_off   the same batch timed in the same run, over the same number of steps, with the prepass OFF (every in-sphere sample through
+                the fp32 kernel, as the reference evaluates it): objects/s (= the top-level `value_fp32_only`), ms_per_step and the fp32
+                kernel's roofline fraction of THAT run; `dtype` says what the headline computed in ("f32 + f16 classifier");
+  roofline.rocprof_check
+                per LEG of this process (headline warm-up / timed, prepass-off warm-up / timed, clock probe, latency probes): launch
+                counts and HIP-event averages of the decoder kernels.  Every leg opens with one launch of a marker kernel (k_debug_lie), so
+                tools/rocpd_legs.py can split a rocprofv3 kernel trace of the same command at the marker dispatches and compare each
+                population of a kernel with its own figure (profiles/rNN_kernel_stats.md);
   cpu_baseline  the reference itself (kind "reference") when DSP_REFERENCE_ROOT points at a DSP-SLAM checkout, else
                 oracle/torch_baseline.py (kind "torch-restatement": the reference's own torch op sequence written out, bit-identical
                 results; `calibrated_vs_reference` = its time / the unmodified reference's, measured in the build container,
