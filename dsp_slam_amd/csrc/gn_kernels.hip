@@ -84,21 +84,37 @@ __device__ double det3(const double* r, int ld) {
 
 // Per-iteration derived quantities of one object (optimizer.py:120-126): T_co = inv(T_oc), scale =
 // det(R_co)^(1/3), depth range t_z -+ scale, torch.linspace(d_min, d_max, D) in float32.
-__device__ void derive_iter_state(ObjState& s, int n_depth) {
+// In registers (k_solve runs it in every lane of one wave and stores from lane 0 / one depth per lane: nothing is read back from memory):
+struct IterDerived { float t_co[16], scale, dmin, dmax, step; bool ok; };
+__device__ __forceinline__ IterDerived derive_iter_core(const float* t_oc, int n_depth) {
+    IterDerived r;
     double toc[16], tco[16];
-    for (int i = 0; i < 16; ++i) toc[i] = (double)s.t_oc[i];
-    if (!inv4(toc, tco)) { s.status = DSP_STATUS_NAN; return; }
-    for (int i = 0; i < 16; ++i) s.t_co[i] = (float)tco[i];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) toc[i] = (double)t_oc[i];
+    r.ok = inv4(toc, tco);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r.t_co[i] = (float)tco[i];
     const double det = det3(tco, 4);
-    const float scale = (float)cbrt(det);
-    s.scale = scale;
-    const float tz = s.t_co[11];
-    const float dmin = tz - 1.0f * scale, dmax = tz + 1.0f * scale;
-    s.dmin = dmin; s.dmax = dmax;
-    const float step = (dmax - dmin) / (float)(n_depth - 1);
-    for (int i = 0; i < n_depth; ++i)   // ATen linspace: first half from start, second half from end
-        s.depths[i] = (i < n_depth / 2) ? __fadd_rn(dmin, __fmul_rn(step, (float)i))
-                                        : __fsub_rn(dmax, __fmul_rn(step, (float)(n_depth - 1 - i)));
+    r.scale = (float)cbrt(det);
+    const float tz = r.t_co[11];
+    r.dmin = tz - 1.0f * r.scale;
+    r.dmax = tz + 1.0f * r.scale;
+    r.step = (r.dmax - r.dmin) / (float)(n_depth - 1);
+    return r;
+}
+// ATen linspace: first half from start, second half from end
+__device__ __forceinline__ float linspace_at(const IterDerived& r, int i, int n_depth) {
+    return (i < n_depth / 2) ? __fadd_rn(r.dmin, __fmul_rn(r.step, (float)i)) : __fsub_rn(r.dmax, __fmul_rn(r.step, (float)(n_depth - 1 - i)));
+}
+__device__ void derive_iter_state(ObjState& s, int n_depth) {
+    float toc[16];
+    for (int i = 0; i < 16; ++i) toc[i] = s.t_oc[i];
+    const IterDerived r = derive_iter_core(toc, n_depth);
+    if (!r.ok) { s.status = DSP_STATUS_NAN; return; }
+    for (int i = 0; i < 16; ++i) s.t_co[i] = r.t_co[i];
+    s.scale = r.scale;
+    s.dmin = r.dmin; s.dmax = r.dmax;
+    for (int i = 0; i < n_depth; ++i) s.depths[i] = linspace_at(r, i, n_depth);
 }
 
 // Prepass margin of an object from the largest entry of its current code (LpDeltaTab: measured per decoder at dsp_create with codes
@@ -1337,10 +1353,17 @@ __device__ void exp_se3_dev(const float* x, float* out /*16*/) {    // loss_util
 }
 
 // compute_rotation_loss_sim3 (loss.py:155-178): J (7) and residual from T_oc
+__device__ void rotation_prior(const float* t_co, float scale, float* jrot, float& res);
 __device__ void rotation_prior(const ObjState& s, float* jrot, float& res) {
+    float t_co[12];
+    for (int i = 0; i < 12; ++i) t_co[i] = s.t_co[i];
+    rotation_prior(t_co, s.scale, jrot, res);
+}
+// (on values: k_solve loads them with everything else it reads, before it waits for any of it)
+__device__ void rotation_prior(const float* t_co, float scale, float* jrot, float& res) {
     double rco[9];
-    const double sc = (double)s.scale;
-    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) rco[3 * r + c] = (double)(float)((double)s.t_co[4 * r + c] / sc);
+    const double sc = (double)scale;
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) rco[3 * r + c] = (double)(float)((double)t_co[4 * r + c] / sc);
     // r_oc = inv(r_co); for a (near-)rotation this is the adjugate / det
     const double det = det3(rco, 3);
     double roc[9];
@@ -1387,8 +1410,11 @@ __device__ __forceinline__ double fast_recip(double d) {
     return r;
 }
 
-// SOLVER 2: LDL^T, rows in lanes, eight columns per wave (default).  SOLVER 0: LDL^T with the packed triangle in the registers of eight waves (first
-// round-4 form).  SOLVER 1: the round-2/3 pivot-free Gauss-Jordan.  Both kept as A/B references (dsp_batch_set_solver).
+// SOLVER 3 (default): rows in lanes, eight columns per wave, one barrier per panel of eight pivots.  SOLVER 2: the same arithmetic with one barrier
+// per pivot (round 4).  SOLVER 0: LDL^T with the packed triangle in the registers of eight waves (first round-4 form).  SOLVER 1: the round-2/3
+// pivot-free Gauss-Jordan.  0-2 are kept as A/B references (dsp_batch_set_solver).
+template <bool V> struct BoolC { static constexpr bool value = V; };
+
 template <int SOLVER>
 __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, ObjState* st, const double* gsum, const float* partials, int n_slices, GnParamsDev prm, int iter,
                                                          const float* codew, const float* cb0, const float* cblat, float* cbias,
@@ -1399,7 +1425,16 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
     if (stamp) g_solve_clk[0] = wall_clock64();
     const ObjConst c = oc[b];
     ObjState& s = st[b];
-    if (s.status != DSP_STATUS_GOOD) return;
+    // Everything this launch reads from global memory goes out HERE, before the first of it is waited for -- the status word included
+    // (k_solve is a chain of latencies: status -> Gram loads -> state for the prior -> ... was three round trips of ~1 us each).
+    const int status = s.status, K = s.K;
+    float pr_tco[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) pr_tco[i] = s.t_co[i];
+    const float pr_scale = s.scale;
+    // the pose and the code this iteration started from, parked in LDS for the update at the end (visible after the assembly's barrier)
+    __shared__ float s_toc0[16], s_code0[CODE_LEN];
+    const float park = tid < 16 ? s.t_oc[tid] : (tid >= 64 && tid < 64 + CODE_LEN) ? s.code[tid - 64] : 0.f;
     // The 72 x 72 Gram matrices of the two terms, reduced over the Gram kernel's slices by k_gram_reduce.  (Round 5 tried summing the
     // per-slice partials HERE -- same slice order, bit-identical, one launch and one kernel boundary less per iteration: 3.01 ms per
     // detection against 2.94, because 786 KB of partials through ONE CU's load path take longer than the 41-workgroup reduce kernel and
@@ -1419,34 +1454,44 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
         return a;
     };
 #endif
-    const int M = c.n_pts, K = s.K;
+    const int M = c.n_pts;
     const int pd = prm.pose_only ? 6 : 7;
     const int n = prm.pose_only ? 6 : NSOLVE;
+    // thread (tr, tc) fills column tc of rows tr, tr+12, ... of the joint system: its Gram loads
+    const int tr0 = tid / (NSOLVE + 1), j = tid % (NSOLVE + 1);
+    constexpr int RG = 12, RPT = (NSOLVE + RG - 1) / RG;
+    double g0[RPT], g1[RPT];
+    float zq[RPT];
     if (!prm.pose_only) {
-        // losses (optimizer.py:134-155): mean of robust residual^2; an empty set gives NaN in the reference
-        if (M == 0 || K == 0) { if (tid == 0) s.status = DSP_STATUS_NAN; return; }
-        const float sdf_loss = (float)gram(0, 71 * 72 + 71) / (float)M;
-        const float ren_loss = (float)gram(1, 71 * 72 + 71) / (float)K;
-        if (isnan(sdf_loss) || isnan(ren_loss)) { if (tid == 0) s.status = DSP_STATUS_NAN; return; }
-        if (tid == 0) s.loss = prm.k1 * ren_loss + prm.k2 * sdf_loss;
-        float jrot[7], res_rot;
-        rotation_prior(s, jrot, res_rot);
-        // only entries 3 and 5 of the prior's jacobian are non-zero; selects instead of a run-time index keep it out of scratch
-        const float jrot3 = jrot[3], jrot5 = jrot[5];
-        auto jr = [=](int i) { return i == 3 ? jrot3 : (i == 5 ? jrot5 : 0.f); };
-        const double w_s = (double)prm.k2 / (double)M, w_r = (double)prm.k1 / (double)K;
-        // thread (tr, tc) fills column tc of rows tr, tr+12, ...: all its Gram loads are issued before the first use
-        const int tr0 = tid / (NSOLVE + 1), j = tid % (NSOLVE + 1);
-        constexpr int RG = 12, RPT = (NSOLVE + RG - 1) / RG;
-        double g0[RPT], g1[RPT];
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
             const int i = tr0 + RG * q;
             const bool live = tr0 < RG && i < n;
             const int col = (j < n) ? j : 71;            // the augmented column is b = -J^T r~ (Gram column 71)
-            g0[q] = live ? gram(0, i * 72 + col) : 0.0;
-            g1[q] = live ? gram(1, i * 72 + col) : 0.0;
+            const int gi = live ? i * 72 + col : 0;
+            g0[q] = gram(0, gi);
+            g1[q] = gram(1, gi);
+            zq[q] = s.code[min(max(i - pd, 0), CODE_LEN - 1)];             // the right-hand side's k3 z term (optimizer.py:172); unconditional: a
+                                                                           // load in a branch is waited for at the branch's end
         }
+    }
+    const double g_loss0 = prm.pose_only ? 0.0 : gram(0, 71 * 72 + 71), g_loss1 = prm.pose_only ? 0.0 : gram(1, 71 * 72 + 71);
+    if (status != DSP_STATUS_GOOD) return;
+    if (tid < 16) s_toc0[tid] = park;
+    if (tid >= 64 && tid < 64 + CODE_LEN) s_code0[tid - 64] = park;
+    if (!prm.pose_only) {
+        // losses (optimizer.py:134-155): mean of robust residual^2; an empty set gives NaN in the reference
+        if (M == 0 || K == 0) { if (tid == 0) s.status = DSP_STATUS_NAN; return; }
+        const float sdf_loss = (float)g_loss0 / (float)M;
+        const float ren_loss = (float)g_loss1 / (float)K;
+        if (isnan(sdf_loss) || isnan(ren_loss)) { if (tid == 0) s.status = DSP_STATUS_NAN; return; }
+        if (tid == 0) s.loss = prm.k1 * ren_loss + prm.k2 * sdf_loss;
+        float jrot[7], res_rot;
+        rotation_prior(pr_tco, pr_scale, jrot, res_rot);
+        // only entries 3 and 5 of the prior's jacobian are non-zero; selects instead of a run-time index keep it out of scratch
+        const float jrot3 = jrot[3], jrot5 = jrot[5];
+        auto jr = [=](int i) { return i == 3 ? jrot3 : (i == 5 ? jrot5 : 0.f); };
+        const double w_s = (double)prm.k2 / (double)M, w_r = (double)prm.k1 / (double)K;
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
             const int i = tr0 + RG * q;
@@ -1463,7 +1508,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
                 if (i == pd - 1 && j == pd - 1) v += (double)prm.s_damp;                       // :184
             } else {
                 v = -(w_s * g0[q] + w_r * g1[q]);                                              // b = -J^T r~
-                if (i >= pd) v -= (double)prm.k3 * (double)s.code[i - pd];                     // :172
+                if (i >= pd) v -= (double)prm.k3 * (double)zq[q];                              // :172
                 if (i >= pd + prm.code_len) v = 0.0;
                 if (i < pd) v += (double)prm.k4 * (double)jr(i) * (double)res_rot;             // :177,179 (sign as written)
             }
@@ -1514,8 +1559,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
         __shared__ double rdv[NS1];
         __shared__ int s_sing;
         if (tid < n) A[n][tid] = A[tid][n];           // b as row n
-        if constexpr (SOLVER == 2) {
-        // Rows-in-lanes form (default).  What bounds the packed form below is the LDS: twelve 8-byte reads per thread and step = 96
+        if (SOLVER == 3 && tid == 0) s_sing = 0;      // raised by the panel waves
+        if constexpr (SOLVER == 2 || SOLVER == 3) {
+        // Rows-in-lanes form (SOLVER 3, the default, runs it panel-wise -- below; SOLVER 2 is its round-4 schedule, one barrier per pivot).  What bounds the packed form below is the LDS: twelve 8-byte reads per thread and step = 96
         // wave-wide LDS instructions = 42 KB through a 128 B/clk port, ~400 of its ~1100 cycles per step (a 9 x 9-blocked form with 11
         // broadcast reads per lane cost the same: the port does not care that 56 of 64 lanes read the same word).  Here wave w < 9 owns
         // columns 8w .. 8w+7 and lane l is row l: v0[jj] = A[l][8w+jj]; rows 64 .. 71 (seven code unknowns and the right-hand side) sit
@@ -1538,6 +1584,90 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
         auto readlane_f64 = [](double x, int l) {
             return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
         };
+        if constexpr (SOLVER == 3) {
+        // Panel schedule (round 5).  The arithmetic of the round-4 schedule below, element for element (every a_ij sees the same
+        // v -= (c_ik rd_k) c_jk for k ascending: bit-identical), but ONE barrier per EIGHT pivots instead of one per pivot: what a step
+        // of the old schedule cost was not its 36 VALU instructions but the chain publish -> barrier -> LDS read in front of them
+        // (~860 cycles per pivot, 25 of k_solve's 40 us).  Wave kb owns columns 8kb .. 8kb+7 whole (rows in lanes), so it can run the
+        // eight steps of its panel on its own registers: the pivot and the column entries c_jk are lanes of the register that IS
+        // column k (v_readlane), and only the eight extra rows (vx) need the LDS -- the wave's own write, read back in order, off the
+        // pivot chain.  It publishes each column as it becomes final, with the pivot's reciprocal.  After the barrier the waves to
+        // its right apply the eight steps in one burst (24 LDS reads issued up front), the next panel's wave at raised priority.
+        const bool active = worker && 8 * w <= n;                         // pose-only (n = 6): wave 0 alone
+#pragma unroll 1
+        for (int kb = 0; 8 * kb < n; ++kb) {
+            if (active && w == kb) {
+                auto panel = [&](auto last_c) {
+                    constexpr bool LAST = decltype(last_c)::value;        // wave 8: rows / pivots 64 .. 70 live in vx
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const int k = 8 * kb + t;
+                        if (k < n) {                                      // uniform
+                            Af[o0 + k] = v0[t];                           // column k is final: publish it (rows 0 .. 63, then rows 64 .. 71)
+                            if ((lane >> 3) == t) Af[oxr + k] = vx;
+                            const bool open = t < 7 || LAST;              // a column of mine is still open
+                            double cix = 0.0, cjx = 0.0;
+                            // rows 64 .. 71 of column k and rows 8w .. 8w+7 come back from the LDS: OTHER LANES' writes of this wave.  The
+                            // LDS serves a wave's instructions in order, but to the compiler lanes are unrelated threads (without the
+                            // fences it hoisted the non-writing lanes' read above the write): wave-scope release / acquire, no instruction
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                            if (open) { cix = Af[oxr + k]; cjx = Af[oxc + k]; }
+                            __builtin_amdgcn_sched_barrier(0);
+                            // the pivot chain: nothing in it waits for the LDS (except in wave 8, whose column entries are rows of vx)
+                            const double d = LAST ? readlane_f64(vx, 9 * t) : readlane_f64(v0[t], k);
+                            const double rdk = fast_recip(d);
+                            sing = sing || !(d > 0.0);                    // also NaN
+                            if (open) {
+                                const double l0 = lane == k ? 0.0 : v0[t] * rdk;
+#pragma unroll
+                                for (int jj = t + 1; jj < 8; ++jj)
+                                    v0[jj] = fma(-l0, LAST ? readlane_f64(cix, jj) : readlane_f64(v0[t], 8 * kb + jj), v0[jj]);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (lane == 0) rdv[k] = rdk;
+                            if (open) {
+                                const double lx = (64 + (lane & 7)) == k ? 0.0 : cix * rdk;
+                                vx = fma(-lx, cjx, vx);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                };
+                if (kb == 8) panel(BoolC<true>{}); else panel(BoolC<false>{});
+                if (sing && lane == 0) s_sing = 1;
+            }
+            if (w == kb + 1) __builtin_amdgcn_s_setprio(2);
+            __syncthreads();                                              // panel kb and its reciprocals are published
+            if (active && w > kb) {
+                // every column of the panel exists here (8 kb + 7 < 8 w <= n) and every pivot row is one of rows 0 .. 63: straight-line
+                // code, in two half-bursts of four steps whose 16 LDS reads are all in flight before the first use
+                const int cbase = (w == 8) ? 0 : 8 * w;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    double ci0[4], cix[4], cjx[4], rk[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int k = 8 * kb + 4 * h + t;
+                        ci0[t] = Af[o0 + k]; cix[t] = Af[oxr + k]; cjx[t] = Af[oxc + k]; rk[t] = rdv[k];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int k = 8 * kb + 4 * h + t;
+                        const double csrc = (w == 8) ? cix[t] : ci0[t];
+                        const double l0 = lane == k ? 0.0 : ci0[t] * rk[t], lx = cix[t] * rk[t];
+#pragma unroll
+                        for (int jj = 0; jj < 8; ++jj) v0[jj] = fma(-l0, readlane_f64(csrc, cbase + jj), v0[jj]);
+                        vx = fma(-lx, cjx[t], vx);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (w == kb + 1) __builtin_amdgcn_s_setprio(0);
+        }
+        } else {
 #pragma unroll 1
         for (int kb = 0; 8 * kb < n; ++kb) {
 #pragma unroll
@@ -1569,6 +1699,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
             }
         }
         if (tid == 8 * 64) s_sing = sing ? 1 : 0;
+        }
         __syncthreads();
         // dx_i = A[i][n] / d_i: column n is register n & 7 of wave n >> 3 (n = 71: wave 8, v0[7] and the vx lanes of column 7; n = 6: wave 0, v0[6])
         if (w == (n >> 3)) {
@@ -1753,7 +1884,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
     __shared__ float zc[CODE_LEN];
     if (!prm.pose_only && tid >= 64 && tid < 64 + CODE_LEN) {
         const int i = tid - 64;
-        const float zv = s.code[i] + prm.lr * (float)A[pd + i][n];
+        const float zv = s_code0[i] + prm.lr * (float)A[pd + i][n];
         s.code[i] = zv;
         zc[i] = zv;
         // the prepass margin follows the code (this wave holds all CODE_LEN = 64 entries)
@@ -1764,7 +1895,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
         if (i == 0) s.lp_delta = lp_delta_of(bad ? __int_as_float(0x7f800000) : zmax, prm.lp);
     }
     __syncthreads();
-    if (tid == 0) {
+    if (tid < 64) {
+        // the whole of wave 0 runs the serial pose arithmetic (a wave costs what a lane costs), so that lane 0 stores the matrices and
+        // lane i the i-th depth sample; the old pose and code were parked in LDS by the assembly: no global round trip on this path
         float dx[7], dT[16], nt[16];
         for (int i = 0; i < pd; ++i) dx[i] = (prm.pose_only ? 1.f : prm.lr) * (float)A[i][n];
         if (prm.pose_only) exp_se3_dev(dx, dT); else exp_sim3_dev(dx, dT);
@@ -1774,20 +1907,33 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
             for (int cc = 0; cc < 4; ++cc) {
                 float acc = 0.f;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) acc += dT[4 * r + k] * s.t_oc[4 * k + cc];
+                for (int k = 0; k < 4; ++k) acc += dT[4 * r + k] * s_toc0[4 * k + cc];
                 nt[4 * r + cc] = acc;
             }
+        if (tid == 0) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s.t_oc[i] = nt[i];
-        s.vsum = 0; s.ksum = 0;
-        s.V = 0; s.P = 0;          // the wave-per-ray bookkeeping counts into these (k_front_wave, k_band_wave); the scans of the other forms overwrite them
+            for (int i = 0; i < 16; ++i) s.t_oc[i] = nt[i];
+            s.vsum = 0; s.ksum = 0;
+            s.V = 0; s.P = 0;      // the wave-per-ray bookkeeping counts into these (k_front_wave, k_band_wave); the scans of the other forms overwrite them
+        }
         if (stamp) g_solve_clk[3] = wall_clock64();
         if (!prm.pose_only) {
-            derive_iter_state(s, prm.n_depth);
-            if (depths_next) {     // forensics (dsp_batch_set_depth_schedule): the next iteration samples exactly these depths
-                for (int i = 0; i < prm.n_depth; ++i) s.depths[i] = depths_next[MAX_DEPTH_SAMPLES * b + i];
-                s.dmin = s.depths[0];
-                s.dmax = s.depths[prm.n_depth - 1];
+            const IterDerived r = derive_iter_core(nt, prm.n_depth);
+            if (!r.ok) {
+                if (tid == 0) s.status = DSP_STATUS_NAN;
+            } else {
+                if (tid == 0) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) s.t_co[i] = r.t_co[i];
+                    s.scale = r.scale;
+                }
+                // forensics (dsp_batch_set_depth_schedule): the next iteration samples exactly these depths
+                const float* dn = depths_next ? depths_next + MAX_DEPTH_SAMPLES * b : nullptr;
+                if (tid < prm.n_depth) s.depths[tid] = dn ? dn[tid] : linspace_at(r, tid, prm.n_depth);
+                if (tid == 0) {
+                    s.dmin = dn ? dn[0] : r.dmin;
+                    s.dmax = dn ? dn[prm.n_depth - 1] : r.dmax;
+                }
             }
         }
         if (stamp) g_solve_clk[4] = wall_clock64();
@@ -1986,6 +2132,8 @@ void launch_solve(const ObjConst* oc, ObjState* st, const float* partials, doubl
 #endif
     if (solver == 1)
         hipLaunchKernelGGL(k_solve<1>, dim3(B), dim3(SOLVE_THREADS), 0, s, oc, st, gsum, partials, n_slices, prm, iter, codew, b0, blat, cbias, trace, depths_next, B);
+    else if (solver == 3)
+        hipLaunchKernelGGL(k_solve<3>, dim3(B), dim3(SOLVE_THREADS), 0, s, oc, st, gsum, partials, n_slices, prm, iter, codew, b0, blat, cbias, trace, depths_next, B);
     else if (solver == 2)
         hipLaunchKernelGGL(k_solve<2>, dim3(B), dim3(SOLVE_THREADS), 0, s, oc, st, gsum, partials, n_slices, prm, iter, codew, b0, blat, cbias, trace, depths_next, B);
     else

@@ -318,10 +318,11 @@ int dsp_batch_set_cluster_tiles(dsp_batch* b, int mode);
  * themselves instead of reading lists a single-workgroup kernel built in front of them (two launches less per iteration of a
  * detection).  -1 = automatic (on), 0 = off, 1 = on.  Same tiles, same results. */
 int dsp_batch_set_direct_tiles(dsp_batch* b, int mode);
-/* The 71 x 71 (pose-only: 6 x 6) normal equations are solved in fp64 on the device: LDL^T with the right-hand side as an extra row + one
- * back substitution -- 2 = blocked over nine waves (default), 0 = packed triangle in the registers of eight waves (bit-identical to 2) --
- * or 1 = pivot-free Gauss-Jordan (rounds 2-3).  0 and 1 are kept as A/B references.  All are exact to fp64 round-off on the symmetric
- * positive definite H of optimizer.py:161-184; dx agrees to ~1e-12 relative. */
+/* The 71 x 71 (pose-only: 6 x 6) normal equations are solved in fp64 on the device, pivot-free (H of optimizer.py:161-184 is symmetric
+ * positive definite): 3 = rows in lanes, columns in the registers of nine waves, the right-hand side as one more column, elimination
+ * above and below the pivot, ONE barrier per panel of eight pivots (default); 2 = the same arithmetic with one barrier per pivot
+ * (round 4; bit-identical to 3); 0 = LDL^T with the packed triangle in the registers of eight waves + a back substitution; 1 = the
+ * Gauss-Jordan kernel of rounds 2-3.  0-2 are kept as A/B references; dx agrees to ~1e-12 relative among all of them. */
 int dsp_batch_set_solver(dsp_batch* b, int mode);
 /* HIP events around every decoder launch, i.e. the dsp_stats.ms_mlp_* fields: -1 = automatic (on for batches of more than 16 objects --
  * the bench's roofline needs them; off for latency-sized batches, where an event record between two kernels is a queue packet of its own),

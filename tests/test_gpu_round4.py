@@ -134,8 +134,14 @@ def test_ldl_solver_equals_gauss_jordan(eng):
     n_it = 5
     prm = E.gn_params(num_iterations=n_it)
     objs = synth.make_batch(4, first_seed=2100, n_surface=300, n_background=120)
-    a = _run_traced(eng, prm, objs, n_it, solver=2)
+    a = _run_traced(eng, prm, objs, n_it, solver=3)
     c = _run_traced(eng, prm, objs, n_it, solver=1)
+    # the round-4 schedule of the default form (one barrier per pivot instead of one per panel of eight): the same arithmetic, element for
+    # element -- every bit of every iteration's H, b and dx and of the results
+    a2 = _run_traced(eng, prm, objs, n_it, solver=2)
+    for ta, t2 in zip(a[1], a2[1]):
+        assert np.array_equal(ta["H"], t2["H"]) and np.array_equal(ta["b"], t2["b"]) and np.array_equal(ta["dx"], t2["dx"])
+    assert all(np.array_equal(x, y) for x, y in zip(a[0], a2[0]))
     # the packed LDL^T form (solver 0, first round-4 form): same pivots, dx from a back substitution instead of the elimination above the diagonal
     p0 = _run_traced(eng, prm, objs, n_it, solver=0)
     assert np.array_equal(a[1][0]["H"], p0[1][0]["H"]) and np.array_equal(a[0][3], p0[0][3])

@@ -36,6 +36,7 @@ for name, (M, Bg) in (("KITTI-size 250+200", (250, 200)), ("cfg2-size 2000+500",
                 ("render rows repeat their forward sweep (mixed mask reuse off)", dict(mixed_reuse=0)),
                 ("fused per-object bookkeeping (round 3)", dict(fused_bookkeeping=1)),
                 ("throughput bookkeeping", dict(fused_bookkeeping=0)),
+                ("solve with one barrier per pivot (round 4) instead of one per panel of eight", dict(solver=2)),
                 ("packed LDL^T solve (first round-4 form)", dict(solver=0)),
                 ("Gauss-Jordan solve (round 3)", dict(solver=1)),
                 ("per-kernel events on", dict(kernel_timing=1)),
