@@ -11,6 +11,7 @@
 #include "dsp_internal.h"
 
 #include <algorithm>
+#include <cstdio>
 
 namespace dsp {
 
@@ -1384,6 +1385,12 @@ __device__ void rotation_prior(const float* t_co, float scale, float* jrot, floa
 constexpr int NSOLVE = 71;
 
 __device__ unsigned long long g_solve_clk[8];   // development aid: wall_clock64 (100 MHz) stamps of object 0's last k_solve
+#if defined(SOLVE_STAMPS)
+__device__ unsigned long long g_solve_clk2[40];
+#define SOLVE_STAMP2(i) do { if (b == 0 && lane == 0) g_solve_clk2[i] = clock64(); } while (0)
+#else
+#define SOLVE_STAMP2(i) do { } while (0)
+#endif
 
 // per-slice Gram partials -> one fp64 Gram matrix per (object, term); fixed summation order
 __global__ __launch_bounds__(256) void k_gram_reduce(const ObjState* st, const float* partials, int n_slices, double* gsum) {
@@ -1586,17 +1593,20 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
         };
         if constexpr (SOLVER == 3) {
         // Panel schedule (round 5).  The arithmetic of the round-4 schedule below, element for element (every a_ij sees the same
-        // v -= (c_ik rd_k) c_jk for k ascending: bit-identical), but ONE barrier per EIGHT pivots instead of one per pivot: what a step
-        // of the old schedule cost was not its 36 VALU instructions but the chain publish -> barrier -> LDS read in front of them
-        // (~860 cycles per pivot, 25 of k_solve's 40 us).  Wave kb owns columns 8kb .. 8kb+7 whole (rows in lanes), so it can run the
-        // eight steps of its panel on its own registers: the pivot and the column entries c_jk are lanes of the register that IS
-        // column k (v_readlane), and only the eight extra rows (vx) need the LDS -- the wave's own write, read back in order, off the
-        // pivot chain.  It publishes each column as it becomes final, with the pivot's reciprocal.  After the barrier the waves to
-        // its right apply the eight steps in one burst (24 LDS reads issued up front), the next panel's wave at raised priority.
+        // v -= (c_ik rd_k) c_jk for k ascending: bit-identical), but ONE barrier per EIGHT pivots instead of one per pivot.  Wave kb owns
+        // columns 8kb .. 8kb+7 whole (rows in lanes), so it can run the eight steps of its panel on its own registers: the pivot and the
+        // column entries c_jk are lanes of the register that IS column k (v_readlane), and only the eight extra rows (vx) need the LDS --
+        // the wave's own write, read back in order, off the pivot chain.  It publishes each column as it becomes final, with the
+        // pivot's reciprocal.  After the barrier the waves to its right apply the eight steps in one burst (LDS reads issued up front).
+        // Measured with shader-clock stamps (-DSOLVE_STAMPS, profiles/r05_latency_kernel_stats.md): panel 2600 cycles, barrier 160,
+        // burst of the next panel's wave 2150 -> 18 us for the 71 pivots against 25 with one barrier per pivot (860 cycles each).  Both
+        // phases are issue-bound, ~8 cycles per instruction for a lone wave of fp64 FMAs and v_readlane pairs (~40 instructions per
+        // step each): raising the next panel wave's priority, bursts of 2 or 8 steps, changed nothing.
         const bool active = worker && 8 * w <= n;                         // pose-only (n = 6): wave 0 alone
 #pragma unroll 1
         for (int kb = 0; 8 * kb < n; ++kb) {
             if (active && w == kb) {
+                SOLVE_STAMP2(4 * kb);
                 auto panel = [&](auto last_c) {
                     constexpr bool LAST = decltype(last_c)::value;        // wave 8: rows / pivots 64 .. 70 live in vx
 #pragma unroll
@@ -1637,36 +1647,46 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
                 };
                 if (kb == 8) panel(BoolC<true>{}); else panel(BoolC<false>{});
                 if (sing && lane == 0) s_sing = 1;
+                SOLVE_STAMP2(4 * kb + 1);
             }
-            if (w == kb + 1) __builtin_amdgcn_s_setprio(2);
             __syncthreads();                                              // panel kb and its reciprocals are published
+            if (active && w == kb + 1) SOLVE_STAMP2(4 * kb + 2);
             if (active && w > kb) {
                 // every column of the panel exists here (8 kb + 7 < 8 w <= n) and every pivot row is one of rows 0 .. 63: straight-line
                 // code, in two half-bursts of four steps whose 16 LDS reads are all in flight before the first use
                 const int cbase = (w == 8) ? 0 : 8 * w;
+                constexpr int BS = 4;       // (8: 125 registers, no faster; 2: slower)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    double ci0[4], cix[4], cjx[4], rk[4];
+                for (int h = 0; h < 8 / BS; ++h) {
+                    double ci0[BS], cix[BS], cjx[BS], rk[BS];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int k = 8 * kb + 4 * h + t;
+                    for (int t = 0; t < BS; ++t) {
+                        const int k = 8 * kb + BS * h + t;
                         ci0[t] = Af[o0 + k]; cix[t] = Af[oxr + k]; cjx[t] = Af[oxc + k]; rk[t] = rdv[k];
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int k = 8 * kb + 4 * h + t;
+                    for (int t = 0; t < BS; ++t) {
+                        const int k = 8 * kb + BS * h + t;
                         const double csrc = (w == 8) ? cix[t] : ci0[t];
                         const double l0 = lane == k ? 0.0 : ci0[t] * rk[t], lx = cix[t] * rk[t];
+                        // the eight column entries into eight scalar pairs first, then the eight FMAs (one pair reused eight times
+                        // serialises v_readlane -> FMA through the scalar write: 2550 -> 2150 cycles per burst)
+                        double cj[8];
 #pragma unroll
-                        for (int jj = 0; jj < 8; ++jj) v0[jj] = fma(-l0, readlane_f64(csrc, cbase + jj), v0[jj]);
+                        for (int jj = 0; jj < 8; ++jj) cj[jj] = readlane_f64(csrc, cbase + jj);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int jj = 0; jj < 8; ++jj) v0[jj] = fma(-l0, cj[jj], v0[jj]);
+                        __builtin_amdgcn_sched_barrier(0);
                         vx = fma(-lx, cjx[t], vx);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (w == kb + 1) __builtin_amdgcn_s_setprio(0);
+            if (active && w == kb + 1) SOLVE_STAMP2(4 * kb + 3);
         }
+        if (w == 8) SOLVE_STAMP2(36);
         } else {
 #pragma unroll 1
         for (int kb = 0; 8 * kb < n; ++kb) {
@@ -2147,7 +2167,18 @@ void launch_finalize(ObjState* st, const float* scale, int B, int pose_only, flo
     hipLaunchKernelGGL(k_finalize, dim3((B + 63) / 64), dim3(64), 0, s, st, scale, B, pose_only, packed, guard_out);
 }
 
-hipError_t debug_solve_clocks(unsigned long long* out8) { return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_solve_clk), 64); }
+hipError_t debug_solve_clocks(unsigned long long* out8) {
+#if defined(SOLVE_STAMPS)     // development aid: per-panel shader-clock stamps of object 0's last k_solve<3>, to stderr
+    unsigned long long c2[40];
+    if (hipMemcpyFromSymbol(c2, HIP_SYMBOL(g_solve_clk2), sizeof(c2)) == hipSuccess) {
+        for (int kb = 0; kb < 9; ++kb)
+            fprintf(stderr, "panel %d: begin +%llu  panel %llu cycles  | next wave: barrier passed +%llu after panel end, burst %llu cycles\n", kb,
+                    c2[4 * kb] - c2[0], c2[4 * kb + 1] - c2[4 * kb], c2[4 * kb + 2] - c2[4 * kb + 1], c2[4 * kb + 3] - c2[4 * kb + 2]);
+        fprintf(stderr, "elimination end +%llu\n", c2[36] - c2[0]);
+    }
+#endif
+    return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_solve_clk), 64);
+}
 
 // Testing (dsp_debug_lie): the Lie-group maps and the rotation prior exactly as k_solve evaluates them -- ONE thread, the same device
 // functions, the same fp32 / fp64 arithmetic -- on caller-supplied arguments, so that each branch (theta <= 1e-8, s == 0, the
