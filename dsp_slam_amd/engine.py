@@ -2,6 +2,7 @@
 
 Everything numeric happens in the HIP library; there is no CPU or PyTorch fallback.
 """
+import atexit
 import ctypes as C
 import weakref
 
@@ -250,6 +251,19 @@ def pack_results_c(t_cam_obj, codes, loss, status):
 
 
 _last_engine = None
+_live_engines = weakref.WeakSet()
+
+
+@atexit.register
+def _close_engines_at_exit():
+    """Engines (and their batches) that are still alive when the interpreter exits -- a test that failed half way, a script that never called
+    close() -- are closed HERE, while the interpreter and the HIP runtime are intact and in the right order (batches first), instead of by
+    finalisers in no particular order."""
+    for e in list(_live_engines):
+        try:
+            e.close()
+        except Exception:
+            pass
 
 
 def last_engine():
@@ -269,6 +283,7 @@ class Engine(object):
         lib = L.load()
         self._desc = L.DecoderDescHolder(layers, latent_in, code_len)
         self._batches = weakref.WeakSet()
+        _live_engines.add(self)
         self._h = C.c_void_p()
         rc = lib.dsp_create(C.byref(self._desc.desc), int(device), C.byref(self._h))
         if rc != 0:

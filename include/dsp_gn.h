@@ -106,6 +106,8 @@ typedef struct dsp_stats {
 /* Thread safety: calls on ONE handle (and on batches created from it) are serialised inside the library (one call at a time per handle);
  * different handles are independent.  Callers that release the GIL around these calls (ctypes, pybind11) may therefore call from any thread. */
 int dsp_create(const dsp_decoder_desc* decoder, int device, dsp_handle** out);
+/* Destroys the handle AND every resident batch still alive on it; a later dsp_batch_destroy of such a batch is ignored (either order of the
+ * two calls is safe: finalisers at interpreter exit run in no particular order). */
 void dsp_destroy(dsp_handle* h);
 /* A handle keeps device blocks (up to 1 GiB, size-classed) and pinned host staging of dropped one-shot batches for its next call.  dsp_trim
  * hands all of it back to the runtime: for a process that shares the GPU with another allocator (torch, RCCL, a second handle).  Destroying
