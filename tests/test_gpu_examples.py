@@ -89,3 +89,17 @@ def test_cfg4_strong_scaling_job_with_two_ranks_on_one_gpu(partition):
     assert sum(r["objects"] for r in d["by_rank"]) == 10 and d["config"]["objects_good"] == 10
     assert partition in d["config"]["workload"]
     assert all(r["sum_V_per_step"] > 0 for r in d["by_rank"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["atexit", "reverse"])
+def test_a_process_that_exits_with_live_objects_exits(mode):
+    """A process that ends with an Engine and a Batch still alive (a test that failed half way, a script without close()) must END: finalisers
+    run in no particular order at interpreter exit, and dsp_batch_destroy after dsp_destroy used to lock a mutex inside the freed handle --
+    a hang that took a whole gpurun call with it (profiles/r05_cluster_exchange_stores.md).  `atexit`: both are left to the atexit handler of
+    dsp_slam_amd.engine (batches first).  `reverse`: dsp_destroy(handle) first, dsp_batch_destroy(batch) after it -- the library takes a
+    handle's live batches with it and ignores the late call.  In a child process, under a time limit."""
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_exit_leak.py"), mode], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240)
+    assert out.returncode == 0, out.stdout[-2000:]
+    assert "results ok" in out.stdout
