@@ -147,7 +147,8 @@ class Batch(object):
         L.check(L.load().dsp_batch_set_direct_tiles(self._h, int(mode)), self.engine._h, "dsp_batch_set_direct_tiles")
 
     def set_solver(self, mode):
-        """2 = blocked LDL^T with rows in lanes (default), 0 = packed LDL^T, 1 = pivot-free Gauss-Jordan (0 and 1: A/B references; dsp_gn.h)."""
+        """3 = fp64 elimination with rows in lanes, one barrier per panel of eight pivots (default); 2 = the same arithmetic, one barrier per
+        pivot (bit-identical to 3); 0 = packed LDL^T; 1 = pivot-free Gauss-Jordan (0-2: A/B references; dsp_gn.h)."""
         L.check(L.load().dsp_batch_set_solver(self._h, int(mode)), self.engine._h, "dsp_batch_set_solver")
 
     def set_mixed_reuse(self, mode):
