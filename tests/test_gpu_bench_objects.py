@@ -118,7 +118,8 @@ def test_batch64_at_the_references_recorded_states(batch64, oracle_decoder):
         b.set_start_state(t_oc, codes, depths)
         b.set_iterations(1)
         b.run()
-        assert (b.results()[3] == 0).all()
+        res_e = b.results()
+        assert (res_e[3] == 0).all()
         tr = b.trace(0)
         for i in full:
             assert np.array_equal(tr["t_obj_cam"][i], g["tr%d_it_t_obj_cam" % i][e]) and np.array_equal(tr["code"][i], g["tr%d_it_code" % i][e])
@@ -139,6 +140,11 @@ def test_batch64_at_the_references_recorded_states(batch64, oracle_decoder):
             tol_rot_h = k4 * (j_rot[:, None] + j_rot[None, :]) * 1e-6 + 3e-5 * hs
             assert np.all(np.abs(tr["H"][i] - h_ref)[3:6, 3:6] <= tol_rot_h), (i, e, np.abs(tr["H"][i] - h_ref)[3:6, 3:6].max(), tol_rot_h.max())
             n_named = 0
+            # `loss` after one iteration from the recorded state = the reference's loss AT that state (optimizer.py:155; tr<i>_it_loss:
+            # tools/make_golden_it_loss.py --bench); at the last state it is the value the recorded run returned (all_loss)
+            rl = F.loss_rel(res_e[2][i], g["tr%d_it_loss" % i][e])
+            if e == 9:
+                assert float(g["tr%d_it_loss" % i][e]) == float(g["all_loss"][i])
             if (int(tr["V"][i]), int(tr["K"][i])) != (v_ref, k_ref):
                 o = objs[i]
                 ot = F.oracle_linearisation(oracle_decoder, oprm, o["pts"], o["rays"], o["depth"], g["tr%d_it_t_obj_cam" % i][e], g["tr%d_it_code" % i][e],
@@ -149,8 +155,10 @@ def test_batch64_at_the_references_recorded_states(batch64, oracle_decoder):
                 assert flips and all(f["explained"] for f in flips) and len(flips) <= 4, (i, e, flips)
                 n_named = len(flips)
                 named_total += 1
+                assert rl <= F.LOSS_RTOL_FLIPPED, (i, e, rl)
             else:
                 strict += 1
+                assert rl <= F.LOSS_RTOL, (i, e, float(res_e[2][i]), float(g["tr%d_it_loss" % i][e]))
                 # Identical sample sets: H and b within 3e-5 / 1.2e-4 of the reference's recorded values (the bound of the seven
                 # single-object goldens, 3x what they measure) -- or, for the linearisations whose render rows sit on the amplifying inner
                 # edge of the band (de_ds ~ 1 / (1 - o) -> 1 / (2 th (1 - o)) ~ 5e3...5e4 per unit of sdf: these eight objects include the
@@ -175,11 +183,13 @@ def test_batch64_at_the_references_recorded_states(batch64, oracle_decoder):
                     tol_b[3:6] += _rot_prior_bound(h_ref, k4)
                     tol_dx = np.abs(np.linalg.inv(h_ref.astype(np.float64))) @ tol_b + 1e-4 * np.abs(dx_ref).max()
                     assert np.all(np.abs(tr["dx"][i] - dx_ref) <= tol_dx), (i, e)
-            rows.append(dict(object=i, iteration=e, V=v_ref, K=k_ref, rel_H=rh, rel_b=rb, named=n_named))
+            rows.append(dict(object=i, iteration=e, V=v_ref, K=k_ref, rel_H=rh, rel_b=rb, rel_loss=rl, named=n_named))
     b.set_start_state(None, zero_codes, None)
     parity_log(kind="bench_at_reference_states", case="64 x cfg2 bench batch, %d traced objects x 10 iterations inside the resident batch" % len(full), objects=full,
                n=len(rows), strict=strict, with_named_flips=named_total, beyond_tight_bounds=jitter_rows, max_rel_H=max(r["rel_H"] for r in rows), max_rel_b=max(r["rel_b"] for r in rows),
+               max_rel_loss=max(r["rel_loss"] for r in rows), n_loss_comparisons=len(rows),
                per_object={str(i): dict(max_rel_H=max(r["rel_H"] for r in rows if r["object"] == i), max_rel_b=max(r["rel_b"] for r in rows if r["object"] == i),
+                                        max_rel_loss=max(r["rel_loss"] for r in rows if r["object"] == i),
                                         K=[r["K"] for r in rows if r["object"] == i], named=sum(r["named"] > 0 for r in rows if r["object"] == i)) for i in full})
     assert strict >= len(rows) - 2, "more than two of %d linearisations with (named) flips at the reference's own states" % len(rows)
 

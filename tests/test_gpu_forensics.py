@@ -99,7 +99,7 @@ def test_linearisation_at_reference_states(eng, name):
     n_rays, n_d = g["in_rays"].shape[0], oprm.num_depth_samples
     obj = dict(pts=g["in_pts"], rays=g["in_rays"], depth=g["in_depth"])
     rows, strict, report = [], 0, ["## %s: device linearised at the reference's recorded states (injected bit for bit)" % name, "",
-                                   "| it | V dev/ref | K dev/ref | rel dH | rel db | rel ddx | flips |", "|---|---|---|---|---|---|---|"]
+                                   "| it | V dev/ref | K dev/ref | rel dH | rel db | rel ddx | rel dloss | flips |", "|---|---|---|---|---|---|---|---|"]
     n_unk = 7 + oprm.code_len                # 71, or 39 with the 32-D decoder (the device carries 64 code slots; the unused ones are pinned)
     mask = np.ones(n_unk, bool)
     mask[3:6] = False
@@ -115,6 +115,12 @@ def test_linearisation_at_reference_states(eng, name):
         h_ref, b_ref, dx_ref = g["it_H"][e], g["it_b"][e], g["it_dx"][e]
         rh, rb = F.rel_max(tr["H"][0], h_ref), F.rel_max(tr["b"][0][mask], b_ref[mask])
         rdx = F.rel_max(tr["dx"][0], dx_ref)
+        # the result's `loss` field after one iteration from this state IS the reference's loss at this state (optimizer.py:155,200-203;
+        # the field LocalMapping_util.cc:405-406 branches on); it_loss: the reference's own functions at the recorded state
+        # (tools/make_golden_it_loss.py; its last entry is bit-identical to the loss the recorded run returned)
+        rl = F.loss_rel(tr["loss"][0], g["it_loss"][e])
+        if e == n_it - 1:
+            assert float(g["it_loss"][e]) == float(g["loss"])
         flips = []
         if (v_dev, k_dev) != (v_ref, k_ref):
             ot = F.oracle_linearisation(oracle_decoder, oprm, obj["pts"], obj["rays"], obj["depth"], g["it_t_obj_cam"][e], g["it_code"][e], g["it_depths"][e])
@@ -124,9 +130,11 @@ def test_linearisation_at_reference_states(eng, name):
             assert flips, "set sizes differ but no differing sample was found"
             assert all(f["explained"] for f in flips), "\n".join(_fmt_flip(f) for f in flips)
             assert len(flips) <= 4
+            assert rl <= F.LOSS_RTOL_FLIPPED, (e, rl)
             report += ["", "iteration %d:" % e] + ["* " + _fmt_flip(f) for f in flips] + [""]
         else:
             strict += 1
+            assert rl <= F.LOSS_RTOL, (e, float(tr["loss"][0]), float(g["it_loss"][e]))
             # measured on MI355X (profiles/parity_r03.md): rel dH <= 9.2e-6, rel db <= 3.7e-5 over all 35 recorded iterations; the bounds
             # leave a factor of three, so a 10x regression of the per-step agreement fails here
             assert rh < 3e-5, (e, rh)
@@ -137,12 +145,12 @@ def test_linearisation_at_reference_states(eng, name):
             tol_b[3:6] += _rot_prior_bound(h_ref, k4)
             tol_dx = np.abs(np.linalg.inv(h_ref.astype(np.float64))) @ tol_b + 1e-4 * np.abs(dx_ref).max()
             assert np.all(np.abs(tr["dx"][0] - dx_ref) <= tol_dx), (e, np.abs(tr["dx"][0] - dx_ref).max(), tol_dx.max())
-        rows.append(dict(V=(v_dev, v_ref), K=(k_dev, k_ref), rel_H=rh, rel_b=rb, rel_dx=rdx, flips=len(flips)))
-        report.append("| %d | %d / %d | %d / %d | %.2e | %.2e | %.2e | %d |" % (e, v_dev, v_ref, k_dev, k_ref, rh, rb, rdx, len(flips)))
+        rows.append(dict(V=(v_dev, v_ref), K=(k_dev, k_ref), rel_H=rh, rel_b=rb, rel_dx=rdx, rel_loss=rl, flips=len(flips)))
+        report.append("| %d | %d / %d | %d / %d | %.2e | %.2e | %.2e | %.2e | %d |" % (e, v_dev, v_ref, k_dev, k_ref, rh, rb, rdx, rl, len(flips)))
     b.close()
     _write_report(name, report)
     parity_log(kind="at_reference_states", case=name, n=n_it, strict=strict, rel_H=[r["rel_H"] for r in rows], rel_b=[r["rel_b"] for r in rows],
-               rel_dx=[r["rel_dx"] for r in rows], flips=[r["flips"] for r in rows], K=[r["K"][1] for r in rows])
+               rel_dx=[r["rel_dx"] for r in rows], rel_loss=[r["rel_loss"] for r in rows], flips=[r["flips"] for r in rows], K=[r["K"][1] for r in rows])
     # measured on MI355X: strict in 45 of 45 recorded iterations (profiles/parity_r03.md); one named flip per run is the most a changed
     # instruction schedule could plausibly add
     assert strict >= n_it - 1, "more than one iteration with (named) flips at the reference's own states: %d of %d strict" % (strict, n_it)
@@ -201,6 +209,12 @@ def test_chained_divergence_is_the_maps_own(eng, name):
             tol_dx = np.abs(np.linalg.inv(ot["H"].astype(np.float64))) @ tol_b + 1e-4 * np.abs(ot["dx"]).max()
             assert F.rel_max(tr["H"][0], ot["H"]) < 1e-4, (e, F.rel_max(tr["H"][0], ot["H"]))
             assert np.all(np.abs(tr["dx"][0] - ot["dx"]) <= tol_dx), (e, loc)
+            if e == n_it - 1:
+                # the chained run's returned `loss` is the loss at the device's OWN last linearisation point (optimizer.py:155,200-203): against
+                # the oracle evaluated at exactly that state (the oracle reproduces the reference's it_loss at every recorded state to 1e-5,
+                # tests/test_oracle_golden.py) -- a statement about the returned field that the chained map's chaos cannot blur
+                chained_loss_rel = F.loss_rel(loss[0], ot["loss"])
+                assert chained_loss_rel <= F.LOSS_RTOL, (float(loss[0]), ot["loss"])
         report.append("| %d | %.1e / %.1e / %.1e | %d / %d | %d / %d | %.2e | %.2e | %d |" % (
             e, sd["rot"], sd["trans"], sd["code"], tr["V"][0], g["it_V"][e], tr["K"][0], g["it_K"][e], loc, pro, len(flips)))
     import test_gpu_parity as P
@@ -225,6 +239,7 @@ def test_chained_divergence_is_the_maps_own(eng, name):
         report.append("the device selected the reference's sample sets in all %d iterations" % n_it)
     _write_report(name, report)
     parity_log(kind="chained_forensic", case=name, first_flip_iteration=first, final=m, reference_spread=sens, local_rel_dx=local,
+               loss_vs_reference_rel=F.loss_rel(loss[0], g["loss"]),
                propagated_rel_dx=prop, incoming_state_diff=drift_in, flips_named=len(named), flips_explained=sum(1 for f in named if f["explained"]))
     b.close()
     if first is not None and drift_in[first] <= 2e-5:

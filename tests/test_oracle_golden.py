@@ -113,6 +113,10 @@ def _check_trace(oracle_decoder, name, tol_final, at_ref_iterations=None, pinned
         j_rot = np.sqrt(np.abs(np.diag(g["it_H"][e])[3:6]) / max(prm.k4, 1.0))
         tol_rot = prm.k4 * (j_rot + 1e-3) * 2.4e-7 + 1e-4 * np.abs(g["it_b"][e]).max()
         assert np.all(np.abs(it["b"][3:6] - g["it_b"][e][3:6]) <= tol_rot)
+        # the returned `loss` field at this state (optimizer.py:155; tools/make_golden_it_loss.py): measured <= 2e-6 relative
+        assert abs(it["loss"] - float(g["it_loss"][e])) <= 1e-5 * abs(float(g["it_loss"][e])), (e, it["loss"], float(g["it_loss"][e]))
+        assert abs(it["sdf_loss"] - float(g["it_loss_sdf"][e])) <= 1e-5 * abs(float(g["it_loss_sdf"][e]))
+        assert abs(it["render_loss"] - float(g["it_loss_render"][e])) <= 1e-5 * abs(float(g["it_loss_render"][e]))
 
     def chained(depths):
         tr = []
@@ -213,6 +217,7 @@ def test_cfg2_linearisation_at_reference_states(oracle_decoder):
         it = F.oracle_linearisation(oracle_decoder, prm, g["in_pts"], g["in_rays"], g["in_depth"], g["it_t_obj_cam"][e], g["it_code"][e], g["it_depths"][e])
         assert (it["V"], it["K"]) == (int(g["it_V"][e]), int(g["it_K"][e]))
         assert rel(it["H"], g["it_H"][e]) < 1e-4 and rel(it["b"][mask], g["it_b"][e][mask]) < 1e-4
+        assert abs(it["loss"] - float(g["it_loss"][e])) <= 1e-5 * abs(float(g["it_loss"][e])), (e, it["loss"], float(g["it_loss"][e]))
         # dx = inverse(H) b: the reference inverts in float32 (optimizer.py:186; cond(H) ~ 1e3 => ~1e-4 of |H^-1| |b| is its own round-off)
         hinv = np.abs(np.linalg.inv(g["it_H"][e].astype(np.float64)))
         tol_b = np.full(71, 1e-4 * np.abs(g["it_b"][e]).max())

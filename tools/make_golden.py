@@ -46,15 +46,16 @@ def make_cfg(deepsdf_dir, joint, data_type="KITTI", code_len=64):
 class Recorder(object):
     """Wraps reference-module names + torch.inverse/mv to record one GN trace."""
 
-    def __init__(self, ropt, rloss, th):
+    def __init__(self, ropt, rloss, th, k1=None, k2=None):
         self.ropt, self.rloss, self.th = ropt, rloss, th
+        self.k1, self.k2 = k1, k2          # with both given, `loss = k1 * render_loss + k2 * sdf_loss` (optimizer.py:155) is recorded per iteration
         self.iters = []
         self.cur = None
 
     def __enter__(self):
         ro, rl = self.ropt, self.rloss
         self.saved = dict(sdf=ro.compute_sdf_loss, rend=ro.compute_render_loss, rot=ro.compute_rotation_loss_sim3,
-                          exp=ro.exp_sim3, dec=rl.decode_sdf, inv=torch.inverse, mv=torch.mv, lin=torch.linspace)
+                          exp=ro.exp_sim3, dec=rl.decode_sdf, inv=torch.inverse, mv=torch.mv, lin=torch.linspace, rob=ro.get_robust_res)
         rec = self
         rec.pending_depths = None
 
@@ -85,6 +86,17 @@ class Recorder(object):
             rec.cur["K"] = -1 if out is None else int(out[0].shape[0])
             return out
 
+        def w_rob(res, b_):           # optimizer.py:133 (surface term, first call of an iteration) and :147 (render term, second call)
+            out = rec.saved["rob"](res, b_)
+            if rec.cur is not None:
+                if "loss_sdf" not in rec.cur:
+                    rec.cur["loss_sdf"] = out[1].clone()
+                elif "loss_render" not in rec.cur:
+                    rec.cur["loss_render"] = out[1].clone()
+                    if rec.k1 is not None:      # the reference's own expression on the reference's own operands (optimizer.py:155)
+                        rec.cur["loss"] = np.float32(float(rec.k1 * rec.cur["loss_render"] + rec.k2 * rec.cur["loss_sdf"]))
+            return out
+
         def w_inv(x):
             out = rec.saved["inv"](x)
             if rec.cur is not None and x.shape[0] > 8:
@@ -99,6 +111,7 @@ class Recorder(object):
             return out
 
         ro.compute_sdf_loss, ro.compute_render_loss, rl.decode_sdf = w_sdf, w_rend, w_dec
+        ro.get_robust_res = w_rob
         torch.inverse, torch.mv, torch.linspace = w_inv, w_mv, w_lin
         return self
 
@@ -106,6 +119,7 @@ class Recorder(object):
         ro, rl = self.ropt, self.rloss
         ro.compute_sdf_loss, ro.compute_render_loss = self.saved["sdf"], self.saved["rend"]
         rl.decode_sdf = self.saved["dec"]
+        ro.get_robust_res = self.saved["rob"]
         torch.inverse, torch.mv, torch.linspace = self.saved["inv"], self.saved["mv"], self.saved["lin"]
 
     def pack(self, prefix=""):
@@ -115,6 +129,10 @@ class Recorder(object):
         for k in keys:
             if full:
                 out[prefix + "it_" + k] = np.stack([it[k] for it in full]).astype(np.float32)
+        if full and all("loss" in it for it in full):
+            out[prefix + "it_loss"] = np.array([it["loss"] for it in full], np.float32)
+            out[prefix + "it_loss_sdf"] = np.array([float(it["loss_sdf"]) for it in full], np.float32)
+            out[prefix + "it_loss_render"] = np.array([float(it["loss_render"]) for it in full], np.float32)
         out[prefix + "it_V"] = np.array([it.get("V", -1) for it in self.iters], np.int64)
         out[prefix + "it_m"] = np.array([it.get("m", -1) for it in self.iters], np.int64)
         out[prefix + "it_K"] = np.array([it.get("K", -1) for it in self.iters], np.int64)
@@ -127,7 +145,8 @@ def run_recon(Optimizer, ropt, rloss, decoder, cfg_dict, obj, code=None, get_con
     cfg = get_configs(f.name)
     os.unlink(f.name)
     opt = Optimizer(decoder, cfg)
-    with Recorder(ropt, rloss, cfg_dict["optimizer"]["cut_off_threshold"]) as rec:
+    j = cfg_dict["optimizer"]["joint_optim"]
+    with Recorder(ropt, rloss, cfg_dict["optimizer"]["cut_off_threshold"], j["k1"], j["k2"]) as rec:
         rst = opt.reconstruct_object(obj["t_cam_obj_init"].copy(), obj["pts"].copy(), obj["rays"].copy(),
                                      obj["depth"].copy(), None if code is None else code.copy())
     out = rec.pack()
@@ -144,6 +163,8 @@ def run_recon(Optimizer, ropt, rloss, decoder, cfg_dict, obj, code=None, get_con
             out["ulp_code"] = np.asarray(rst2.code, np.float32)
     out["is_good"] = np.array(bool(rst.is_good))
     out["loss"] = np.array(float(rst.loss), np.float32)
+    if rst.is_good and "it_loss" in out:      # the returned loss IS the last iteration's (optimizer.py:155,200-203)
+        assert out["it_loss"][-1] == out["loss"], (out["it_loss"][-1], out["loss"])
     if rst.is_good:
         out["t_cam_obj"] = np.asarray(rst.t_cam_obj, np.float32)
         out["code"] = np.asarray(rst.code, np.float32)
