@@ -1,9 +1,57 @@
-"""Config / decoder plumbing -- mirror of reference reconstruct/utils.py:82-116 (the parts on the hot path)."""
+"""Config / decoder plumbing -- mirror of reference reconstruct/utils.py:58-163: everything the hot path and the reference's sequence loaders
+import from it (the loaders themselves stay the reference's files, see reconstruct/__init__.py).  The two viewer helpers of the reference's
+module (`color_table`, `set_view`: Open3D camera set-up for reconstruct_frame.py / visualize_map.py) are not restated: asking this module for
+them loads the reference's own utils.py under a private name and hands its object through (module __getattr__ below)."""
 import json
 
 import numpy as np
 
 from deep_sdf.workspace import config_decoder
+
+
+def read_calib_file(filepath):
+    """KITTI calibration file -> {key: float64 array} (reference utils.py:58-73, imported by kitti_sequence.py:23): `key: v0 v1 ...` per line,
+    parsing stops at the first empty line, lines whose values are not all numbers (the date stamps) are skipped."""
+    out = {}
+    with open(filepath, "r") as f:
+        for line in f:
+            if line == "\n":
+                break
+            key, value = line.split(":", 1)
+            try:
+                out[key] = np.array([float(tok) for tok in value.split()])
+            except ValueError:
+                continue
+    return out
+
+
+def load_velo_scan(file):
+    """Velodyne .bin -> (N, 4) float32 [x, y, z, reflectance] (reference utils.py:76-79, imported by kitti_sequence.py:23)."""
+    return np.fromfile(file, dtype=np.float32).reshape((-1, 4))
+
+
+_reference_utils = None
+
+
+def __getattr__(name):
+    """Names of the reference's reconstruct/utils.py that this module does not restate (color_table, set_view): taken from the reference's
+    own file, loaded once under a private module name (it needs the reference's environment: addict, plyfile, scikit-image)."""
+    global _reference_utils
+    if name.startswith("__") or name not in ("color_table", "set_view"):
+        raise AttributeError("module 'reconstruct.utils' has no attribute %r" % name)
+    if _reference_utils is None:
+        import importlib.util
+        import os
+        from reconstruct import reference_package_dir
+        d = reference_package_dir()
+        if d is None:
+            raise AttributeError("reconstruct.utils.%s lives in the reference's utils.py and no reference checkout was found "
+                                 "(run from the DSP-SLAM source directory or set DSP_REFERENCE_ROOT)" % name)
+        spec = importlib.util.spec_from_file_location("_dsp_reference_reconstruct_utils", os.path.join(d, "utils.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        _reference_utils = mod
+    return getattr(_reference_utils, name)
 
 
 class ForceKeyErrorDict(dict):

@@ -7,6 +7,9 @@
 //               src/LocalMapping_util.cc:179-191 (reconstruct_object -> is_good / t_cam_obj / code),
 //               src/LocalMapping_util.cc:391-413 (5-argument form with a warm-start code, loss, code_len),
 //               src/LocalMapping_util.cc:194-196,426-428 (extract_mesh_from_code -> vertices MatrixXf / faces MatrixXi).
+// With an argument "seq=<dir>": the call that follows get_decoder in the System constructor, src/System.cc:98 --
+// `py::module::import("reconstruct").attr("get_sequence")(strSequencePath, pyCfg)` -- whose classes are the REFERENCE'S files, reached through
+// the mirror package's __path__ (dsp_slam_amd/reconstruct/__init__.py); prints the class and the file it came from.
 // With a 4th argument "mono": the MONOCULAR sequence of src/LocalMapping_util.cc:391-428 instead -- 5-argument call with the map object's
 // 64-float vShapeCode, the 180-degree-yaw-flipped second call for an object that is not reconstructed yet, the `loss` comparison that
 // picks one of the two, t_cam_obj -> Matrix4f, code_len read as int, the code cast to a FIXED-SIZE Vector<float,32> when code_len == 32
@@ -41,17 +44,31 @@ struct PyThreadStateLock {   // reference include/System.h:56-70
 };
 
 int main(int argc, char** argv) {
-    if (argc < 4) { std::fprintf(stderr, "usage: embed_harness <mirror_dir> <cfg.json> <inputs.npz>\n"); return 2; }
+    if (argc < 4) { std::fprintf(stderr, "usage: embed_harness <mirror_dir> <cfg.json> <inputs.npz> [mono] [seq=<sequence dir>]\n"); return 2; }
     const std::string mirror = argv[1], cfg_file = argv[2], npz = argv[3];
-    const bool mono = argc > 4 && std::string(argv[4]) == "mono";
+    bool mono = false;
+    std::string seq_dir;
+    for (int i = 4; i < argc; ++i) {
+        const std::string a = argv[i];
+        if (a == "mono") mono = true;
+        else if (a.rfind("seq=", 0) == 0) seq_dir = a.substr(4);
+    }
     std::setvbuf(stdout, nullptr, _IOLBF, 1 << 16);                            // whole lines, so that Python's own prints cannot land inside one
     py::initialize_interpreter();                                              // System.cc:90
     py::object pyCfg, pyDecoder;
     {
-        py::module::import("sys").attr("path").attr("insert")(0, mirror);      // System.cc:92 appends "./"; the mirror goes first
+        py::module sys = py::module::import("sys");                           // System.cc:92
+        sys.attr("path").attr("insert")(0, mirror);                            // the one change: the mirror goes first (or PYTHONPATH)
+        sys.attr("path").attr("append")("./");                                 // System.cc:93
         py::module io_utils = py::module::import("reconstruct.utils");         // System.cc:94
         pyCfg = io_utils.attr("get_configs")(cfg_file);                        // System.cc:96
         pyDecoder = io_utils.attr("get_decoder")(pyCfg);                       // System.cc:97
+        if (!seq_dir.empty()) {
+            py::object pySequence = py::module::import("reconstruct").attr("get_sequence")(seq_dir, pyCfg);      // System.cc:98
+            const std::string cls = py::str(py::type::of(pySequence).attr("__name__"));
+            const std::string file = py::str(py::module::import("sys").attr("modules")[py::type::of(pySequence).attr("__module__")].attr("__file__"));
+            std::printf("sequence %s %s\n", cls.c_str(), file.c_str());
+        }
     }
     PyThreadState* main_state = PyEval_SaveThread();                           // System.cc:152: GIL released by the main thread
 

@@ -33,15 +33,26 @@ def test_cpp_embed_call_surface(tmp_path):
     cfg = json.load(open(os.path.join(ROOT, "tests", "golden", "config_kitti_optimizer.json")))
     cfg["DeepSDF_DIR"] = ddir
     cfg["voxels_dim"] = 16
+    # System.cc:98 -- reconstruct.get_sequence right after get_decoder -- from a working directory that is a DSP-SLAM checkout (a stand-in one: the
+    # reference is not on the GPU box; tests/test_dropin_delegation.py runs the same call against the real reference on the CPU tier)
+    import test_dropin_delegation as D
+    checkout, seq_dir = str(tmp_path / "dsp_slam_src"), str(tmp_path / "kitti07")
+    D.write_standin_checkout(checkout)
+    os.makedirs(seq_dir)
+    D.write_kitti_dir(seq_dir)
+    cfg.update(data_type="KITTI", detect_online=False, path_label_2d="labels/2d", path_label_3d="labels/3d")
     (tmp_path / "cfg.json").write_text(json.dumps(cfg))
     g = golden("golden_recon_small.npz")
     gp = golden("golden_pose_only.npz")
     np.savez(tmp_path / "in.npz", t_cam_obj=g["in_t_cam_obj_init"], pts=g["in_pts"], rays=g["in_rays"], depth=g["in_depth"],
              pose_t_co_se3=gp["t_co_se3"], pose_scale=gp["scale"], pose_pts=gp["pts"], pose_code=gp["code"])
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), PYTHONUNBUFFERED="1")
-    out = subprocess.run([HARNESS, os.path.join(ROOT, "dsp_slam_amd"), str(tmp_path / "cfg.json"), str(tmp_path / "in.npz")],
-                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
+    env.pop("DSP_REFERENCE_ROOT", None)
+    out = subprocess.run([HARNESS, os.path.join(ROOT, "dsp_slam_amd"), str(tmp_path / "cfg.json"), str(tmp_path / "in.npz"), "seq=" + seq_dir],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600, cwd=checkout)
     assert out.returncode == 0, out.stderr[-2000:]
+    seq_line = [ln.split() for ln in out.stdout.splitlines() if ln.startswith("sequence ")]
+    assert seq_line and seq_line[0][1] == "KITIISequence" and os.path.realpath(seq_line[0][2]).startswith(os.path.realpath(checkout)), seq_line
     res = {}
     keys = ("mesh_shape", "mesh_vertices", "mesh_faces", "is_good", "keyerror", "code_len", "grid_size", "pose_only", "t_cam_obj", "t_cam_obj2", "code", "loss2")
     for line in out.stdout.splitlines():
