@@ -21,6 +21,10 @@ GRAD_DIM = 67
 OBJ_GOOD, OBJ_FEW_SAMPLES, OBJ_NAN = 0, 1, 2
 PREPASS_OFF, PREPASS_F16, PREPASS_BF16 = 0, 1, 2
 PREPASS_SMALL_TILES = 0x100
+# keys of dsp_batch_set_debug (include/dsp_gn.h: DSP_DBG_*)
+(DBG_MASK_REUSE, DBG_SPLIT_ROWS, DBG_TAIL_SPLIT, DBG_WAVE_BOOKKEEPING, DBG_SPECULATIVE_BAND, DBG_MIXED_REUSE, DBG_CLUSTER_TILES, DBG_DIRECT_TILES,
+ DBG_PREPASS_TILE, DBG_PREPASS_AUDIT, DBG_CLUSTER_FAULT) = range(1, 12)
+ABI_VERSION = 6
 
 
 class DecoderDesc(C.Structure):
@@ -44,7 +48,7 @@ class Stats(C.Structure):
                 ("prepass_mode", C.c_int32), ("prepass_delta", C.c_float), ("prepass_max_err", C.c_float),
                 ("prepass_misclassified", C.c_double), ("prepass_audited", C.c_double),
                 ("prepass_guard_trips", C.c_double), ("prepass_guard_objects", C.c_double), ("prepass_guard_max_err", C.c_float),
-                ("prepass_guard_rerun", C.c_int32), ("n_cluster_tiles", C.c_double), ("cluster_fallback", C.c_int32), ("reserved0", C.c_int32)]
+                ("prepass_guard_rerun", C.c_int32), ("n_cluster_tiles", C.c_double), ("cluster_fallback", C.c_int32), ("cluster_cooldown", C.c_int32)]
 
 
 class DspError(RuntimeError):
@@ -80,27 +84,18 @@ SYMBOLS = [
     ("dsp_batch_results", C.c_int, [_VP, c_f32p, c_f32p, c_f32p, c_i32p]),
     ("dsp_batch_stats", C.c_int, [_VP, C.POINTER(Stats)]),
     ("dsp_batch_set_ray_passes", C.c_int, [_VP, C.c_int]),
-    ("dsp_batch_set_ray_pass_bounds", C.c_int, [_VP, c_i32p, C.c_int]),
-    ("dsp_batch_set_mask_reuse", C.c_int, [_VP, C.c_int]),
-    ("dsp_batch_set_fused_bookkeeping", C.c_int, [_VP, C.c_int]),
-    ("dsp_batch_set_tail_split", C.c_int, [_VP, C.c_int]),
-    ("dsp_batch_set_speculative_band", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_set_prepass", C.c_int, [_VP, C.c_int, C.c_float]),
+    ("dsp_batch_set_prepass_guard", C.c_int, [_VP, C.c_int]),
+    ("dsp_batch_set_kernel_timing", C.c_int, [_VP, C.c_int]),
+    ("dsp_batch_set_iterations", C.c_int, [_VP, C.c_int32]),
+    ("dsp_batch_set_debug", C.c_int, [_VP, C.c_int, C.c_int]),
     ("dsp_prepass_calibration", C.c_int, [_VP, C.c_int, c_f32p, c_f32p]),
     ("dsp_prepass_calibration_table", C.c_int, [_VP, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p]),
-    ("dsp_batch_set_prepass_audit", C.c_int, [_VP, C.c_int]),
-    ("dsp_batch_set_prepass_tile", C.c_int, [_VP, C.c_int]),
-    ("dsp_batch_set_prepass_guard", C.c_int, [_VP, C.c_int]),
-    ("dsp_batch_set_start_state", C.c_int, [_VP, c_f32p, c_f32p, c_f32p]),
-    ("dsp_batch_set_iterations", C.c_int, [_VP, C.c_int32]),
-    ("dsp_batch_set_depth_schedule", C.c_int, [_VP, c_f32p, C.c_int32]),
+    ("dsp_batch_debug_ray_pass_bounds", C.c_int, [_VP, c_i32p, C.c_int]),
+    ("dsp_batch_debug_start_state", C.c_int, [_VP, c_f32p, c_f32p, c_f32p]),
+    ("dsp_batch_debug_depth_schedule", C.c_int, [_VP, c_f32p, C.c_int32]),
     ("dsp_batch_debug_samples", C.c_int, [_VP, C.c_int32, C.POINTER(C.c_uint64), c_f32p, c_f32p, C.c_int64]),
-    ("dsp_batch_set_split_rows", C.c_int, [_VP, C.c_int]),
-    ("dsp_batch_set_solver", C.c_int, [_VP, C.c_int]),
-    ("dsp_batch_set_direct_tiles", C.c_int, [_VP, C.c_int]),
-    ("dsp_batch_set_cluster_tiles", C.c_int, [_VP, C.c_int]),
-    ("dsp_batch_set_mixed_reuse", C.c_int, [_VP, C.c_int]),
-    ("dsp_batch_set_kernel_timing", C.c_int, [_VP, C.c_int]),
+    ("dsp_debug_fail_alloc", C.c_int, [_VP, C.c_int]),
     ("dsp_prepass_reset_guard", C.c_int, [_VP]),
     ("dsp_trim", C.c_int, [_VP]),
     ("dsp_set_stream_priority", C.c_int, [_VP, C.c_int]),

@@ -269,16 +269,8 @@ void launch_build_tiles(const ObjConst* oc, ObjState* st, int B, int mode, int4*
 void launch_tail_tiles(const int4* tiles, int* n_tiles, int4* tiles16, int* n_tiles16, int n_cu, hipStream_t s);   // see k_tail_tiles
 void launch_band_select(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff, const float* ssdf, float th,
                         unsigned guard_salt, int* pcnt, int* poff, int* plist, int maxR, int B, hipStream_t s);
-// fused per-object forms (latency path): front = sample_count + scan + sample_write + surface; band = count + scan + write;
-// render tail = scan + sum_m + render_write (behind k_render_scan, one wave per ray over the whole chip)
-void launch_front_fused(const ObjConst* oc, ObjState* st, const float* rays, const float* pts, unsigned long long* raymask, int* raycnt, int* rayoff,
-                        float4* spts, float* ssdf, unsigned char* alive, float4* jpts, float2* jaux, int D, int B, hipStream_t s);
-void launch_band_fused(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff, const float* ssdf, float th, unsigned guard_salt,
-                       int* pcnt, int* poff, int* plist, const float4* spts, float4* jpts, int* srow, int B, hipStream_t s);   // jpts / srow: speculative band rows (or null)
-void launch_render_tail_fused(const ObjConst* oc, ObjState* st, const int* raycnt, const int* rayoff, const float4* spts, const float* sdeds,
-                              const float* ray_res, const int* kcnt, int* koff, const int* mcnt, float4* jpts, float2* jaux, const int* srow, int* jrow,
-                              int B, hipStream_t s);
-// wave-per-ray forms of the three fused stages (one wave per ray, 16 rays per workgroup, whole chip): list segments from running counters
+// wave-per-ray forms (latency path; one wave per ray, 16 rays per workgroup, whole chip) of front = sample_count + scan + sample_write +
+// surface, band = count + scan + write, render tail = scan + sum_m + render_write (behind k_render_scan): list segments from running counters
 // (ObjState::V / ::P) instead of scans; kept rows stay in ray-major order.  See gn_kernels.hip.
 void launch_front_wave(const ObjConst* oc, ObjState* st, const float* rays, const float* pts, unsigned long long* raymask, int* raycnt, int* rayoff,
                        float4* spts, float* ssdf, unsigned char* alive, float4* jpts, float2* jaux, int D, int maxR, int maxM, int B, hipStream_t s);
@@ -312,8 +304,8 @@ void launch_gram(const ObjConst* oc, const ObjState* st, const float4* jpts, con
 void launch_jrows(const ObjConst* oc, const ObjState* st, const float4* jpts, const float2* jaux, const float* jgrad, const int* jrow, int term, float* rows,
                   int cap, hipStream_t s);   // jrow (optional): render row i takes its gradient from jgrad row jrow[i]
 void launch_solve(const ObjConst* oc, ObjState* st, const float* partials, double* gsum, int n_slices, const GnParamsDev& prm, int iter,
-                  float* trace, const float* codew, const float* b0, const float* blat, float* cbias, const float* depths_next, int B, hipStream_t s,
-                  int solver = 0);   // cbias: next iteration's code bias; depths_next: optional B x 64 override of the next iteration's depth samples; solver: 0 LDL^T, 1 Gauss-Jordan (A/B)
+                  float* trace, const float* codew, const float* b0, const float* blat, float* cbias, const float* depths_next, int B,
+                  hipStream_t s);    // cbias: next iteration's code bias; depths_next: optional B x 64 override of the next iteration's depth samples
 void launch_inlier_filter(const ObjConst* oc, ObjState* st, const float* jgrad, unsigned char* alive, int maxM, int B, hipStream_t s);
 constexpr int DSP_RESULT_WIDTH_DEV = 82;   // == DSP_RESULT_WIDTH (dsp_gn.h): t_cam_obj 16 | code 64 | loss | status
 void launch_finalize(ObjState* st, const float* scale, int B, int pose_only, float* packed, unsigned* guard_out /*optional B x 3*/, hipStream_t s);

@@ -398,11 +398,7 @@ __global__ void k_pass_update(const ObjConst* oc, const ObjState* st, const unsi
 // can misclassify, and a gross failure hits many samples).  Together with the band itself, where EVERY sample is compared, that is
 // ~0.3 % of the in-sphere samples on the bench workload.  The id hash is xor-ed with a per-launch salt; salt == 0: no guard samples.
 __device__ __forceinline__ bool guard_pick(unsigned id, unsigned salt, bool ring) {
-#if defined(GUARD_UNIFORM_64)      // A/B aid: the round-3 first form, a uniform 1/64 sample
-    return salt != 0u && ((id_hash(id) ^ salt) & 63u) == 0u;
-#else
     return salt != 0u && ((id_hash(id) ^ salt) & (ring ? 7u : 511u)) == 0u;
-#endif
 }
 
 __device__ __forceinline__ void band_count_ray(const ObjConst& c, const ObjState& s, const unsigned long long* raymask, const int* rayoff,
@@ -740,182 +736,16 @@ __global__ __launch_bounds__(256) void k_render_write(const ObjConst* oc, const 
 }
 
 // ------------------------------------------------------------------------------------------------
-// fused per-object forms of the bookkeeping above (latency path): one workgroup per object runs the per-ray bodies, the scan
-// and the compaction back to back -- the same device functions, so the same bits -- instead of three or four launches.
-// ------------------------------------------------------------------------------------------------
-constexpr int FUSED_THREADS = 1024;
-
-// k_sample_count + k_scan_rays(0) + k_sample_write (+ k_surface)
-// One wave per ray, lane = depth index.  Everything a ray needs besides its direction is loaded once (this lane's depth sample, the
-// pose), and the next ray's direction / mask / offset are fetched before the current ray is processed, so no iteration waits for memory.
-__global__ __launch_bounds__(FUSED_THREADS) void k_front_fused(const ObjConst* oc, ObjState* st, const float* __restrict__ rays, const float* pts,
-                                                               unsigned long long* raymask, int* raycnt, int* rayoff, float4* spts, float* ssdf,
-                                                               unsigned char* alive, float4* jpts, float2* jaux, int n_depth) {
-    __shared__ int part[FUSED_THREADS];
-    const int b = blockIdx.x;
-    const ObjConst c = oc[b];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int NW = FUSED_THREADS / 64;
-    const bool good0 = st[b].status == DSP_STATUS_GOOD;
-    float T[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) T[i] = st[b].t_oc[i];
-    const float dj = st[b].depths[lane < n_depth ? lane : 0];
-    const float* rbase = rays + 3 * (size_t)c.ray_off;
-    unsigned hsum = 0;
-    {
-        float nx = 0.f, ny = 0.f, nz = 0.f;
-        if (wave < c.n_rays) { nx = rbase[3 * wave]; ny = rbase[3 * wave + 1]; nz = rbase[3 * wave + 2]; }
-        for (int r = wave; r < c.n_rays; r += NW) {
-            const float dx = nx, dy = ny, dz = nz;
-            if (r + NW < c.n_rays) { nx = rbase[3 * (r + NW)]; ny = rbase[3 * (r + NW) + 1]; nz = rbase[3 * (r + NW) + 2]; }
-            bool in = false;
-            if (good0 && lane < n_depth) {
-                const float3 p = xform(T, __fmul_rn(dx, dj), __fmul_rn(dy, dj), __fmul_rn(dz, dj));
-                const float n2 = __fadd_rn(__fadd_rn(__fmul_rn(p.x, p.x), __fmul_rn(p.y, p.y)), __fmul_rn(p.z, p.z));
-                in = __fsqrt_rn(n2) < 1.0f;
-            }
-            const unsigned long long mask = __ballot(in);
-            if (in) hsum += id_hash(((unsigned)r << 6) | (unsigned)lane);
-            if (lane == 0) { raymask[c.ray_off + r] = mask; raycnt[c.ray_off + r] = __popcll(mask); }
-        }
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) hsum += __shfl_xor(hsum, d);
-    if (lane == 0 && hsum) atomicAdd(&st[b].vsum, hsum);
-    __syncthreads();
-    scan_rays_block<FUSED_THREADS>(c, st, b, raycnt, rayoff, 0, part);
-    __syncthreads();
-    if (st[b].status == DSP_STATUS_GOOD) {
-        float nx = 0.f, ny = 0.f, nz = 0.f;
-        unsigned long long nmask = 0ull;
-        int noff = 0;
-        if (wave < c.n_rays) {
-            nx = rbase[3 * wave]; ny = rbase[3 * wave + 1]; nz = rbase[3 * wave + 2];
-            nmask = raymask[c.ray_off + wave]; noff = rayoff[c.ray_off + wave];
-        }
-        for (int r = wave; r < c.n_rays; r += NW) {
-            const float dx = nx, dy = ny, dz = nz;
-            const unsigned long long mask = nmask;
-            const int dst = c.samp_off + noff;
-            if (r + NW < c.n_rays) {
-                nx = rbase[3 * (r + NW)]; ny = rbase[3 * (r + NW) + 1]; nz = rbase[3 * (r + NW) + 2];
-                nmask = raymask[c.ray_off + r + NW]; noff = rayoff[c.ray_off + r + NW];
-            }
-            if (lane == 0) alive[c.ray_off + r] = mask ? 1 : 0;
-            if ((mask >> lane) & 1ull) {
-                const float3 p = xform(T, __fmul_rn(dx, dj), __fmul_rn(dy, dj), __fmul_rn(dz, dj));
-                const int k = __popcll(mask & ((1ull << lane) - 1ull));
-                spts[dst + k] = make_float4(p.x, p.y, p.z, __int_as_float((r << 6) | lane));
-                ssdf[dst + k] = 1.0f;   // "not evaluated": free space (see sample_write_ray)
-            }
-        }
-    }
-    for (int i = threadIdx.x; i < c.n_pts; i += FUSED_THREADS) surface_point(c, st[b], pts, jpts, jaux, i);
-}
-
-// k_band_count + k_scan_rays(2) + k_band_write: one THREAD per ray, the ray's <= 64 sample values as independent loads (the
-// front-to-back walk of band_count_ray becomes mask arithmetic: first certainly-solid sample = lowest set bit)
-__device__ __forceinline__ unsigned long long band_select_thread(const ObjConst& c, const unsigned long long* raymask, const int* rayoff,
-                                                                 const float* ssdf, float thd, float delta, unsigned salt, int r, int& base) {
-    const int gr = c.ray_off + r;
-    const unsigned long long rmask = raymask[gr];
-    const int cnt = __popcll(rmask);
-    base = c.samp_off + rayoff[gr];
-    unsigned long long solid = 0ull, band = 0ull, decoded = 0ull, ring = 0ull;
-#pragma unroll
-    for (int k = 0; k < 64; ++k) {
-        const float v = ssdf[k < cnt ? base + k : c.samp_off];
-        if (k < cnt && v <= -thd) solid |= 1ull << k;
-        if (k < cnt && !(fabsf(v) >= thd)) band |= 1ull << k;      // NaN -> band
-        if (k < cnt && v != 1.0f) decoded |= 1ull << k;
-        if (k < cnt && fabsf(v) < thd + delta) ring |= 1ull << k;
-    }
-    const int first = solid ? __ffsll((long long)solid) - 1 : 64;     // samples behind the first certainly-solid one are skipped
-    if (salt) {       // guard samples (band_count_ray): classified samples up to and including the first certainly-solid one
-        unsigned long long m = rmask, pick = 0ull;
-        for (int k = 0; m; ++k) {
-            const int j = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            if (guard_pick(((unsigned)r << 6) | (unsigned)j, salt, (ring >> k) & 1ull)) pick |= 1ull << k;
-        }
-        band |= pick & decoded;
-        return first >= 63 ? band : band & ((2ull << first) - 1ull);
-    }
-    return first >= 64 ? band : band & ((1ull << first) - 1ull);
-}
-
-__global__ __launch_bounds__(FUSED_THREADS) void k_band_fused(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff,
-                                                              const float* ssdf, float th, unsigned salt, int* pcnt, int* poff, int* plist, const float4* spts,
-                                                              float4* jpts, int* srow) {
-    __shared__ int part[FUSED_THREADS];
-    const int b = blockIdx.x;
-    const ObjConst c = oc[b];
-    const bool good = st[b].status == DSP_STATUS_GOOD;
-    const float thd = th + st[b].lp_delta;
-    int base;
-    for (int r = threadIdx.x; r < c.n_rays; r += FUSED_THREADS) pcnt[c.ray_off + r] = good ? __popcll(band_select_thread(c, raymask, rayoff, ssdf, thd, st[b].lp_delta, salt, r, base)) : 0;
-    __syncthreads();
-    scan_rays_block<FUSED_THREADS>(c, st, b, pcnt, poff, 2, part);
-    __syncthreads();
-    if (good) {
-        for (int r = threadIdx.x; r < c.n_rays; r += FUSED_THREADS) {
-            unsigned long long sel = band_select_thread(c, raymask, rayoff, ssdf, thd, st[b].lp_delta, salt, r, base);
-            int pos = poff[c.ray_off + r];
-            while (sel) {
-                const int idx = base + __ffsll((long long)sel) - 1;
-                sel &= sel - 1;
-                plist[c.samp_off + pos] = idx;
-                if (jpts) {   // speculative band rows: the sample goes straight into the jacobian launch (forward + backward), row jren_off + pos
-                    float4 p = spts[idx];
-                    p.w = __int_as_float(idx);
-                    jpts[c.jren_off + pos] = p;
-                    srow[idx] = c.jren_off + pos;
-                }
-                ++pos;
-            }
-        }
-    }
-}
-
-// k_render_scan + k_scan_rays(1) + k_sum_m + k_render_write
-// k_scan_rays(1) + k_sum_m + k_render_write, behind k_render_scan (which spreads the rays over the whole chip, one wave each)
-__global__ __launch_bounds__(FUSED_THREADS) void k_render_tail_fused(const ObjConst* oc, ObjState* st, const int* raycnt, const int* rayoff,
-                                                                     const float4* spts, const float* sdeds, const float* ray_res,
-                                                                     const int* kcnt, int* koff, const int* mcnt, float4* jpts, float2* jaux,
-                                                                     const int* srow, int* jrow) {
-    __shared__ int part[FUSED_THREADS];
-    const int b = blockIdx.x;
-    const ObjConst c = oc[b];
-    scan_rays_block<FUSED_THREADS>(c, st, b, kcnt, koff, 1, part);
-    __syncthreads();
-    {   // k_sum_m
-        int sum = 0;
-        for (int r = threadIdx.x; r < c.n_rays; r += FUSED_THREADS) sum += mcnt[c.ray_off + r];
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
-        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int tot = 0;
-            for (int w = 0; w < FUSED_THREADS / 64; ++w) tot += part[w];
-            st[b].m = tot;
-        }
-    }
-    for (int r = threadIdx.x; r < c.n_rays; r += FUSED_THREADS) render_write_ray(c, st[b], raycnt, rayoff, koff, spts, sdeds, ray_res, jpts, jaux, r, srow, jrow);
-}
-
-// ------------------------------------------------------------------------------------------------
-// wave-per-ray forms of the same three stages (latency path, round 4): the fused kernels above give an object ONE workgroup, i.e. one
-// CU, and a detection's 450 rays x 50 samples then cost 27 + 41 + 22 us per iteration on it.  Here a ray is a wave (lane = depth index,
-// as in k_render_scan), 16 rays a workgroup, and the rays of an object spread over as many CUs as they fill.  What made the fused
-// form need one workgroup per object was the scan over the rays; two of the three scans are not needed at all:
+// wave-per-ray forms of the same three stages (latency path): sampling + compaction (+ surface points), band selection, row compaction, one
+// launch each.  A ray is a wave (lane = depth index, as in k_render_scan), 16 rays a workgroup, and the rays of an object spread over as many
+// CUs as they fill (a per-object fused form -- one workgroup per object -- cost a detection 27 + 41 + 22 us per iteration on ONE CU:
+// profiles/r06_removed_experiments.md).  Two of the throughput form's three scans over the rays are not needed at all:
 //   * the in-sphere sample list and the band / speculative-row list are INTERNAL orders -- every consumer goes through rayoff / plist /
 //     srow / jrow, each point's decoder result is independent of the tile it shares (test_decode_is_tile_independent), and the Gram
 //     kernel walks the kept rows in koff order -- so their segments are handed out by one atomicAdd per workgroup (ObjState::V / ::P);
 //   * the kept-row order IS the Gram summation order, so k_render_tail_wave keeps it: every workgroup sums the counts of the rays in
 //     front of its own (<= 2500 integers) instead of waiting for a scan launch.
-// Same per-sample arithmetic, same sets, same H / b / dx bits as the fused and the throughput forms (test_wave_bookkeeping_is_exact).
+// Same per-sample arithmetic, same sets, same H / b / dx bits as the throughput form (test_wave_bookkeeping_is_exact).
 // ------------------------------------------------------------------------------------------------
 constexpr int WAVE_RAYS = 16;            // rays (= waves) per workgroup of k_front_wave / k_band_wave
 constexpr int WAVE_THREADS = 64 * WAVE_RAYS;
@@ -991,7 +821,7 @@ __global__ __launch_bounds__(WAVE_THREADS) void k_front_wave(const ObjConst* oc,
     }
 }
 
-// k_band_count + k_band_write (+ the speculative band rows of k_band_fused): the selection of band_select_thread with lane = depth
+// k_band_count + k_band_write (+ the speculative band rows): the selection of band_count_ray / band_write_ray with lane = depth
 // index; list slots from the running counter ObjState::P (zero at the start of an iteration)
 __global__ __launch_bounds__(WAVE_THREADS) void k_band_wave(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff,
                                                             const float* ssdf, float th, unsigned salt, int* plist, const float4* spts, float4* jpts,
@@ -1385,12 +1215,6 @@ __device__ void rotation_prior(const float* t_co, float scale, float* jrot, floa
 constexpr int NSOLVE = 71;
 
 __device__ unsigned long long g_solve_clk[8];   // development aid: wall_clock64 (100 MHz) stamps of object 0's last k_solve
-#if defined(SOLVE_STAMPS)
-__device__ unsigned long long g_solve_clk2[40];
-#define SOLVE_STAMP2(i) do { if (b == 0 && lane == 0) g_solve_clk2[i] = clock64(); } while (0)
-#else
-#define SOLVE_STAMP2(i) do { } while (0)
-#endif
 
 // per-slice Gram partials -> one fp64 Gram matrix per (object, term); fixed summation order
 __global__ __launch_bounds__(256) void k_gram_reduce(const ObjState* st, const float* partials, int n_slices, double* gsum) {
@@ -1404,9 +1228,8 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const ObjState* st, const f
     gsum[((size_t)b * 2 + term) * (72 * 72) + e] = a;
 }
 
-constexpr int SOLVE_THREADS = 1024;   // 16 waves: assembly, trace and the code bias use all of them; the factorisation four (LDL^T) or all (Gauss-Jordan)
+constexpr int SOLVE_THREADS = 1024;   // 16 waves: assembly, trace and the code bias use all of them; the elimination nine
 constexpr int NS1 = NSOLVE + 1;       // rows of the augmented system: the unknowns + the right-hand side as row n
-constexpr int LDL_THREADS = 512, LDL_NP = NS1 * (NS1 + 1) / 2, LDL_EPT = (LDL_NP + LDL_THREADS - 1) / LDL_THREADS;   // 2628 packed elements, 6 per thread of eight waves
 
 // 1 / d to full double precision without the IEEE division sequence (it sits on the factorisation's critical path, once per pivot):
 // v_rcp_f64 (>= 25 bits) + two Newton steps
@@ -1417,16 +1240,14 @@ __device__ __forceinline__ double fast_recip(double d) {
     return r;
 }
 
-// SOLVER 3 (default): rows in lanes, eight columns per wave, one barrier per panel of eight pivots.  SOLVER 2: the same arithmetic with one barrier
-// per pivot (round 4).  SOLVER 0: LDL^T with the packed triangle in the registers of eight waves (first round-4 form).  SOLVER 1: the round-2/3
-// pivot-free Gauss-Jordan.  0-2 are kept as A/B references (dsp_batch_set_solver).
+// The 71 x 71 (pose-only: 6 x 6) normal equations in fp64, pivot-free: rows in lanes, eight columns per wave, one barrier per panel of eight
+// pivots.  (Earlier forms -- one barrier per pivot, packed LDL^T, Gauss-Jordan on 16 waves -- and their measurements: profiles/r06_removed_experiments.md.)
 template <bool V> struct BoolC { static constexpr bool value = V; };
 
-template <int SOLVER>
-__global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, ObjState* st, const double* gsum, const float* partials, int n_slices, GnParamsDev prm, int iter,
+__global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, ObjState* st, const double* gsum, GnParamsDev prm, int iter,
                                                          const float* codew, const float* cb0, const float* cblat, float* cbias,
                                                float* trace /*nullable*/, const float* depths_next /*nullable: forensics*/, int n_obj) {
-    __shared__ double A[NS1][NS1 + 1];          // [H | b] in rows 0..n-1 (b = column n); the LDL^T form also keeps b as ROW n
+    __shared__ double A[NS1][NS1 + 1];          // [H | b] in rows 0..n-1 (b = column n); b is also kept as ROW n (rows 64 .. 71 are one register of the elimination)
     const int b = blockIdx.x, tid = threadIdx.x;
     const bool stamp = (b == 0 && tid == 0);
     if (stamp) g_solve_clk[0] = wall_clock64();
@@ -1442,25 +1263,12 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
     // the pose and the code this iteration started from, parked in LDS for the update at the end (visible after the assembly's barrier)
     __shared__ float s_toc0[16], s_code0[CODE_LEN];
     const float park = tid < 16 ? s.t_oc[tid] : (tid >= 64 && tid < 64 + CODE_LEN) ? s.code[tid - 64] : 0.f;
-    // The 72 x 72 Gram matrices of the two terms, reduced over the Gram kernel's slices by k_gram_reduce.  (Round 5 tried summing the
-    // per-slice partials HERE -- same slice order, bit-identical, one launch and one kernel boundary less per iteration: 3.01 ms per
-    // detection against 2.94, because 786 KB of partials through ONE CU's load path take longer than the 41-workgroup reduce kernel and
-    // the boundary together.  -DSOLVE_FUSED_REDUCE rebuilds that form.)
-#if !defined(SOLVE_FUSED_REDUCE)
+    // The 72 x 72 Gram matrices of the two terms, reduced over the Gram kernel's slices by k_gram_reduce.  (Summing the per-slice partials HERE
+    // -- one launch and one kernel boundary less per iteration -- was measured and lost: 786 KB of partials through ONE CU's load path take longer
+    // than the 41-workgroup reduce kernel and the boundary together, profiles/r06_removed_experiments.md.)
     const double* G0p = gsum + ((size_t)b * 2 + 0) * (72 * 72);
     const double* G1p = gsum + ((size_t)b * 2 + 1) * (72 * 72);
     auto gram = [=](int term, int idx) -> double { return (term ? G1p : G0p)[idx]; };
-#else
-    const float* P0 = partials + (((size_t)b * 2 + 0) * n_slices) * (72 * 72);
-    const float* P1 = partials + (((size_t)b * 2 + 1) * n_slices) * (72 * 72);
-    auto gram = [=](int term, int idx) -> double {
-        const float* p = (term ? P1 : P0) + idx;
-        double a = 0.0;
-#pragma unroll 8
-        for (int sl = 0; sl < n_slices; ++sl) a += (double)p[(size_t)sl * 72 * 72];
-        return a;
-    };
-#endif
     const int M = c.n_pts;
     const int pd = prm.pose_only ? 6 : 7;
     const int n = prm.pose_only ? 6 : NSOLVE;
@@ -1553,30 +1361,22 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
         }
         __syncthreads();
     }
-    if constexpr (SOLVER != 1) {
-        // 2. H dx = b by LDL^T in fp64.  H = sum w J^T J + positive diagonal is symmetric (bit for bit: the Gram kernel's fmaf chains
-        //    commute) positive definite, so no pivoting is needed (the reference inverts H with fp32 LU, optimizer.py:186).  The
-        //    right-hand side rides along as row n of the augmented matrix [[H, b], [b^T, .]]: after the n elimination steps row n holds
-        //    z = L^-1 b, and dx follows from L^T dx = D^-1 z.
-        //    Right-looking, one step per pivot: a_ij -= c_ik c_jk / d_k with UNSCALED columns c_ik = l_ik d_k.  The lower triangle (2628
-        //    elements of the 72 x 72 augmented matrix, packed column-major) lives in the REGISTERS of eight waves, 6 elements per thread;
-        //    an element is final after step j - 1 and is published then, once, to its own LDS cell A[i][j] -- so step k reads column k
-        //    that step k - 1 wrote, writes column k + 1, and ONE barrier per step orders both.  The pivot's reciprocal is published by the
-        //    diagonal's owner with the column.  (profiles/r04_latency_kernel_stats.md for what it costs.)
+    {
+        // 2. H dx = b by elimination in fp64.  H = sum w J^T J + positive diagonal is symmetric (bit for bit: the Gram kernel's fmaf chains
+        //    commute) positive definite, so no pivoting is needed (the reference inverts H with fp32 LU, optimizer.py:186).  The right-hand side
+        //    rides along as column n (and row n) of the augmented matrix; rows above the pivot are eliminated too, so there is no back substitution:
+        //    after step n - 1 column n holds d_i dx_i.
         __shared__ double rdv[NS1];
         __shared__ int s_sing;
         if (tid < n) A[n][tid] = A[tid][n];           // b as row n
-        if (SOLVER == 3 && tid == 0) s_sing = 0;      // raised by the panel waves
-        if constexpr (SOLVER == 2 || SOLVER == 3) {
-        // Rows-in-lanes form (SOLVER 3, the default, runs it panel-wise -- below; SOLVER 2 is its round-4 schedule, one barrier per pivot).  What bounds the packed form below is the LDS: twelve 8-byte reads per thread and step = 96
-        // wave-wide LDS instructions = 42 KB through a 128 B/clk port, ~400 of its ~1100 cycles per step (a 9 x 9-blocked form with 11
-        // broadcast reads per lane cost the same: the port does not care that 56 of 64 lanes read the same word).  Here wave w < 9 owns
+        if (tid == 0) s_sing = 0;                     // raised by the panel waves
+        {
+        // Rows in lanes: wave w < 9 owns
         // columns 8w .. 8w+7 and lane l is row l: v0[jj] = A[l][8w+jj]; rows 64 .. 71 (seven code unknowns and the right-hand side) sit
         // in one more register, vx = A[64 + (l & 7)][8w + (l >> 3)].  A step costs a wave THREE LDS reads (its rows' entries of column
         // k for both register sets, and the per-lane column entry of vx); the pivot and the eight column entries c_jk are rows of the
         // same column, i.e. other lanes' values of the register just read: v_readlane into scalar operands of the FMAs.  Waves whose
-        // columns are all finished skip the step.  
-        // Values computed for columns <= k are never read again.
+        // columns are all finished skip the step.  Values computed for columns <= k are never read again.
         const int w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;      // w in a scalar register: lane selects below are scalar
         const bool worker = w < 9;
         double* Af = &A[0][0];
@@ -1591,14 +1391,14 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
         auto readlane_f64 = [](double x, int l) {
             return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
         };
-        if constexpr (SOLVER == 3) {
-        // Panel schedule (round 5).  The arithmetic of the round-4 schedule below, element for element (every a_ij sees the same
-        // v -= (c_ik rd_k) c_jk for k ascending: bit-identical), but ONE barrier per EIGHT pivots instead of one per pivot.  Wave kb owns
+        {
+        // Panel schedule.  Every a_ij sees v -= (c_ik rd_k) c_jk for k ascending (tests/test_solve_schedule.py emulates the schedule lane for lane),
+        // with ONE barrier per EIGHT pivots.  Wave kb owns
         // columns 8kb .. 8kb+7 whole (rows in lanes), so it can run the eight steps of its panel on its own registers: the pivot and the
         // column entries c_jk are lanes of the register that IS column k (v_readlane), and only the eight extra rows (vx) need the LDS --
         // the wave's own write, read back in order, off the pivot chain.  It publishes each column as it becomes final, with the
         // pivot's reciprocal.  After the barrier the waves to its right apply the eight steps in one burst (LDS reads issued up front).
-        // Measured with shader-clock stamps (-DSOLVE_STAMPS, profiles/r05_latency_kernel_stats.md): panel 2600 cycles, barrier 160,
+        // Measured with shader-clock stamps (profiles/r05_latency_kernel_stats.md; the stamp patch: profiles/r06_removed_experiments.patch): panel 2600 cycles, barrier 160,
         // burst of the next panel's wave 2150 -> 18 us for the 71 pivots against 25 with one barrier per pivot (860 cycles each).  Both
         // phases are issue-bound, ~8 cycles per instruction for a lone wave of fp64 FMAs and v_readlane pairs (~40 instructions per
         // step each): raising the next panel wave's priority, bursts of 2 or 8 steps, changed nothing.
@@ -1606,7 +1406,6 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
 #pragma unroll 1
         for (int kb = 0; 8 * kb < n; ++kb) {
             if (active && w == kb) {
-                SOLVE_STAMP2(4 * kb);
                 auto panel = [&](auto last_c) {
                     constexpr bool LAST = decltype(last_c)::value;        // wave 8: rows / pivots 64 .. 70 live in vx
 #pragma unroll
@@ -1647,10 +1446,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
                 };
                 if (kb == 8) panel(BoolC<true>{}); else panel(BoolC<false>{});
                 if (sing && lane == 0) s_sing = 1;
-                SOLVE_STAMP2(4 * kb + 1);
             }
             __syncthreads();                                              // panel kb and its reciprocals are published
-            if (active && w == kb + 1) SOLVE_STAMP2(4 * kb + 2);
             if (active && w > kb) {
                 // every column of the panel exists here (8 kb + 7 < 8 w <= n) and every pivot row is one of rows 0 .. 63: straight-line
                 // code, in two half-bursts of four steps whose 16 LDS reads are all in flight before the first use
@@ -1684,41 +1481,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (active && w == kb + 1) SOLVE_STAMP2(4 * kb + 3);
         }
-        if (w == 8) SOLVE_STAMP2(36);
-        } else {
-#pragma unroll 1
-        for (int kb = 0; 8 * kb < n; ++kb) {
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int k = 8 * kb + t;
-                if (k < n) {                                  // uniform
-                    __syncthreads();                          // column k is published; every read of column k - 1 has retired
-                    if (worker && 8 * w + 7 > k) {            // uniform per wave: a column of mine is still open (wave 8: always)
-                        const double ci0 = Af[o0 + k], cix = Af[oxr + k], cjx = Af[oxc + k];
-                        const double d = readlane_f64(k >= 64 ? cix : ci0, k & 63);      // row k of column k
-                        const double rdk = fast_recip(d);
-                        sing = sing || !(d > 0.0);            // also NaN
-                        if (tid == 8 * 64) rdv[k] = rdk;
-                        const double csrc = (w == 8) ? cix : ci0;                        // rows 8w .. 8w+7 of column k are lanes of this
-                        const int cbase = (w == 8) ? 0 : 8 * w;
-                        // rows ABOVE the pivot are eliminated too (Gauss-Jordan on the symmetric trailing part: the lanes are there anyway),
-                        // so there is no back substitution: after step n - 1 column n holds d_i dx_i.  Only the pivot row itself rests.
-                        const double l0 = lane == k ? 0.0 : ci0 * rdk, lx = (64 + (lane & 7)) == k ? 0.0 : cix * rdk;
-#pragma unroll
-                        for (int jj = 0; jj < 8; ++jj) v0[jj] = fma(-l0, readlane_f64(csrc, cbase + jj), v0[jj]);
-                        vx = fma(-lx, cjx, vx);
-                        const int tn = (t + 1) & 7;           // (compile-time after unrolling) column k + 1 is final after this step: its owner publishes it
-                        if (w == (t == 7 ? kb + 1 : kb)) {
-                            Af[o0 + k + 1] = v0[tn];
-                            if ((lane >> 3) == tn) Af[oxr + k + 1] = vx;
-                        }
-                    }
-                }
-            }
-        }
-        if (tid == 8 * 64) s_sing = sing ? 1 : 0;
         }
         __syncthreads();
         // dx_i = A[i][n] / d_i: column n is register n & 7 of wave n >> 3 (n = 71: wave 8, v0[7] and the vx lanes of column 7; n = 6: wave 0, v0[6])
@@ -1727,172 +1490,12 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
             if (lane < n) Af[o0 + n] = bn * rdv[lane];
             if ((lane >> 3) == (n & 7) && 64 + (lane & 7) < n) Af[oxr + n] = vx * rdv[64 + (lane & 7)];
         }
-        } else {
-        if (tid == 0) {
-            const double d0 = A[0][0];
-            rdv[0] = fast_recip(d0);
-            s_sing = !(d0 > 0.0) ? 1 : 0;              // also NaN
-        }
-        double v[LDL_EPT];
-        int ej[LDL_EPT], oi[LDL_EPT], oj[LDL_EPT];     // column of the element (-1: not part of this system), LDS offsets of rows i and j
-        double* Af = &A[0][0];
-        constexpr int LDA = NS1 + 1;
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < LDL_EPT; ++q) {
-            const int e = tid + LDL_THREADS * q;
-            ej[q] = -1; oi[q] = 0; oj[q] = 0; v[q] = 0.0;
-            if (tid < LDL_THREADS && e < LDL_NP) {
-                // packed column-major lower triangle: column j starts at j * NS1 - j (j - 1) / 2
-                int j = (int)((2 * NS1 + 1 - sqrtf((float)((2 * NS1 + 1) * (2 * NS1 + 1) - 8 * e))) * 0.5f);
-                j = min(max(j, 0), NS1 - 1);
-                while (j > 0 && j * NS1 - j * (j - 1) / 2 > e) --j;
-                while ((j + 1) * NS1 - (j + 1) * j / 2 <= e) ++j;
-                const int i = j + (e - (j * NS1 - j * (j - 1) / 2));
-                if (i <= n && j <= n && !(i == n && j == n)) { ej[q] = j; oi[q] = i * LDA; oj[q] = j * LDA; v[q] = A[i][j]; }
-            }
-        }
-        // ONE compact loop body, executed n times: k_solve runs once per object and iteration with a cold instruction cache, and the
-        // first two forms of this loop (eleven branchy blocks; then nine unswitched copies of a 380-instruction body) spent their time
-        // FETCHING code -- 48 and 58 us for the 71 steps, ~1800 cycles each, like the Gauss-Jordan form whose notes say the same.  So:
-        // no per-slot liveness tests (every thread reads its 12 column entries every step, always-valid addresses, all in flight at once:
-        // six elements per thread keep them within the 128 registers a 1024-thread workgroup allows), selects instead of branches, and one
-        // publication block per step (a column has <= 72 consecutive packed elements: at most one per thread).
-#pragma unroll 1
-        for (int k = 0; k < n; ++k) {
-            __syncthreads();                              // column k and rdv[k] are published; every read of column k - 1 has retired
-            if (tid < LDL_THREADS) {
-                const double rdk = rdv[k];
-                double cik[LDL_EPT], cjk[LDL_EPT];
-#pragma unroll
-                for (int q = 0; q < LDL_EPT; ++q) { cik[q] = Af[oi[q] + k]; cjk[q] = Af[oj[q] + k]; }
-                double pv = 0.0;
-                int po = -1;
-                bool pdiag = false;
-#pragma unroll
-                for (int q = 0; q < LDL_EPT; ++q) {
-                    const double nv = fma(-(cik[q] * rdk), cjk[q], v[q]);
-                    v[q] = ej[q] > k ? nv : v[q];
-                    const bool pub = ej[q] == k + 1;      // final after this step: column k + 1 of the next one
-                    pv = pub ? v[q] : pv;
-                    po = pub ? oi[q] : po;
-                    pdiag = pub ? (oi[q] == oj[q]) : pdiag;
-                }
-                if (po >= 0) {
-                    Af[po + k + 1] = pv;
-                    if (pdiag) {                          // the next pivot: its owner publishes the reciprocal with the column
-                        rdv[k + 1] = fast_recip(pv);
-                        if (!(pv > 0.0)) s_sing = 1;
-                    }
-                }
-            }
-        }
         }
         __syncthreads();
         if (stamp) g_solve_clk[7] = wall_clock64();
         if (s_sing) { if (tid == 0) s.status = DSP_STATUS_NAN; return; }      // uniform
-        // back substitution L^T dx = D^-1 z by wave 0, column-oriented from the last unknown up: lane j holds w_j = z_j - sum_{i > j}
-        // c_ij dx_i for j = lane and lane + 64; dx_i = rd_i w_i is final when every i' > i has been folded in.  Rows of c are contiguous
-        // in LDS; the next row is fetched while the current one is folded.
-        if (SOLVER == 0 && tid < 64) {
-            const int j0 = tid, j1 = tid + 64;
-            double w0 = j0 < n ? A[n][j0] : 0.0, w1 = j1 < n ? A[n][j1] : 0.0;
-            const double rd0 = j0 < n ? rdv[j0] : 0.0, rd1 = j1 < n ? rdv[j1] : 0.0;
-            double c0 = (n >= 1 && j0 < n - 1) ? A[n - 1][j0] : 0.0, c1 = (n >= 1 && j1 < n - 1) ? A[n - 1][j1] : 0.0;
-            for (int i = n - 1; i >= 0; --i) {
-                const double cc0 = c0, cc1 = c1;
-                if (i >= 1) { c0 = j0 < i - 1 ? A[i - 1][j0] : 0.0; c1 = j1 < i - 1 ? A[i - 1][j1] : 0.0; }
-                const double xi_src = (i < 64) ? rd0 * w0 : rd1 * w1;             // valid in lane i & 63
-                const int src = i & 63;
-                const int lo = __builtin_amdgcn_readlane(__double2loint(xi_src), src), hi = __builtin_amdgcn_readlane(__double2hiint(xi_src), src);
-                const double xi = __hiloint2double(hi, lo);
-                if (tid == src) A[i][n] = xi;                                       // dx_i, where the update below expects it
-                w0 = fma(-cc0, xi, w0);                                             // cc = 0 for j >= i
-                w1 = fma(-cc1, xi, w1);
-            }
-        }
         if (stamp) { g_solve_clk[2] = wall_clock64(); g_solve_clk[6] = clock64(); }
         __syncthreads();
-    } else {
-    // 2. Gauss-Jordan elimination of [H | b] in fp64.  H = sum w J^T J + positive diagonal is symmetric positive
-    //    definite, so no pivoting is needed (the reference inverts H with fp32 LU, optimizer.py:186); eliminating above
-    //    and below the diagonal leaves x_i = A[i][n] / A[i][i] with no serial back-substitution.  Column k itself is
-    //    never rewritten (it is not read again), so one barrier per step suffices.
-    //    The matrix lives in REGISTERS during the elimination: thread (tr, tc) holds column tc of rows tr, tr+12, ... (6
-    //    doubles).  Per step only the pivot row and the pivot column travel through LDS (published by their owners, one
-    //    barrier per step).  Register indices must be compile-time, yet a 71-step unrolled body is 150 KB of code executed once
-    //    (instruction-fetch bound, 100 us), so the loop runs over groups of twelve pivots and ROTATES the register file by one
-    //    position per group: the pivot rows of the current group are always a[0], and a[i] is row 12*((kk+i) mod 6) + tr.
-    //    (History for one 71x71 solve: [H | b] in LDS with per-element division and one LDS round trip per element, 137 us;
-    //    registers + batched reads on 4 waves, 94 us, instruction-issue bound; 16 waves, this form: 74 us.)
-    const int tr = tid / (NSOLVE + 1), tc = tid % (NSOLVE + 1);     // 12 row groups x 72 columns = 864 working threads
-    constexpr int ROW_GROUPS = 12, ROWS_PER_THREAD = (NSOLVE + ROW_GROUPS - 1) / ROW_GROUPS;
-    __shared__ double prow[ROW_GROUPS][NSOLVE + 1];
-    __shared__ __attribute__((aligned(16))) double pcol[ROW_GROUPS][ROW_GROUPS][ROWS_PER_THREAD];
-    __shared__ double diag[NSOLVE + 1];
-    const bool worker = tr < ROW_GROUPS && tc <= n;
-    double a[ROWS_PER_THREAD];
-#pragma unroll
-    for (int i = 0; i < ROWS_PER_THREAD; ++i) {
-        const int r = tr + ROW_GROUPS * i;
-        a[i] = (worker && r < n) ? A[r][tc] : 0.0;
-    }
-    bool singular = false;
-#pragma unroll 1
-    for (int kk = 0; kk < ROWS_PER_THREAD; ++kk) {
-#pragma unroll
-        for (int t = 0; t < ROW_GROUPS; ++t) {
-            const int k = ROW_GROUPS * kk + t;
-            if (k < n) {                                                  // uniform
-                if (worker && tr == t) prow[t][tc] = a[0];                // row k = 3 kk + t is a[0] of row group t
-                if (worker && tc == k) {
-#pragma unroll
-                    for (int i = 0; i < ROWS_PER_THREAD; ++i) pcol[t][tr][i] = a[i];      // column k, in rotated order
-                }
-                __syncthreads();
-                const double pv = prow[t][k];
-                if (!(fabs(pv) > 0.0) || isnan(pv)) singular = true;      // uniform: every thread reads the same pivot
-                const double ipv = 1.0 / pv;
-                const bool col_live = worker && tc > k;
-                const double akj = col_live ? prow[t][tc] : 0.0;
-                // all column entries are read up front and unconditionally, and the row tests
-                // become selects: as `if (live) a[i] -= pc[i] * ...` hipcc emitted one branch + LDS round trip per element
-                // (24 serialised ~150-cycle waits per step -- that, not LDS bandwidth, was the 115 us)
-                const double2* pc2 = reinterpret_cast<const double2*>(pcol[t][tr < ROW_GROUPS ? tr : 0]);
-                double pc[ROWS_PER_THREAD];
-#pragma unroll
-                for (int i = 0; i < ROWS_PER_THREAD / 2; ++i) { const double2 v = pc2[i]; pc[2 * i] = v.x; pc[2 * i + 1] = v.y; }
-#pragma unroll
-                for (int i = 0; i < ROWS_PER_THREAD; ++i) {
-                    int pos = kk + i;
-                    if (pos >= ROWS_PER_THREAD) pos -= ROWS_PER_THREAD;
-                    const int r = ROW_GROUPS * pos + tr;
-                    const double f = (col_live && r < n && r != k) ? (pc[i] * ipv) * akj : 0.0;
-                    a[i] = a[i] - f;
-                }
-            }
-        }
-        const double first = a[0];
-#pragma unroll
-        for (int i = 0; i + 1 < ROWS_PER_THREAD; ++i) a[i] = a[i + 1];
-        a[ROWS_PER_THREAD - 1] = first;
-    }
-    // ROWS_PER_THREAD rotations later a[i] is row tr + 12 i again
-    if (singular) { if (tid == 0) s.status = DSP_STATUS_NAN; return; }
-    // x_i = b_i / H_ii after the elimination: the diagonal sits in thread (r % 3, r), the right-hand side in column n
-#pragma unroll
-    for (int i = 0; i < ROWS_PER_THREAD; ++i) {
-        const int r = tr + ROW_GROUPS * i;
-        if (worker && r < n && r == tc) diag[r] = a[i];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < ROWS_PER_THREAD; ++i) {
-        const int r = tr + ROW_GROUPS * i;
-        if (worker && r < n && tc == n) A[r][n] = a[i] / diag[r];
-    }
-    if (stamp) { g_solve_clk[2] = wall_clock64(); g_solve_clk[6] = clock64(); }
-    __syncthreads();
     }
     if (trace) {
         float* tr = trace + ((size_t)iter * n_obj + b) * TRACE_STRIDE;
@@ -2083,20 +1686,6 @@ void launch_prepass_audit(const ObjConst* oc, const ObjState* st, const float* s
                           int B, hipStream_t s) {
     hipLaunchKernelGGL(k_prepass_audit, dim3(64, B), dim3(256), 0, s, oc, st, ssdf, saudit, th, out);
 }
-void launch_front_fused(const ObjConst* oc, ObjState* st, const float* rays, const float* pts, unsigned long long* raymask, int* raycnt, int* rayoff,
-                        float4* spts, float* ssdf, unsigned char* alive, float4* jpts, float2* jaux, int D, int B, hipStream_t s) {
-    hipLaunchKernelGGL(k_front_fused, dim3(B), dim3(FUSED_THREADS), 0, s, oc, st, rays, pts, raymask, raycnt, rayoff, spts, ssdf, alive, jpts, jaux, D);
-}
-void launch_band_fused(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff, const float* ssdf, float th, unsigned guard_salt,
-                       int* pcnt, int* poff, int* plist, const float4* spts, float4* jpts, int* srow, int B, hipStream_t s) {
-    hipLaunchKernelGGL(k_band_fused, dim3(B), dim3(FUSED_THREADS), 0, s, oc, st, raymask, rayoff, ssdf, th, guard_salt, pcnt, poff, plist, spts, jpts, srow);
-}
-void launch_render_tail_fused(const ObjConst* oc, ObjState* st, const int* raycnt, const int* rayoff, const float4* spts, const float* sdeds,
-                              const float* ray_res, const int* kcnt, int* koff, const int* mcnt, float4* jpts, float2* jaux, const int* srow, int* jrow,
-                              int B, hipStream_t s) {
-    hipLaunchKernelGGL(k_render_tail_fused, dim3(B), dim3(FUSED_THREADS), 0, s, oc, st, raycnt, rayoff, spts, sdeds, ray_res, kcnt, koff, mcnt, jpts, jaux,
-                       srow, jrow);
-}
 void launch_front_wave(const ObjConst* oc, ObjState* st, const float* rays, const float* pts, unsigned long long* raymask, int* raycnt, int* rayoff,
                        float4* spts, float* ssdf, unsigned char* alive, float4* jpts, float2* jaux, int D, int maxR, int maxM, int B, hipStream_t s) {
     const int nrb = std::max(1, (maxR + WAVE_RAYS - 1) / WAVE_RAYS), nsb = (maxM + WAVE_THREADS - 1) / WAVE_THREADS;
@@ -2145,19 +1734,9 @@ void launch_jrows(const ObjConst* oc, const ObjState* st, const float4* jpts, co
     hipLaunchKernelGGL(k_jrows, dim3((cap + 255) / 256), dim3(256), 0, s, oc, st, jpts, jaux, jgrad, jrow, term, rows);
 }
 void launch_solve(const ObjConst* oc, ObjState* st, const float* partials, double* gsum, int n_slices, const GnParamsDev& prm, int iter,
-                  float* trace, const float* codew, const float* b0, const float* blat, float* cbias, const float* depths_next, int B, hipStream_t s,
-                  int solver) {
-#if !defined(SOLVE_FUSED_REDUCE)
+                  float* trace, const float* codew, const float* b0, const float* blat, float* cbias, const float* depths_next, int B, hipStream_t s) {
     hipLaunchKernelGGL(k_gram_reduce, dim3((72 * 72 + 255) / 256, B, prm.pose_only ? 1 : 2), dim3(256), 0, s, st, partials, n_slices, gsum);
-#endif
-    if (solver == 1)
-        hipLaunchKernelGGL(k_solve<1>, dim3(B), dim3(SOLVE_THREADS), 0, s, oc, st, gsum, partials, n_slices, prm, iter, codew, b0, blat, cbias, trace, depths_next, B);
-    else if (solver == 3)
-        hipLaunchKernelGGL(k_solve<3>, dim3(B), dim3(SOLVE_THREADS), 0, s, oc, st, gsum, partials, n_slices, prm, iter, codew, b0, blat, cbias, trace, depths_next, B);
-    else if (solver == 2)
-        hipLaunchKernelGGL(k_solve<2>, dim3(B), dim3(SOLVE_THREADS), 0, s, oc, st, gsum, partials, n_slices, prm, iter, codew, b0, blat, cbias, trace, depths_next, B);
-    else
-        hipLaunchKernelGGL(k_solve<0>, dim3(B), dim3(SOLVE_THREADS), 0, s, oc, st, gsum, partials, n_slices, prm, iter, codew, b0, blat, cbias, trace, depths_next, B);
+    hipLaunchKernelGGL(k_solve, dim3(B), dim3(SOLVE_THREADS), 0, s, oc, st, gsum, prm, iter, codew, b0, blat, cbias, trace, depths_next, B);
 }
 void launch_inlier_filter(const ObjConst* oc, ObjState* st, const float* jgrad, unsigned char* alive, int maxM, int B, hipStream_t s) {
     hipLaunchKernelGGL(k_inlier_filter, GRID2(maxM, B), dim3(256), 0, s, oc, st, jgrad, alive);
@@ -2168,15 +1747,6 @@ void launch_finalize(ObjState* st, const float* scale, int B, int pose_only, flo
 }
 
 hipError_t debug_solve_clocks(unsigned long long* out8) {
-#if defined(SOLVE_STAMPS)     // development aid: per-panel shader-clock stamps of object 0's last k_solve<3>, to stderr
-    unsigned long long c2[40];
-    if (hipMemcpyFromSymbol(c2, HIP_SYMBOL(g_solve_clk2), sizeof(c2)) == hipSuccess) {
-        for (int kb = 0; kb < 9; ++kb)
-            fprintf(stderr, "panel %d: begin +%llu  panel %llu cycles  | next wave: barrier passed +%llu after panel end, burst %llu cycles\n", kb,
-                    c2[4 * kb] - c2[0], c2[4 * kb + 1] - c2[4 * kb], c2[4 * kb + 2] - c2[4 * kb + 1], c2[4 * kb + 3] - c2[4 * kb + 2]);
-        fprintf(stderr, "elimination end +%llu\n", c2[36] - c2[0]);
-    }
-#endif
     return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_solve_clk), 64);
 }
 
@@ -2198,6 +1768,11 @@ __global__ void k_debug_lie(int kind, const float* x, float* out, int n_depth) {
         for (int i = 0; i < 16; ++i) s.t_oc[i] = x[i];
         s.status = DSP_STATUS_GOOD;
         derive_iter_state(s, n_depth);
+        if (s.status != DSP_STATUS_GOOD) {      // singular matrix: derive_iter_state left the derived state unset -- report the status alone
+            for (int i = 0; i < 11; ++i) out[i] = 0.f;
+            out[11] = (float)s.status;
+            return;
+        }
         float jrot[7], res;
         rotation_prior(s, jrot, res);
         for (int i = 0; i < 7; ++i) out[i] = jrot[i];

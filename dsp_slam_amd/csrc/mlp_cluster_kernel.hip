@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256, 1) void mlp_cluster_kernel(const MlpArgs a) {
     if (a.direct.kind) dl = direct_list(a.direct, SPLIT_TILE_PTS);
     const int n_tiles = a.direct.kind ? dl.n_tiles : *a.n_tiles;
     // (a one-object batch without a list: this kernel records the counts when the list is its own -- an empty one included; if this launch
-    // then loses a hand-off the latency form repeats the list and counts it again: the counters say what was computed)
+    // then loses a hand-off the latency form repeats the list but does not count it again: the error word names the launch)
     if (a.direct.kind && n_tiles <= a.cluster_max_tiles && blockIdx.x == 0 && tid == 0 &&
         (n_tiles <= 0 || *reinterpret_cast<const volatile unsigned*>(a.cl_err) == 0u)) direct_commit(a.direct, dl);
     // the launch sequence issues this kernel AND the latency form for the same list; the tile count (known on the device only) picks one
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256, 1) void mlp_cluster_kernel(const MlpArgs a) {
                     if (spins == 0) t0 = wall_clock64();
                     if ((++spins & 15u) == 0u && wall_clock64() - t0 > (unsigned long long)a.cl_spin_ticks) {
                         dead = true;
-                        if (lane == 0) atomicOr(a.cl_err, 1u);
+                        if (lane == 0) atomicCAS(a.cl_err, 0u, a.cl_epoch_base | 1u);     // non-zero, and says WHICH launch gave up (mlp_split_kernel: no second direct_commit)
                         __threadfence();      // the word is out before anything this wave publishes from here on (stale data under a current tag)
                         break;
                     }

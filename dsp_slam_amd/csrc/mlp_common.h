@@ -13,13 +13,10 @@ constexpr int BIAS_BYTES = BIAS_ROWS_MAX * WIDTH * 4;      // 22 KiB
 constexpr int CODEBIAS_BYTES = 2 * WIDTH * 4;              // per-object code contribution of layer 0 and of the latent_in layer
 constexpr int MASK_SLOTS = 8;
 constexpr int MASK_BYTES = MASK_SLOTS * 8 * 256 * 2;       // [slot][og][tid] u16 = 32 KiB
-constexpr int PREFETCH = 2;                   // A operands are read this many k-steps ahead of their MFMAs (<= 3 with 4 buffers)
-// A operands are read from LDS in groups of PAIR_READS k-steps, one s_waitcnt per group, instead of one read + one wait per k-step:
-// every instruction between two MFMAs costs matrix-pipe time even in the MFMA's shadow (measured: 1 read + 1 wait per k-step 0.885 of
-// peak, groups of 2: 0.903, groups of 4: 0.898; 0 rebuilds the per-k-step form)
-#ifndef PAIR_READS
-#define PAIR_READS 2
-#endif
+// A operands are read from LDS in groups of PAIR_READS k-steps, one s_waitcnt per group, two groups ahead of their MFMAs: every instruction
+// between two MFMAs costs matrix-pipe time even in the MFMA's shadow (measured: one read + one wait per k-step 0.885 of peak, groups of 2:
+// 0.903, groups of 4: 0.898; profiles/r06_removed_experiments.md)
+constexpr int PAIR_READS = 2;
 constexpr int GLDS_PER_CHUNK = 4;             // per wave: 4 x 1 KiB pieces of a 16 KiB chunk
 
 #define MFMA16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x4f32((A), (B), (C), 0, 0, 0)
@@ -47,36 +44,16 @@ __device__ __forceinline__ void glds_quarter(const char* gsrc_uniform, unsigned 
         : "memory");
 }
 
-// One 1 KiB piece of the quarter: PIECE selects the immediate offset (moves source and destination alike).
-template <int PIECE>
-__device__ __forceinline__ void glds_piece(const char* gsrc_uniform, unsigned lane_off, unsigned lds_dst) {
-    asm volatile(
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %0, %1 offset:%3"
-        :
-        : "v"(lane_off), "s"(gsrc_uniform), "s"(lds_dst), "n"(PIECE * 1024)
-        : "memory");
-}
-
 // The four pieces of a chunk share one LDS destination base: M0 is set once (glds_set_dst, at the barrier that frees the slot) and the
-// pieces are bare loads -- 5 instructions per chunk and wave in the MFMA stream instead of 12.  M0 has to survive the k-steps in
-// between; nothing else in these kernels writes it (tests/test_cabi_symbols.py checks the code objects).
-#ifndef GLDS_M0_PER_PIECE
-#define GLDS_M0_PER_PIECE 0      // 1: every piece writes M0 itself (A/B switch)
-#endif
+// pieces are bare loads whose immediate offset moves source and destination alike -- 5 instructions per chunk and wave in the MFMA stream
+// (a form in which every piece writes M0 itself: 12; profiles/r06_removed_experiments.md).  M0 has to survive the k-steps in between;
+// nothing else in these kernels writes it (tests/test_cabi_symbols.py checks the code objects).
 __device__ __forceinline__ void glds_set_dst(unsigned lds_dst) {
-#if !GLDS_M0_PER_PIECE
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" : : "s"(lds_dst) : "memory");
-#endif
 }
 template <int PIECE>
 __device__ __forceinline__ void glds_piece_m0(const char* gsrc_uniform, unsigned lane_off, unsigned lds_dst) {
-#if GLDS_M0_PER_PIECE
-    glds_piece<PIECE>(gsrc_uniform, lane_off, lds_dst);
-#else
     asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" : : "v"(lane_off), "s"(gsrc_uniform), "n"(PIECE * 1024) : "memory");
-#endif
 }
 
 __device__ __forceinline__ unsigned lds_addr(const void* p) {

@@ -80,18 +80,10 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
     for (int i = 0; i < NBUF - 1; ++i) issue();
     // chunk 0 visible to every wave; from here on the barrier for chunk q+1 sits in the middle of chunk q
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(GLDS_PER_CHUNK * (NBUF - 2)) : "memory");
-#if PAIR_READS
-    f32x4 abuf[2 * PAIR_READS];
-#else
-    f32x4 abuf[4];   // A operands run PREFETCH k-steps ahead of the MFMAs, across chunk / group / pass seams
-                     // (4 slots, not 3: 16 k-steps per chunk must be a multiple of the rotation length)
-#endif
+    f32x4 abuf[2 * PAIR_READS];   // A operands run one group of PAIR_READS k-steps ahead of the MFMAs, across chunk / group / pass seams
+    static_assert(PAIR_READS == 2, "the prologue below reads the first group");
     abuf[0] = *reinterpret_cast<const f32x4*>(ring_ptr + lane * 16);
     abuf[1] = *reinterpret_cast<const f32x4*>(ring_ptr + lane * 16 + 1024);
-    if (PREFETCH > 2) abuf[2] = *reinterpret_cast<const f32x4*>(ring_ptr + lane * 16 + 2048);
-#if PAIR_READS
-    if (PAIR_READS > 2) { abuf[2] = *reinterpret_cast<const f32x4*>(ring_ptr + lane * 16 + 2048); abuf[3] = *reinterpret_cast<const f32x4*>(ring_ptr + lane * 16 + 3072); }
-#endif
 
     float sin_[128];   // input slab of the current pass:  sin_[4t+r] = row 16t + 4g + r of point pl
     f32x4 acc[32];     // output slab being produced: the MFMA accumulators of all 32 row tiles
@@ -251,21 +243,12 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
                                     // Chunk q+1 has landed for this wave once <= NBUF-3 younger chunks are in flight; the
                                     // barrier publishes every wave's quarter and proves all reads of chunk q-1 retired
                                     // (every wave is inside chunk q), so its slot can be refilled right away.
-#if defined(K1_ABL_NOBAR)        // ablation (WRONG results, timing only: profiles/r05_k1_idle.md): what the per-chunk barrier costs
-                                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GLDS_PER_CHUNK * (NBUF - 3)) : "memory");
-#else
                                     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(GLDS_PER_CHUNK * (NBUF - 3)) : "memory");
-#endif
                                 }
-#if PAIR_READS
                                 // A operands in groups of RG k-steps: one wait (lgkmcnt(0): the group read RG k-steps ago) and RG reads
                                 // (k-steps s+RG .. s+2RG-1) every RG-th k-step -- 1 + 1/RG non-MFMA instructions per k-step instead of 2
                                 constexpr int RG = PAIR_READS;
-#if defined(K1_ABL_NOLDS)        // ablation (WRONG results, timing only): no A-operand reads from LDS, no lgkmcnt waits
-                                if (false) {
-#else
                                 if ((s % RG) == 0) {
-#endif
                                     __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0), vmcnt / expcnt untouched
                                     __builtin_amdgcn_sched_barrier(0);      // keep it ahead of the k-step's first MFMA
 #pragma unroll
@@ -276,28 +259,14 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
                                                            : *reinterpret_cast<const f32x4*>(nb + (sp - KSTEPS_PER_CHUNK) * 1024);
                                     }
                                 }
-#else
-                                const int sp = s + PREFETCH;
-                                abuf[sp % 4] = (sp < KSTEPS_PER_CHUNK)
-                                                   ? *reinterpret_cast<const f32x4*>(cb + sp * 1024)
-                                                   : *reinterpret_cast<const f32x4*>(nb + (sp - KSTEPS_PER_CHUNK) * 1024);
-#endif
-#if PAIR_READS
                                 const f32x4 av = abuf[s % (2 * PAIR_READS)];
-#else
-                                const f32x4 av = abuf[s % 4];
-#endif
                                 const float b = sin_[16 * c + s];
                                 acc[4 * og + 0] = MFMA16(av.x, b, (c == 0 && s == 0) ? bias4[0] : acc[4 * og + 0]);
                                 // refill of the slot freed by the barrier above: one DMA piece per k-step, behind an MFMA
-#if defined(K1_ABL_NODMA)        // ablation (WRONG results, timing only): the weight stream is not refilled (and its vmcnt waits find nothing in flight)
-                                if (s == KSTEPS_PER_CHUNK / 2 + 3) issue_next();
-#else
                                 if (s == KSTEPS_PER_CHUNK / 2 + 0) { glds_set_dst(idst); glds_piece_m0<0>(isrc, lane_off, idst); };
                                 if (s == KSTEPS_PER_CHUNK / 2 + 1) glds_piece_m0<1>(isrc, lane_off, idst);
                                 if (s == KSTEPS_PER_CHUNK / 2 + 2) glds_piece_m0<2>(isrc, lane_off, idst);
                                 if (s == KSTEPS_PER_CHUNK / 2 + 3) { glds_piece_m0<3>(isrc, lane_off, idst); issue_next(); }
-#endif
                                 acc[4 * og + 1] = MFMA16(av.y, b, (c == 0 && s == 0) ? bias4[1] : acc[4 * og + 1]);
                                 acc[4 * og + 2] = MFMA16(av.z, b, (c == 0 && s == 0) ? bias4[2] : acc[4 * og + 2]);
                                 acc[4 * og + 3] = MFMA16(av.w, b, (c == 0 && s == 0) ? bias4[3] : acc[4 * og + 3]);
@@ -321,11 +290,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
                         v[4 * j + 0] = acc[4 * og + j].x; v[4 * j + 1] = acc[4 * og + j].y;
                         v[4 * j + 2] = acc[4 * og + j].z; v[4 * j + 3] = acc[4 * og + j].w;
                     }
-#if defined(K1_ABL_NOEPI)        // ablation (WRONG results, timing only): no relu, no mask bits -- the accumulator -> slab moves stay
-                    if (false) {
-#else
                     if (pd.relu) {
-#endif
                         if (MASKS) {
                             unsigned bits = 0;
 #pragma unroll

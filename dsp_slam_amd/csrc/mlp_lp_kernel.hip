@@ -150,7 +150,7 @@ __device__ __forceinline__ void lp_epilogue(int g, int rt0, int rt1, const f32x4
 // NBLK = 2: the wave's 32 points as two column blocks (128-point tiles, the throughput form); NBLK = 1: ONE column block of 16 points
 // (64-point tiles: a detection-sized list -- ~117 tiles of 128 points on 256 CUs -- becomes ~235 tiles of half the length; the same
 // arithmetic per point, so the same values).
-template <bool BF, int NCH, bool LAST, int NBLK, int NW>
+template <bool BF, int NCH, bool LAST, int NBLK>
 __device__ __forceinline__ void lp_pass(const LpPass pd, u32x4 (&in)[32], u32x4 (&out)[32], f32x4 (&acc)[2][LP_RT][2],
                                         u32x4 (&abuf)[2][LP_RT], LpRing& rg, const u32x4 (&xb)[2], const float* bp,
                                         const float* dp, int lane, int gq, float (&part)[2]) {
@@ -205,7 +205,7 @@ __device__ __forceinline__ void lp_pass(const LpPass pd, u32x4 (&in)[32], u32x4 
                 if (kq == LP_KQ / 2) {
                     // chunk q+1 has landed for this wave once <= LP_NBUF-3 younger chunks are in flight; the barrier
                     // publishes every wave's quarter and proves all reads of chunk q-1 retired (mlp_kernel.hip)
-                    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((16 / NW) * (LP_NBUF - 3)) : "memory");
+                    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(GLDS_PER_CHUNK * (LP_NBUF - 3)) : "memory");
                 }
                 // One step = eight MFMAs of 16 cycles (row tile m >> 1, column block m & 1).  A 16-cycle MFMA leaves this one wave THREE issue
                 // slots, so everything else is dealt out over the eight gaps and pinned there (sched_barrier after every MFMA):
@@ -223,9 +223,7 @@ __device__ __forceinline__ void lp_pass(const LpPass pd, u32x4 (&in)[32], u32x4 
 #pragma unroll
                 for (int m = 0; m < NM; ++m) {
                     const int rt = NBLK == 2 ? m >> 1 : m, blk = NBLK == 2 ? m & 1 : 0;
-#if !defined(LP_WAIT_PER_USE)
                     if (m == 0) __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0), vmcnt / expcnt untouched
-#endif
                     if (m < 2) {
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
@@ -235,19 +233,11 @@ __device__ __forceinline__ void lp_pass(const LpPass pd, u32x4 (&in)[32], u32x4 
                         }
                     }
                     acc[par][rt][blk] = lp_mfma<BF>(abuf[kq & 1][rt], in[2 * ks + blk], ks == 0 ? bias[rt] : acc[par][rt][blk]);
-                    // refill of the slot freed by the barrier above: four DMA pieces per chunk
-                    if constexpr (NW == 4) {        // this wave's quarter of the chunk: four 1 KiB pieces
-                        if (kq == LP_KQ / 2 && m == 1) { glds_set_dst(rg.idst); glds_piece_m0<0>(rg.isrc, rg.lane_off, rg.idst); }
-                        if (kq == LP_KQ / 2 && m == 2) glds_piece_m0<1>(rg.isrc, rg.lane_off, rg.idst);
-                        if (kq == LP_KQ / 2 + 1 && m == 1) glds_piece_m0<2>(rg.isrc, rg.lane_off, rg.idst);
-                        if (kq == LP_KQ / 2 + 1 && m == 2) { glds_piece_m0<3>(rg.isrc, rg.lane_off, rg.idst); lp_issue_next(rg); }
-                    } else {                        // eight waves: an eighth, two pieces
-                        if (kq == LP_KQ / 2 && m == 1) { glds_set_dst(rg.idst); glds_piece_m0<0>(rg.isrc, rg.lane_off, rg.idst); }
-                        if (kq == LP_KQ / 2 + 1 && m == 1) { glds_piece_m0<1>(rg.isrc, rg.lane_off, rg.idst); lp_issue_next(rg); }
-                    }
-#if defined(LP_EPILOGUE_BURST)
-                    if (g > 0 && ks == 1 && blk == NBLK - 1) lp_epilogue<BF, LAST>(g - 1, rt, rt + 1, acc[par ^ 1], dp, gq, out, part, 0, NBLK);
-#else
+                    // refill of the slot freed by the barrier above: this wave's quarter of the chunk, four 1 KiB DMA pieces
+                    if (kq == LP_KQ / 2 && m == 1) { glds_set_dst(rg.idst); glds_piece_m0<0>(rg.isrc, rg.lane_off, rg.idst); }
+                    if (kq == LP_KQ / 2 && m == 2) glds_piece_m0<1>(rg.isrc, rg.lane_off, rg.idst);
+                    if (kq == LP_KQ / 2 + 1 && m == 1) glds_piece_m0<2>(rg.isrc, rg.lane_off, rg.idst);
+                    if (kq == LP_KQ / 2 + 1 && m == 2) { glds_piece_m0<3>(rg.isrc, rg.lane_off, rg.idst); lp_issue_next(rg); }
                     if (NCH == 1) {          // first layer: four steps in all, one row tile behind the last MFMA of each row tile of step 1
                         if (g > 0 && ks == 1 && blk == NBLK - 1) lp_epilogue<BF, LAST>(g - 1, rt, rt + 1, acc[par ^ 1], dp, gq, out, part, 0, NBLK);
                     } else if (epi && !LAST) {
@@ -259,7 +249,6 @@ __device__ __forceinline__ void lp_pass(const LpPass pd, u32x4 (&in)[32], u32x4 
                     } else if (epi && m == E0) {      // last hidden layer (one pass in eight): the unit's dot-product terms in one piece
                         lp_epilogue<BF, LAST>(g - 1, ert, ert + 1, acc[par ^ 1], dp, gq, out, part, eblk, eblk + 1);
                     }
-#endif
                     // the next group's bias: behind the second MFMA of the group's last step, six MFMAs ahead of the lgkmcnt(0) that follows
                     if (ks == LP_KQ * NCH - 1 && m == 1 && g + 1 < LP_NOG) lp_load_rows(bp, g + 1, gq, bias);
                     __builtin_amdgcn_sched_barrier(0);
@@ -272,12 +261,13 @@ __device__ __forceinline__ void lp_pass(const LpPass pd, u32x4 (&in)[32], u32x4 
     lp_epilogue<BF, LAST>(LP_NOG - 1, 0, LP_RT, acc[(LP_NOG - 1) & 1], dp, gq, out, part, 0, NBLK);
 }
 
-// NW = 4 waves (one per SIMD) or 8 (two per SIMD, NBLK = 1 only: 208 registers): with two waves on a SIMD one wave's A-fragment reads, DMA
-// issue and epilogue fill the slots the other's 16-cycle MFMAs leave, at the price of one fragment read per MFMA instead of one per two.
-template <bool BF, int NBLK, int NW>
-__global__ __launch_bounds__(64 * NW, 1) void mlp_lp_kernel(const LpArgs a) {
-    constexpr int TILE = 16 * NBLK * NW, WAVE_PTS = 16 * NBLK;     // LP_TILE_PTS / LP_WAVE_PTS for NBLK = 2, NW = 4
-    constexpr int NT = 64 * NW, WAVE_BYTES = CHUNK_BYTES / NW, PIECES = 16 / NW;
+// Four waves, one per SIMD.  (Eight waves of one column block each -- two per SIMD, one wave's reads and epilogue in the slots the other's
+// MFMAs leave -- were measured: duty 0.71 against 0.67, granted clock -150 MHz, slower; profiles/r05_k0_clock.md, r06_removed_experiments.md.)
+template <bool BF, int NBLK>
+__global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpArgs a) {
+    constexpr int NW = 4;
+    constexpr int TILE = 16 * NBLK * NW, WAVE_PTS = 16 * NBLK;     // LP_TILE_PTS / LP_WAVE_PTS for NBLK = 2
+    constexpr int NT = 64 * NW, WAVE_BYTES = CHUNK_BYTES / NW, PIECES = GLDS_PER_CHUNK;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -314,12 +304,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mlp_lp_kernel(const LpArgs a) {
     rg.ring_lane = lds_addr(ring_ptr) + lane * 16;
 #pragma unroll
     for (int i = 0; i < LP_NBUF - 1; ++i) {
-        if constexpr (NW == 4) {
-            glds_quarter(rg.isrc, rg.lane_off, rg.idst);
-        } else {
-            glds_piece<0>(rg.isrc, rg.lane_off, rg.idst);
-            glds_piece<1>(rg.isrc, rg.lane_off, rg.idst);
-        }
+        glds_quarter(rg.isrc, rg.lane_off, rg.idst);
         lp_issue_next(rg);
     }
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PIECES * (LP_NBUF - 2)) : "memory");
@@ -357,7 +342,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mlp_lp_kernel(const LpArgs a) {
             pt[blk] = a.pts[src[blk]];
             if (!valid[blk]) pt[blk] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        if (tid < 256) reinterpret_cast<float4*>(cb_l)[tid] = reinterpret_cast<const float4*>(a.code_bias + (size_t)td.z * a.code_bias_stride)[tid];
+        reinterpret_cast<float4*>(cb_l)[tid] = reinterpret_cast<const float4*>(a.code_bias + (size_t)td.z * a.code_bias_stride)[tid];
         __syncthreads();
 
         // split-precision xyz operands (LP_XYZ_TERMS): k slot 16 u + 3 t + c of the xyz step carries part xpart(u, t) of coordinate c
@@ -397,12 +382,12 @@ __global__ __launch_bounds__(64 * NW, 1) void mlp_lp_kernel(const LpArgs a) {
         // refuses others: the prepass is then off), so the last layer's input is always in X and the loop has no conditional half --
         // a join there costs ~120 spilled registers per tile.
         const int n_mid = a.n_pass - 2;      // hidden layers between the first and the last one
-        lp_pass<BF, 1, false, NBLK, NW>(a.pass[0], Y, X, acc, abuf, rg, xb, bias_of(a.pass[0]), zero_l, lane, gq, part);
+        lp_pass<BF, 1, false, NBLK>(a.pass[0], Y, X, acc, abuf, rg, xb, bias_of(a.pass[0]), zero_l, lane, gq, part);
         for (int ps = 1; ps < n_mid; ps += 2) {       // n_mid is even (the host refuses odd pass counts): always both halves, no join
-            lp_pass<BF, LP_NCH, false, NBLK, NW>(a.pass[ps], X, Y, acc, abuf, rg, xb, bias_of(a.pass[ps]), zero_l, lane, gq, part);
-            lp_pass<BF, LP_NCH, false, NBLK, NW>(a.pass[ps + 1], Y, X, acc, abuf, rg, xb, bias_of(a.pass[ps + 1]), zero_l, lane, gq, part);
+            lp_pass<BF, LP_NCH, false, NBLK>(a.pass[ps], X, Y, acc, abuf, rg, xb, bias_of(a.pass[ps]), zero_l, lane, gq, part);
+            lp_pass<BF, LP_NCH, false, NBLK>(a.pass[ps + 1], Y, X, acc, abuf, rg, xb, bias_of(a.pass[ps + 1]), zero_l, lane, gq, part);
         }
-        lp_pass<BF, LP_NCH, true, NBLK, NW>(a.pass[a.n_pass - 1], X, Y, acc, abuf, rg, xb, bias_of(a.pass[a.n_pass - 1]), wl, lane, gq, part);
+        lp_pass<BF, LP_NCH, true, NBLK>(a.pass[a.n_pass - 1], X, Y, acc, abuf, rg, xb, bias_of(a.pass[a.n_pass - 1]), wl, lane, gq, part);
         // a point's 512 rows are spread over the four lane groups: lanes p, p + 16, p + 32, p + 48
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
@@ -423,19 +408,16 @@ __global__ __launch_bounds__(64 * NW, 1) void mlp_lp_kernel(const LpArgs a) {
     if (a.clk && blockIdx.x == 0 && tid == 0) { a.clk[2] = clock64(); a.clk[3] = wall_clock64(); }
 }
 
-template __global__ void mlp_lp_kernel<false, 2, 4>(const LpArgs);
-template __global__ void mlp_lp_kernel<true, 2, 4>(const LpArgs);
-template __global__ void mlp_lp_kernel<false, 1, 4>(const LpArgs);
-template __global__ void mlp_lp_kernel<true, 1, 4>(const LpArgs);
-// (NW = 8 -- 128-point tiles as eight waves of one column block, two waves per SIMD -- was measured in round 5 and dropped: the matrix pipe's
-// duty rises from 0.67 to 0.71, the second fragment read per MFMA pair costs 150 MHz of granted clock, K0 1.105 ms per launch against 1.032:
-// profiles/r05_k0_clock.md.  The template parameter stays for that experiment.)
+template __global__ void mlp_lp_kernel<false, 2>(const LpArgs);
+template __global__ void mlp_lp_kernel<true, 2>(const LpArgs);
+template __global__ void mlp_lp_kernel<false, 1>(const LpArgs);
+template __global__ void mlp_lp_kernel<true, 1>(const LpArgs);
 
 static size_t mlp_lp_lds_bytes() { return BIAS_BYTES + CODEBIAS_BYTES + LP_ZERO_BYTES + LP_NBUF * CHUNK_BYTES; }
 
 hipError_t mlp_lp_prepare_device() {
-    const void* fns[4] = {reinterpret_cast<const void*>(&mlp_lp_kernel<false, 2, 4>), reinterpret_cast<const void*>(&mlp_lp_kernel<true, 2, 4>),
-                          reinterpret_cast<const void*>(&mlp_lp_kernel<false, 1, 4>), reinterpret_cast<const void*>(&mlp_lp_kernel<true, 1, 4>)};
+    const void* fns[4] = {reinterpret_cast<const void*>(&mlp_lp_kernel<false, 2>), reinterpret_cast<const void*>(&mlp_lp_kernel<true, 2>),
+                          reinterpret_cast<const void*>(&mlp_lp_kernel<false, 1>), reinterpret_cast<const void*>(&mlp_lp_kernel<true, 1>)};
     for (int i = 0; i < 4; ++i) {
         const hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlp_lp_lds_bytes());
         if (e != hipSuccess) return e;
@@ -448,11 +430,11 @@ hipError_t launch_mlp_lp(bool bf16, const LpArgs& args, int n_blocks, hipStream_
     const bool small = tile_pts == LP_TILE_PTS_SMALL;
     const size_t lds = mlp_lp_lds_bytes();
     if (small) {
-        if (bf16) hipLaunchKernelGGL((mlp_lp_kernel<true, 1, 4>), dim3(n_blocks), dim3(256), lds, stream, args);
-        else hipLaunchKernelGGL((mlp_lp_kernel<false, 1, 4>), dim3(n_blocks), dim3(256), lds, stream, args);
+        if (bf16) hipLaunchKernelGGL((mlp_lp_kernel<true, 1>), dim3(n_blocks), dim3(256), lds, stream, args);
+        else hipLaunchKernelGGL((mlp_lp_kernel<false, 1>), dim3(n_blocks), dim3(256), lds, stream, args);
     } else {
-        if (bf16) hipLaunchKernelGGL((mlp_lp_kernel<true, 2, 4>), dim3(n_blocks), dim3(256), lds, stream, args);
-        else hipLaunchKernelGGL((mlp_lp_kernel<false, 2, 4>), dim3(n_blocks), dim3(256), lds, stream, args);
+        if (bf16) hipLaunchKernelGGL((mlp_lp_kernel<true, 2>), dim3(n_blocks), dim3(256), lds, stream, args);
+        else hipLaunchKernelGGL((mlp_lp_kernel<false, 2>), dim3(n_blocks), dim3(256), lds, stream, args);
     }
     return hipGetLastError();
 }

@@ -58,8 +58,11 @@ __global__ __launch_bounds__(256, 1) void mlp_split_kernel(const MlpArgs a) {
     const int n_tiles = a.direct.kind ? dl.n_tiles : *a.n_tiles;
     // a list this short is the cluster kernel's (mlp_cluster_kernel.hip): both are launched -- unless that kernel lost a hand-off in this
     // run (error word set: it returns at entry from then on, and what it left of the launch that failed is recomputed here)
-    if (BWD && n_tiles < a.split_min_tiles && !(a.cl_err && *reinterpret_cast<const volatile unsigned*>(a.cl_err) != 0u)) return;
-    if (a.direct.kind && blockIdx.x == 0 && tid == 0) direct_commit(a.direct, dl);       // (this kernel takes the list)
+    const unsigned cl_err = (BWD && a.cl_err) ? *reinterpret_cast<const volatile unsigned*>(a.cl_err) : 0u;
+    if (BWD && n_tiles < a.split_min_tiles && cl_err == 0u) return;
+    // (this kernel takes the list; if the cluster kernel of THIS launch gave up on it, that kernel has recorded the list's counts already)
+    const bool counted = BWD && n_tiles < a.split_min_tiles && cl_err == (a.cl_epoch_base | 1u);
+    if (a.direct.kind && blockIdx.x == 0 && tid == 0 && !counted) direct_commit(a.direct, dl);
     if ((int)blockIdx.x >= n_tiles) return;
     for (int i = tid; i < a.n_bias_rows * WIDTH; i += 256) bias_l[i] = a.bias_tab[i];
     __syncthreads();
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(256, 1) void mlp_split_kernel(const MlpArgs a) {
                                     // after it and the two pieces issued so far in this one are still in flight
                                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (SNB - 3) + 2) : "memory");
                                 }
-#if PAIR_READS == 2
+                                static_assert(PAIR_READS == 2, "pairs");
                                 // A operands in pairs, one lgkmcnt wait per pair (mlp_common.h): at m == 2 the pair belongs to the next
                                 // mini-chunk, which the vmcnt wait above has just proven landed
                                 if ((s & 1) == 0) {
@@ -272,11 +275,6 @@ __global__ __launch_bounds__(256, 1) void mlp_split_kernel(const MlpArgs a) {
                                                                          : *reinterpret_cast<const f32x4*>(nbp + (sp - 4) * 1024);
                                     }
                                 }
-#else
-                                const int sp = m + PREFETCH;
-                                abuf[(s + PREFETCH) % 4] = (sp < 4) ? *reinterpret_cast<const f32x4*>(cbp + sp * 1024)
-                                                                    : *reinterpret_cast<const f32x4*>(nbp + (sp - 4) * 1024);
-#endif
                                 const f32x4 av = abuf[s % 4];
                                 const float b = sin_[16 * c + s];
                                 acc[4 * ol + 0] = MFMA16(av.x, b, (c == 0 && s == 0) ? bias4[0] : acc[4 * ol + 0]);

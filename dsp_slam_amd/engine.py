@@ -64,34 +64,80 @@ class Batch(object):
         if trace:
             L.check(lib.dsp_batch_enable_trace(self._h, 1), engine._h, "dsp_batch_enable_trace")
 
+    # ---- the five settings of the C ABI (include/dsp_gn.h) ------------------------------------------------------------------------------
     def set_ray_passes(self, n):
         """0 = automatic, 1 = decode every in-sphere sample (reference behaviour), n = n front-to-back depth ranges."""
         L.check(L.load().dsp_batch_set_ray_passes(self._h, int(n)), self.engine._h, "dsp_batch_set_ray_passes")
-
-    def set_ray_pass_bounds(self, bounds):
-        bounds = np.ascontiguousarray(bounds, np.int32)
-        L.check(L.load().dsp_batch_set_ray_pass_bounds(self._h, L.ptr(bounds, L.c_i32p), bounds.shape[0] - 1), self.engine._h,
-                "dsp_batch_set_ray_pass_bounds")
-
-    def set_mask_reuse(self, mode):
-        """-1 = automatic, 0 = render rows share the surface points' forward+backward launch, 1 = backward-only from exported masks."""
-        L.check(L.load().dsp_batch_set_mask_reuse(self._h, int(mode)), self.engine._h, "dsp_batch_set_mask_reuse")
 
     def set_prepass(self, mode=-1, delta=-1.0):
         """Low-precision pre-classification of the forward ray samples: -1 automatic, 0 off, 1 f16, 2 bf16; delta < 0 = default margin.
         Results are bit-identical for every setting whose delta exceeds the decoder's prepass error."""
         L.check(L.load().dsp_batch_set_prepass(self._h, int(mode), float(delta)), self.engine._h, "dsp_batch_set_prepass")
 
-    def set_prepass_tile(self, points=-1):
-        """-1 = automatic, 128 or 64 points per prepass tile (dsp_batch_set_prepass_tile).  Results are identical for either."""
-        L.check(L.load().dsp_batch_set_prepass_tile(self._h, int(points)), self.engine._h, "dsp_batch_set_prepass_tile")
-
-    def set_prepass_audit(self, on=True):
-        L.check(L.load().dsp_batch_set_prepass_audit(self._h, int(bool(on))), self.engine._h, "dsp_batch_set_prepass_audit")
-
     def set_prepass_guard(self, on=True):
         """The always-on guard of the prepass (include/dsp_gn.h): off only to see what an unguarded run would return."""
         L.check(L.load().dsp_batch_set_prepass_guard(self._h, int(bool(on))), self.engine._h, "dsp_batch_set_prepass_guard")
+
+    def set_kernel_timing(self, mode):
+        """HIP events around every decoder launch (stats ms_mlp_*): -1 = automatic (batches of more than 16 objects), 0 = off, 1 = on."""
+        L.check(L.load().dsp_batch_set_kernel_timing(self._h, int(mode)), self.engine._h, "dsp_batch_set_kernel_timing")
+
+    def set_iterations(self, n):
+        L.check(L.load().dsp_batch_set_iterations(self._h, int(n)), self.engine._h, "dsp_batch_set_iterations")
+        self.iters = int(n)
+
+    # ---- testing: pin one of the bit-identical forms the library chooses between by itself (dsp_batch_set_debug) --------------------------
+    def set_debug(self, key, value):
+        L.check(L.load().dsp_batch_set_debug(self._h, int(key), int(value)), self.engine._h, "dsp_batch_set_debug(%d, %d)" % (key, value))
+
+    def set_mask_reuse(self, mode):
+        """-1 = automatic, 0 = render rows share the surface points' forward+backward launch, 1 = backward-only from exported masks."""
+        self.set_debug(L.DBG_MASK_REUSE, mode)
+
+    def set_split_rows(self, mode):
+        """-1 = automatic, 0 = 64-point throughput tiles, 1 = 16-point latency tiles for the jacobian launch (when mask reuse is off)."""
+        self.set_debug(L.DBG_SPLIT_ROWS, mode)
+
+    def set_tail_split(self, mode):
+        """-1 = automatic, 0 = off, 1 = the last partial round of the fp32 forward launch runs as 16-point latency-form tiles."""
+        self.set_debug(L.DBG_TAIL_SPLIT, mode)
+
+    def set_wave_bookkeeping(self, mode):
+        """-1 = automatic, 0 = per-ray bookkeeping as count / scan / write launches (throughput form), 1 = one wave per ray over the whole chip."""
+        self.set_debug(L.DBG_WAVE_BOOKKEEPING, mode)
+
+    def set_speculative_band(self, mode):
+        """-1 = automatic, 0 = band samples get a forward launch of their own, 1 = they go straight into the jacobian launch (latency path)."""
+        self.set_debug(L.DBG_SPECULATIVE_BAND, mode)
+
+    def set_mixed_reuse(self, mode):
+        """-1 = automatic, 0 = off, 1 = kept render rows backward-only from exported masks INSIDE the latency-form jacobian launch."""
+        self.set_debug(L.DBG_MIXED_REUSE, mode)
+
+    def set_cluster_tiles(self, mode):
+        """-1 = automatic, 0 = one workgroup per 16-point jacobian tile, 1 = four (cluster form) for lists of up to 128 tiles."""
+        self.set_debug(L.DBG_CLUSTER_TILES, mode)
+
+    def set_direct_tiles(self, mode):
+        """-1 automatic / 1: a one-object batch's decoder kernels derive their tile lists themselves; 0: k_build_tiles launches."""
+        self.set_debug(L.DBG_DIRECT_TILES, mode)
+
+    def set_prepass_tile(self, points=-1):
+        """-1 = automatic, 128 or 64 points per prepass tile.  Results are identical for either."""
+        self.set_debug(L.DBG_PREPASS_TILE, points)
+
+    def set_prepass_audit(self, on=True):
+        self.set_debug(L.DBG_PREPASS_AUDIT, int(bool(on)))
+
+    def set_cluster_fault(self, on):
+        """Fault injection: the following runs' cluster launches lose one workgroup's hand-off; False also ends the handle's cool-down."""
+        self.set_debug(L.DBG_CLUSTER_FAULT, int(bool(on)))
+
+    # ---- forensics ------------------------------------------------------------------------------------------------------------------------
+    def set_ray_pass_bounds(self, bounds):
+        bounds = np.ascontiguousarray(bounds, np.int32)
+        L.check(L.load().dsp_batch_debug_ray_pass_bounds(self._h, L.ptr(bounds, L.c_i32p), bounds.shape[0] - 1), self.engine._h,
+                "dsp_batch_debug_ray_pass_bounds")
 
     def set_start_state(self, t_obj_cam=None, codes=None, depths=None):
         """Testing / forensics: start the following runs from these camera->object matrices (taken bit for bit) and / or codes; depths
@@ -104,12 +150,12 @@ class Batch(object):
             for i, row in enumerate(depths):
                 row = np.asarray(row, np.float32).reshape(-1)
                 d[i, :row.shape[0]] = row
-        L.check(L.load().dsp_batch_set_start_state(self._h, L.ptr(t), L.ptr(c), L.ptr(d)), self.engine._h, "dsp_batch_set_start_state")
+        L.check(L.load().dsp_batch_debug_start_state(self._h, L.ptr(t), L.ptr(c), L.ptr(d)), self.engine._h, "dsp_batch_debug_start_state")
 
     def set_depth_schedule(self, depths=None):
         """Testing / forensics: depths[e][i] = the depth samples object i uses in iteration e (None = derive them from the pose again)."""
         if depths is None:
-            L.check(L.load().dsp_batch_set_depth_schedule(self._h, None, 0), self.engine._h, "dsp_batch_set_depth_schedule")
+            L.check(L.load().dsp_batch_debug_depth_schedule(self._h, None, 0), self.engine._h, "dsp_batch_debug_depth_schedule")
             return
         n_it = len(depths)
         d = np.zeros((n_it, self.n, 64), np.float32)
@@ -117,11 +163,7 @@ class Batch(object):
             for i in range(self.n):
                 row = np.asarray(depths[e][i], np.float32).reshape(-1)
                 d[e, i, :row.shape[0]] = row
-        L.check(L.load().dsp_batch_set_depth_schedule(self._h, L.ptr(d), n_it), self.engine._h, "dsp_batch_set_depth_schedule")
-
-    def set_iterations(self, n):
-        L.check(L.load().dsp_batch_set_iterations(self._h, int(n)), self.engine._h, "dsp_batch_set_iterations")
-        self.iters = int(n)
+        L.check(L.load().dsp_batch_debug_depth_schedule(self._h, L.ptr(d), n_it), self.engine._h, "dsp_batch_debug_depth_schedule")
 
     def debug_samples(self, obj, n_rays, n_depth):
         """(in-sphere mask (n_rays, n_depth) bool, sdf grid, de_ds grid) the last iteration of the last run left for object obj
@@ -133,44 +175,6 @@ class Batch(object):
                 self.engine._h, "dsp_batch_debug_samples")
         mask = ((rm[:, None] >> np.arange(n_depth, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(bool)
         return mask, sdf, deds
-
-    def set_speculative_band(self, mode):
-        """-1 = automatic, 0 = band samples get a forward launch of their own, 1 = they go straight into the jacobian launch (latency path)."""
-        L.check(L.load().dsp_batch_set_speculative_band(self._h, int(mode)), self.engine._h, "dsp_batch_set_speculative_band")
-
-    def set_tail_split(self, mode):
-        """-1 = automatic, 0 = off, 1 = the last partial round of the fp32 forward launch runs as 16-point latency-form tiles."""
-        L.check(L.load().dsp_batch_set_tail_split(self._h, int(mode)), self.engine._h, "dsp_batch_set_tail_split")
-
-    def set_direct_tiles(self, mode):
-        """-1 automatic / 1: a one-object batch's decoder kernels derive their tile lists themselves; 0: k_build_tiles launches."""
-        L.check(L.load().dsp_batch_set_direct_tiles(self._h, int(mode)), self.engine._h, "dsp_batch_set_direct_tiles")
-
-    def set_solver(self, mode):
-        """3 = fp64 elimination with rows in lanes, one barrier per panel of eight pivots (default); 2 = the same arithmetic, one barrier per
-        pivot (bit-identical to 3); 0 = packed LDL^T; 1 = pivot-free Gauss-Jordan (0-2: A/B references; dsp_gn.h)."""
-        L.check(L.load().dsp_batch_set_solver(self._h, int(mode)), self.engine._h, "dsp_batch_set_solver")
-
-    def set_mixed_reuse(self, mode):
-        """-1 = automatic, 0 = off, 1 = kept render rows backward-only from exported masks INSIDE the latency-form jacobian launch."""
-        L.check(L.load().dsp_batch_set_mixed_reuse(self._h, int(mode)), self.engine._h, "dsp_batch_set_mixed_reuse")
-
-    def set_cluster_tiles(self, mode):
-        """-1 = automatic, 0 = one workgroup per 16-point jacobian tile, 1 = four (cluster form) for lists of up to 128 tiles."""
-        L.check(L.load().dsp_batch_set_cluster_tiles(self._h, int(mode)), self.engine._h, "dsp_batch_set_cluster_tiles")
-
-    def set_kernel_timing(self, mode):
-        """HIP events around every decoder launch (stats ms_mlp_*): -1 = automatic (batches of more than 16 objects), 0 = off, 1 = on."""
-        L.check(L.load().dsp_batch_set_kernel_timing(self._h, int(mode)), self.engine._h, "dsp_batch_set_kernel_timing")
-
-    def set_fused_bookkeeping(self, mode):
-        """-1 = automatic, 0 = per-ray bookkeeping as separate launches (throughput form), 1 = fused per object (one workgroup each),
-        2 = one wave per ray over the whole chip (latency form, round 4)."""
-        L.check(L.load().dsp_batch_set_fused_bookkeeping(self._h, int(mode)), self.engine._h, "dsp_batch_set_fused_bookkeeping")
-
-    def set_split_rows(self, mode):
-        """-1 = automatic, 0 = 64-point throughput tiles, 1 = 16-point latency tiles for the jacobian launch (when mask reuse is off)."""
-        L.check(L.load().dsp_batch_set_split_rows(self._h, int(mode)), self.engine._h, "dsp_batch_set_split_rows")
 
     def run(self):
         L.check(L.load().dsp_batch_run(self._h), self.engine._h, "dsp_batch_run")
@@ -413,6 +417,10 @@ class Engine(object):
         return (j7[:k.value].copy(), jc[:k.value, :self.code_len].copy(), r[:k.value].copy()), stats
 
     # -- optimiser ----------------------------------------------------------------------------------
+    def fail_alloc(self, n):
+        """Testing: the (n + 1)-th fresh device allocation of this handle's pool from now on fails like an exhausted HBM (n < 0: off)."""
+        L.check(L.load().dsp_debug_fail_alloc(self._h, int(n)), self._h, "dsp_debug_fail_alloc")
+
     def trim(self):
         """Hand the handle's cached device blocks and pinned staging buffers back to the runtime (dsp_trim): for a process that shares the
         GPU with torch / RCCL / another handle and has just finished a large one-shot batch."""

@@ -99,19 +99,22 @@ typedef struct dsp_stats {
     int32_t cluster_fallback;    /* (ABI version 5) 1: a cluster-form launch of this run lost a hand-off within its time bound (2 ms: a busy shared GPU kept one of the
                                   * four workgroups off its CU); the latency-form kernel recomputed that launch and took the run's remaining lists on the device --
                                   * same results, a few ms later; the handle keeps the cluster form off for its next 64 runs */
-    int32_t reserved0;
+    int32_t cluster_cooldown;    /* (ABI version 6) runs for which the handle still keeps the cluster form off after a lost hand-off (0 = it is in use again) */
 } dsp_stats;
 
 /* ---- lifetime --------------------------------------------------------------------------------- */
 /* Thread safety: calls on ONE handle (and on batches created from it) are serialised inside the library (one call at a time per handle);
  * different handles are independent.  Callers that release the GIL around these calls (ctypes, pybind11) may therefore call from any thread. */
 int dsp_create(const dsp_decoder_desc* decoder, int device, dsp_handle** out);
-/* Destroys the handle AND every resident batch still alive on it; a later dsp_batch_destroy of such a batch is ignored (either order of the
- * two calls is safe: finalisers at interpreter exit run in no particular order). */
+/* Destroys the handle AND every resident batch still alive on it.  A dsp_batch* is an opaque, generation-tagged TOKEN, not an address: once its
+ * batch is gone -- destroyed, or taken by dsp_destroy of its handle -- every call that is handed the token returns DSP_E_ARG (dsp_batch_destroy:
+ * does nothing), also after the memory has been reused for another batch.  So the two destroy calls are safe in either order and from any
+ * thread (finalisers at interpreter exit run in no particular order); dsp_destroy waits for calls in flight on the handle's batches. */
 void dsp_destroy(dsp_handle* h);
 /* A handle keeps device blocks (up to 1 GiB, size-classed) and pinned host staging of dropped one-shot batches for its next call.  dsp_trim
  * hands all of it back to the runtime: for a process that shares the GPU with another allocator (torch, RCCL, a second handle).  Destroying
- * a resident batch (dsp_batch_destroy) trims the cache to the footprint of one KITTI-size detection (64 MiB) on its own. */
+ * a LARGE resident batch (more than 512 MiB left parked behind it) trims the cache to the footprint of one KITTI-size detection (64 MiB) on
+ * its own; detection-sized batches created and destroyed per frame keep their blocks. */
 int dsp_trim(dsp_handle* h);
 /* Priority of the handle's HIP stream among the queues of the device: 1 = highest, 0 = default, -1 = lowest the device offers.  Where the GPU
  * is shared -- DSP-SLAM runs its detectors on it from the Tracking thread (src/Tracking_util.cc:31-57) while this path runs in the
@@ -131,7 +134,7 @@ int dsp_device_count(void);   /* number of gfx950 devices dsp_create accepts (or
 /* ---- decoder ---------------------------------------------------------------------------------- */
 /* decode_sdf(decoder, lat_vec, x)  -- reconstruct/loss_utils.py:51-79.  pts (n,3) object frame -> sdf (n). */
 int dsp_decode_sdf(dsp_handle* h, const float* code, const float* pts, int64_t n, float* sdf_out);
-/* The same decoder evaluated by the low-precision PREPASS kernel (v_mfma_f32_32x32x16_f16 / _bf16, fp32 accumulation; xyz, code
+/* The same decoder evaluated by the low-precision PREPASS kernel (v_mfma_f32_16x16x32_f16 / _bf16, fp32 accumulation; xyz, code
  * and biases enter at fp32 accuracy, hidden activations are rounded to 16 bits per layer).  Never used for results: the optimiser
  * uses it only to classify ray samples whose occupancy is exactly 0 or 1 (sdf outside the cut-off band by more than a calibrated
  * margin, reconstruct/loss_utils.py:40-48); exposed for calibration and tests. */
@@ -212,40 +215,23 @@ int dsp_batch_create(dsp_handle* h, const dsp_gn_params* prm, int32_t n_objects,
 int dsp_batch_run(dsp_batch* b);        /* resets the state to the uploaded initial estimate, runs, synchronises */
 int dsp_batch_results(dsp_batch* b, float* t_cam_obj_out, float* codes_out, float* loss_out, int32_t* status_out);
 int dsp_batch_stats(dsp_batch* b, dsp_stats* out);
+/* ---- settings (all optional; results are identical, bit for bit, for every value) ------------------------------------------------------ */
 /* Number of front-to-back depth ranges the forward decoder is run in per iteration (exact early ray termination: a ray
  * stops being sampled behind its first solid sample, where the transmittance is exactly 0).  0 = automatic (ten uniform
- * ranges for large batches; otherwise 2-3 per-ray ranges steered by where each ray stopped in the previous iteration); 1 = decode every in-sphere sample like the reference does.  Results are identical
- * for every setting.  With the prepass on (dsp_batch_set_prepass) these are the ranges of the low-precision kernel; the fp32 kernel then
- * runs once per iteration over the samples the prepass could not classify. */
+ * ranges for large batches; otherwise 2-3 per-ray ranges steered by where each ray stopped in the previous iteration); 1 = decode every in-sphere sample like the reference does.
+ * With the prepass on these are the ranges of the low-precision kernel; the fp32 kernel then runs once per iteration over the samples the
+ * prepass could not classify. */
 int dsp_batch_set_ray_passes(dsp_batch* b, int n_passes);
-/* The same with explicit depth-index boundaries: bounds[0] = 0 <= ... <= bounds[n_passes] = num_depth_samples. */
-int dsp_batch_set_ray_pass_bounds(dsp_batch* b, const int32_t* bounds, int n_passes);
 /* Exact low-precision pre-classification of the forward ray samples.  The render term only sees clamp(sdf, -cut_off, cut_off)
  * (reconstruct/loss_utils.py:40-48): occupancy is exactly 0 for sdf >= cut_off and exactly 1 for sdf <= -cut_off.  With the
  * prepass on, every candidate sample is first decoded by an f16 (or bf16) MFMA kernel at 16x the fp32 matrix rate; samples with
  * |sdf_lp| >= cut_off + delta are classified by that value alone, rays stop behind their first certainly-solid sample, and only the
  * samples inside the widened band are decoded by the fp32 kernel (one launch per iteration).  delta must exceed the largest
  * |sdf_lp - sdf_fp32| of the decoder.  The default is calibrated PER DECODER at dsp_create: 6x the largest difference over 32 768 seeded
- * unit-ball points x 2 codes per code magnitude (dsp_prepass_calibration_table), not below 5e-4 (f16) / 3e-3 (bf16) -- dsp_prepass_calibration reports both numbers, the audit below
- * measures the error on the actual workload; results are then identical, bit for bit, to prepass off.
+ * unit-ball points x 2 codes per code magnitude (dsp_prepass_calibration_table), not below 5e-4 (f16) / 3e-3 (bf16); the margin of every
+ * object follows the largest entry of its CURRENT code.
  * mode: -1 automatic (f16 when the decoder geometry is supported), DSP_PREPASS_OFF / _F16 / _BF16; delta < 0 = default. */
 int dsp_batch_set_prepass(dsp_batch* b, int mode, float delta);
-/* Points per workgroup tile of the prepass kernel: 128 (a wave decodes two 16-point column blocks that share every weight fragment: the
- * throughput form) or 64 (one column block: half the tile time).  -1 / 0 = automatic: 64 where an iteration's 128-point tiles would leave
- * more than ~40 % of the CUs without one (one detection of SLAM's real size: ~117 tiles on 256 CUs).  Same arithmetic per point: results
- * are identical for either setting. */
-int dsp_batch_set_prepass_tile(dsp_batch* b, int points);
-/* The calibration dsp_create made for this decoder at a ZERO code: largest |sdf_lp - sdf_fp32| it measured and the margin it derived
- * (DSP_E_STATE when the decoder's geometry has no prepass kernel); the full table follows. */
-int dsp_prepass_calibration(dsp_handle* h, int dtype, float* max_err, float* delta);
-/* The whole calibration: the prepass error grows with the hidden activations, hence with the code, so dsp_create measures it with codes
- * drawn uniformly in +-mag on every entry for mag in {0, 0.15, 0.5, 1, 2} (5 entries each: mags, largest error, margin = max(floor,
- * 6 x largest error up to that magnitude), capped at 0.5).  Every object's margin follows the largest entry of its CURRENT code,
- * piecewise linearly through this table, re-evaluated after every Gauss-Newton step.  guard_err: largest error a guard trip on this
- * handle has reported (the margins returned are already raised to 4 x that).  Any pointer may be NULL. */
-int dsp_prepass_calibration_table(dsp_handle* h, int dtype, float* mags, float* max_err, float* delta, float* guard_err);
-/* Audit: every run also decodes all in-sphere samples in fp32 and fills dsp_stats.prepass_max_err / _misclassified / _audited. */
-int dsp_batch_set_prepass_audit(dsp_batch* b, int on);
 /* The guard is ON by default and costs ~0.3 % more fp32 points: with the prepass on, the fp32 kernel also re-decodes a sample of the
  * samples the prepass classified -- 1/8 of the ring th + delta <= |sdf_lp| < th + 2 delta, where an error between delta and 2 delta would
  * misclassify, 1/512 of everything farther out; a different sample every launch -- and compares EVERY sample it decodes (the whole
@@ -256,83 +242,57 @@ int dsp_batch_set_prepass_audit(dsp_batch* b, int on);
  * (at most 0.125; dsp_prepass_reset_guard undoes it); a margin forced through dsp_batch_set_prepass leaves them alone.
  * on = 0 turns the guard off (tests: what an unguarded run would have returned). */
 int dsp_batch_set_prepass_guard(dsp_batch* b, int on);
-/* Render rows (kept ray samples) need the decoder's input gradient at points the forward launches of the same iteration
- * already decoded.  With mask reuse on, those launches export the relu masks of band samples (|sdf| < cut_off, 512 B each)
- * and the render rows run the backward sweep only, in a launch of their own after the surface points' forward + backward
- * launch.  Off: surface points and render rows share one forward + backward launch.  -1 = automatic (on unless the
- * batch is latency-sized -- fewer surface tiles than a quarter of the CUs -- where the extra launch costs more than the
- * skipped forward), 0 = off, 1 = on.  Results are identical for every setting. */
-int dsp_batch_set_mask_reuse(dsp_batch* b, int mode);
-/* The jacobian launch has a latency form for one or two objects in flight (SLAM's per-detection calls): 16-point tiles whose
- * layer rows are split over the four waves of a workgroup, ~3x shorter per tile than the 64-point throughput form, bit-identical
- * results.  -1 = automatic (on while the 16-point tiles fit a round or two over the CUs and mask reuse is off), 0 = off, 1 = on
- * (ignored while mask reuse is on). */
-int dsp_batch_set_split_rows(dsp_batch* b, int mode);
-/* Small batches: a forward launch of T 64-point tiles takes ceil(T / CUs) rounds and its last round is often nearly empty (one
- * 2000-point object: 312 band tiles on 256 CUs).  With the tail split on, a remainder of at most half a round runs as 16-point
- * latency-form tiles in a launch of its own (~0.3 of a 64-point tile's time).  -1 = automatic (on where the 64-point forward kernel runs
- * without mask export), 0 = off, 1 = on where applicable.  Results are identical for every setting. */
-int dsp_batch_set_tail_split(dsp_batch* b, int mode);
-/* Per-ray bookkeeping (sampling + compaction, band selection, occupancy scan + row compaction): 0 = one thread block per 256 rays with
- * separate count / scan / write launches (throughput form); 1 = fused per object, one workgroup each (3 launches instead of 11 per
- * iteration; round 2); 2 = one WAVE per ray over the whole chip, list segments handed out by running counters instead of scans (round 4:
- * a detection's rays no longer sit on one CU); -1 = automatic (2 for batches of <= 16 objects, else 0).  Results are identical for every
- * setting. */
-int dsp_batch_set_fused_bookkeeping(dsp_batch* b, int mode);
-/* Latency path with the prepass on: the samples the prepass could not classify go straight into the jacobian launch (forward + backward,
- * their sdf scattered back for the occupancy scan) instead of a forward launch of their own -- one decoder launch less per iteration.
- * -1 = automatic (fused bookkeeping on, mask reuse off, surface points + band samples fit one round of 16-point tiles), 0 = off,
- * 1 = on where applicable.  Results are identical for every setting. */
-int dsp_batch_set_speculative_band(dsp_batch* b, int mode);
-/* Testing / forensics: start the following runs from the given camera->object matrices (n_objects x 16, used as they are -- no
- * inversion, so a recorded state of the reference can be injected bit for bit) and / or codes (n_objects x 64); NULL t_obj_cam returns
- * to the uploaded object->camera estimates.  depths (optional, n_objects x 64, needs t_obj_cam): the FIRST iteration samples the rays at
- * exactly these num_depth_samples depths instead of deriving them from the pose (optimizer.py:120-125) -- the reference derives them in
- * fp32 LAPACK / powf arithmetic that can differ from this library's by 1-2 ulp, which is enough to move samples across the render term's
- * thresholds.  dsp_batch_set_iterations changes the iteration count of the following runs. */
-int dsp_batch_set_start_state(dsp_batch* b, const float* t_obj_cam, const float* codes, const float* depths);
-int dsp_batch_set_iterations(dsp_batch* b, int32_t n);
-/* Testing / forensics: iteration e < n_iterations of the following runs samples the rays at depths[(e * n_objects + i) * 64 ..] instead of
- * the depths derived from the pose (n_iterations = 0 turns the schedule off).  The reference derives the 50 depths from torch.inverse /
- * torch.det / pow / linspace in float32 (optimizer.py:120-125), whose last bit depends on the LAPACK library; feeding the depths it
- * RECORDED isolates that source of threshold flips from the decoder's own round-off in chained comparisons. */
-int dsp_batch_set_depth_schedule(dsp_batch* b, const float* depths, int32_t n_iterations);
-/* Testing / forensics: the per-sample arrays the LAST iteration of the last run left behind for object obj, expanded to
- * (n_rays x num_depth_samples) grids: raymask (n_rays; bit j = sample j lies inside the unit sphere), ssdf (the sdf the occupancy
- * scan read: fp32 inside the band, the prepass value or the placeholder 1.0 elsewhere; NaN = not in the sphere), sdeds (de_ds of a kept
- * sample, 0 = not kept, NaN = not in the sphere).  cap = floats available in ssdf / sdeds (>= n_rays * num_depth_samples). */
-int dsp_batch_debug_samples(dsp_batch* b, int32_t obj, uint64_t* raymask, float* ssdf, float* sdeds, int64_t cap);
-/* Mask reuse in the latency path ("mixed" form, round 4): where the jacobian launch runs 16-point latency-form tiles and the list is too long
- * for the speculative band rows (one cfg2-size object), the forward launch exports the relu masks of its band samples and the kept render
- * rows run the backward sweep only -- as tiles of the SAME launch as the surface points' forward + backward tiles.  -1 = automatic (on),
- * 0 = off, 1 = on where applicable; dsp_batch_set_mask_reuse(b, 0) turns every form of mask reuse off.  Results are identical for every
- * setting. */
-int dsp_batch_set_mixed_reuse(dsp_batch* b, int mode);
-/* Latency form of the jacobian launch, one step further: a list of at most 128 tiles of 16 points (a detection of SLAM's real size has
- * 40-60) runs with FOUR workgroups per tile -- the rows of every layer split over their 16 waves, the layer's result handed round the
- * cluster through L2 after every pass -- so that a detection occupies ~240 CUs instead of ~60.  Longer lists keep one workgroup per tile.
- * -1 = automatic (on wherever the latency form is), 0 = off, 1 = on where applicable.  Results are identical for every setting.
- * The four workgroups of a cluster wait for each other with spins bounded to 2 ms; on a GPU shared with other work (DSP-SLAM's detectors
- * run on it from the Tracking thread, src/Tracking_util.cc:31-57) a member may be scheduled late: the launch then falls back to one
- * workgroup per tile ON THE DEVICE (dsp_stats.cluster_fallback), results unchanged. */
-int dsp_batch_set_cluster_tiles(dsp_batch* b, int mode);
-/* A batch of ONE object in the wave-per-ray bookkeeping form: the decoder kernels derive their tile lists from the object's counters
- * themselves instead of reading lists a single-workgroup kernel built in front of them (two launches less per iteration of a
- * detection).  -1 = automatic (on), 0 = off, 1 = on.  Same tiles, same results. */
-int dsp_batch_set_direct_tiles(dsp_batch* b, int mode);
-/* The 71 x 71 (pose-only: 6 x 6) normal equations are solved in fp64 on the device, pivot-free (H of optimizer.py:161-184 is symmetric
- * positive definite): 3 = rows in lanes, columns in the registers of nine waves, the right-hand side as one more column, elimination
- * above and below the pivot, ONE barrier per panel of eight pivots (default); 2 = the same arithmetic with one barrier per pivot
- * (round 4; bit-identical to 3); 0 = LDL^T with the packed triangle in the registers of eight waves + a back substitution; 1 = the
- * Gauss-Jordan kernel of rounds 2-3.  0-2 are kept as A/B references; dx agrees to ~1e-12 relative among all of them. */
-int dsp_batch_set_solver(dsp_batch* b, int mode);
 /* HIP events around every decoder launch, i.e. the dsp_stats.ms_mlp_* fields: -1 = automatic (on for batches of more than 16 objects --
  * the bench's roofline needs them; off for latency-sized batches, where an event record between two kernels is a queue packet of its own),
  * 0 = off, 1 = on.  Launch COUNTS and ms_total are filled either way. */
 int dsp_batch_set_kernel_timing(dsp_batch* b, int mode);
+/* The iteration count of the following runs (instead of dsp_gn_params.num_iterations / pose_only_iterations given at creation). */
+int dsp_batch_set_iterations(dsp_batch* b, int32_t n);
+/* The calibration dsp_create made for this decoder at a ZERO code: largest |sdf_lp - sdf_fp32| it measured and the margin it derived
+ * (DSP_E_STATE when the decoder's geometry has no prepass kernel); the full table follows. */
+int dsp_prepass_calibration(dsp_handle* h, int dtype, float* max_err, float* delta);
+/* The whole calibration: the prepass error grows with the hidden activations, hence with the code, so dsp_create measures it with codes
+ * drawn uniformly in +-mag on every entry for mag in {0, 0.15, 0.5, 1, 2} (5 entries each: mags, largest error, margin = max(floor,
+ * 6 x largest error up to that magnitude), capped at 0.5).  Every object's margin follows the largest entry of its CURRENT code,
+ * piecewise linearly through this table, re-evaluated after every Gauss-Newton step.  guard_err: largest error a guard trip on this
+ * handle has reported (the margins returned are already raised to 4 x that).  Any pointer may be NULL. */
+int dsp_prepass_calibration_table(dsp_handle* h, int dtype, float* mags, float* max_err, float* delta, float* guard_err);
 /* Forget what earlier guard trips on this handle have left behind (dsp_prepass_calibration_table: guard_err): the margins return to the
  * decoder's calibration. */
 int dsp_prepass_reset_guard(dsp_handle* h);
+
+/* ---- testing: ONE door for the forms the library chooses between by itself -----------------------------------------------------------
+ * The launch sequence has several bit-identical forms per stage, chosen from the batch's size.  Tests pin a form to
+ * compare it with the one it replaces; an integrator has no reason to.  value: -1 automatic, 0 off, 1 on where applicable, unless noted. */
+#define DSP_DBG_MASK_REUSE 1        /* render rows run the backward sweep only, from relu masks the forward launches exported (throughput form: a launch of their own) */
+#define DSP_DBG_SPLIT_ROWS 2        /* latency form of the decoder launches: 16-point tiles, a layer's rows split over the four waves */
+#define DSP_DBG_TAIL_SPLIT 3        /* the last, at most half-empty round of a 64-point forward launch as 16-point tiles in a launch of its own */
+#define DSP_DBG_WAVE_BOOKKEEPING 4  /* per-ray bookkeeping as one wave per ray with running counters (1) instead of count / scan / write launches (0) */
+#define DSP_DBG_SPECULATIVE_BAND 5  /* prepass on: unclassified samples go straight into the jacobian launch (no forward launch of their own) */
+#define DSP_DBG_MIXED_REUSE 6       /* mask reuse inside the latency form: backward-only tiles in the same launch as the surface points' tiles */
+#define DSP_DBG_CLUSTER_TILES 7     /* cluster form of the jacobian launch: four workgroups per 16-point tile (lists of <= 128 tiles); 1 also bypasses the handle's cool-down */
+#define DSP_DBG_DIRECT_TILES 8      /* one-object batches: the decoder kernels derive their tile lists themselves */
+#define DSP_DBG_PREPASS_TILE 9      /* value = 128 or 64 points per prepass tile, -1 / 0 automatic */
+#define DSP_DBG_PREPASS_AUDIT 10    /* value != 0: every run also decodes all in-sphere samples in fp32 and fills dsp_stats.prepass_max_err / _misclassified / _audited */
+#define DSP_DBG_CLUSTER_FAULT 11    /* value != 0: the following runs' cluster launches lose one workgroup's hand-off (the device-side fallback takes over); 0 also ends the cool-down */
+int dsp_batch_set_debug(dsp_batch* b, int key, int value);
+/* Forensics: front-to-back ranges with explicit depth-index boundaries: bounds[0] = 0 <= ... <= bounds[n_passes] = num_depth_samples. */
+int dsp_batch_debug_ray_pass_bounds(dsp_batch* b, const int32_t* bounds, int n_passes);
+/* Forensics: start the following runs from the given camera->object matrices (n_objects x 16, used as they are -- no
+ * inversion, so a recorded state of the reference can be injected bit for bit) and / or codes (n_objects x 64); NULL t_obj_cam returns
+ * to the uploaded object->camera estimates.  depths (optional, n_objects x 64, needs t_obj_cam): the FIRST iteration samples the rays at
+ * exactly these num_depth_samples depths instead of deriving them from the pose (optimizer.py:120-125) -- the reference derives them in
+ * fp32 LAPACK / powf arithmetic that can differ from this library's by 1-2 ulp, which is enough to move samples across the render term's
+ * thresholds. */
+int dsp_batch_debug_start_state(dsp_batch* b, const float* t_obj_cam, const float* codes, const float* depths);
+/* Forensics: iteration e < n_iterations of the following runs samples the rays at depths[(e * n_objects + i) * 64 ..] instead of
+ * the depths derived from the pose (n_iterations = 0 turns the schedule off). */
+int dsp_batch_debug_depth_schedule(dsp_batch* b, const float* depths, int32_t n_iterations);
+/* Forensics: the per-sample arrays the LAST iteration of the last run left behind for object obj, expanded to
+ * (n_rays x num_depth_samples) grids: raymask (n_rays; bit j = sample j lies inside the unit sphere), ssdf (the sdf the occupancy
+ * scan read: fp32 inside the band, the prepass value or the placeholder 1.0 elsewhere; NaN = not in the sphere), sdeds (de_ds of a kept
+ * sample, 0 = not kept, NaN = not in the sphere).  cap = floats available in ssdf / sdeds (>= n_rays * num_depth_samples). */
+int dsp_batch_debug_samples(dsp_batch* b, int32_t obj, uint64_t* raymask, float* ssdf, float* sdeds, int64_t cap);
 /* Testing: the Lie-group maps and the rotation prior evaluated ON THE DEVICE by the very functions the solve kernel calls (one thread, same
  * fp32 / fp64 arithmetic), so that every branch can be compared with vectors recorded from the reference:
  *   kind 0: x[7]  -> out[16] = exp_sim3(x)   -- reconstruct/loss_utils.py:188-233 (theta <= 1e-8 / s == 0 branch :211-218, the
@@ -340,10 +300,13 @@ int dsp_prepass_reset_guard(dsp_handle* h);
  *   kind 1: x[6]  -> out[16] = exp_se3(x)    -- reconstruct/loss_utils.py:129-163
  *   kind 2: x[16] = t_obj_cam -> out[0..6] = J_rot, out[7] = res_rot (compute_rotation_loss_sim3, reconstruct/loss.py:155-178, zero branch
  *           :172-173), out[8] = scale = det(R_co)^(1/3), out[9], out[10] = the depth range t_z -+ scale (reconstruct/optimizer.py:120-125),
- *           out[11] = status (DSP_OBJ_NAN for a singular matrix)
+ *           out[11] = status (DSP_OBJ_NAN for a singular matrix: the other entries are then zero)
  *   kind 3: x[0..15] = t_obj_cam, x[16..22] = dx -> out[16] = exp_sim3(dx) @ t_obj_cam  (the update of reconstruct/optimizer.py:187-188)
  * n_depth = num_depth_samples (2..64; only kind 2 reads it). */
 int dsp_debug_lie(dsp_handle* h, int kind, const float* x, int32_t n_depth, float* out16);
+/* Testing: the (n + 1)-th fresh device allocation the handle's pool makes from now on fails as if HBM were exhausted (n < 0: off).  The call
+ * that hits it returns DSP_E_NOMEM with nothing of its half-built batch left allocated; the handle stays usable. */
+int dsp_debug_fail_alloc(dsp_handle* h, int n);
 /* Record per-iteration traces during the following runs (testing; costs ~21 KB per object-iteration). */
 int dsp_batch_enable_trace(dsp_batch* b, int on);
 /* Per-iteration trace of the last run (testing): for iteration e < num_iterations and object i,

@@ -25,7 +25,10 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), "libdspgn.so does not export %s" % n
     bound = {n for n, _, _ in L.SYMBOLS}
     assert set(names) <= bound, "ctypes binding misses %s" % (set(names) - bound)
-    assert lib.dsp_abi_version() == 5    # 2: dsp_stats grew the prepass fields; 3: the guard fields; 4: solver / kernel-timing setters, partial guard re-run; 5: dsp_debug_lie, dsp_trim, cluster time-out
+    assert lib.dsp_abi_version() == L.ABI_VERSION == 6    # 2: dsp_stats grew the prepass fields; 3: the guard fields; 4: kernel-timing setter, partial guard re-run; 5: dsp_debug_lie, dsp_trim, cluster time-out; 6: batch tokens, five setters + dsp_batch_set_debug
+    setters = [n for n in names if n.startswith("dsp_batch_set_")]
+    assert sorted(setters) == ["dsp_batch_set_debug", "dsp_batch_set_iterations", "dsp_batch_set_kernel_timing", "dsp_batch_set_prepass", "dsp_batch_set_prepass_guard",
+                               "dsp_batch_set_ray_passes"], setters
 
 
 def test_gfx950_code_object_present():

@@ -349,35 +349,6 @@ def test_tail_split_is_exact(eng):
                 len(objs), prepass, out[0][2]["ms_mlp_fwd"], out[1][2]["ms_mlp_fwd"]))
 
 
-def test_fused_bookkeeping_is_exact(eng):
-    """The per-object fused bookkeeping kernels (latency form) and the per-ray launches (throughput form) call the same device
-    functions: every bit of every iteration must agree, with and without the prepass, including an object that fails."""
-    prm = E.gn_params(num_iterations=4)
-    objs = synth.make_batch(5, first_seed=980, n_surface=300, n_background=90)
-    bad = synth.make_object(985, 60, 20)
-    bad["t_cam_obj_init"] = bad["t_cam_obj_init"].copy()
-    bad["t_cam_obj_init"][:3, 3] += 500.0
-    objs.insert(2, bad)
-    args = ([o["t_cam_obj_init"] for o in objs], [o["pts"] for o in objs], [o["rays"] for o in objs], [o["depth"] for o in objs])
-    for prepass in (0, 1):
-        out = {}
-        for fused in (0, 1):
-            b = eng.batch(prm, *args, trace=True)
-            b.set_prepass(prepass)
-            b.set_fused_bookkeeping(fused)
-            b.run()
-            out[fused] = (b.results(), [b.trace(e) for e in range(4)], b.stats())
-            b.close()
-        assert list(out[0][0][3]) == [0, 0, 1, 0, 0, 0]
-        for a, c in zip(out[0][0], out[1][0]):
-            assert np.array_equal(a, c)
-        good = np.array([0, 1, 3, 4, 5])        # the failed object's trace rows are never written
-        for ta, tc in zip(out[0][1], out[1][1]):
-            for k in ("H", "b", "dx", "V", "m", "K", "set_sums"):
-                assert np.array_equal(ta[k][good], tc[k][good]), (prepass, k)
-        assert out[0][2]["n_fwd_points"] == out[1][2]["n_fwd_points"] and out[0][2]["n_jac_points"] == out[1][2]["n_jac_points"]
-
-
 def test_speculative_band_rows_are_exact(eng, oracle_decoder):
     """Latency path: the samples the prepass could not classify go straight into the jacobian launch (forward + backward, sdf
     scattered back) and the Gram kernel picks the kept rows' gradients up where that launch left them -- every bit of every

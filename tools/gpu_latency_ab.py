@@ -34,13 +34,12 @@ for name, (M, Bg) in (("KITTI-size 250+200", (250, 200)), ("cfg2-size 2000+500",
     variants = [("automatic (cluster tiles, wave bookkeeping, rows-in-lanes solve, no events)    ", {}),
                 ("one workgroup per jacobian tile (cluster form off)", dict(cluster_tiles=0)),
                 ("render rows repeat their forward sweep (mixed mask reuse off)", dict(mixed_reuse=0)),
-                ("fused per-object bookkeeping (round 3)", dict(fused_bookkeeping=1)),
-                ("throughput bookkeeping", dict(fused_bookkeeping=0)),
-                ("solve with one barrier per pivot (round 4) instead of one per panel of eight", dict(solver=2)),
-                ("packed LDL^T solve (first round-4 form)", dict(solver=0)),
-                ("Gauss-Jordan solve (round 3)", dict(solver=1)),
+                ("throughput bookkeeping", dict(wave_bookkeeping=0)),
                 ("per-kernel events on", dict(kernel_timing=1)),
-                ("round-3 equivalent: fused=1 (or 0 for large), GJ, events on, no clusters", dict(fused_bookkeeping=1 if M == 250 else 0, solver=1, kernel_timing=1, cluster_tiles=0, mixed_reuse=0)),
+                ("no speculative band rows", dict(speculative_band=0)),
+                ("tile lists built by k_build_tiles (direct tiles off)", dict(direct_tiles=0)),
+                # (the per-object fused bookkeeping and the earlier solver kernels were measured in rounds 3-5 -- profiles/r04_latency_ab.md,
+                #  profiles/r05_latency_ab.md -- and left the library in round 6: profiles/r06_removed_experiments.md)
                 ("prepass off", dict(prepass=0))]
     ref = None
     for label, kw in variants:
