@@ -86,7 +86,6 @@ struct MlpArgs {
     int split_len[4];           //   chunks wave w consumes per tile (forward + backward)
     int split_len_fwd[4];       //   ... of which the forward passes (a prefix of the wave's stream)
     unsigned long long* clk;    // optional: block 0 writes {clock64, wall_clock64} at entry and exit (effective shader clock)
-    float* dbg;                 // development aid: [pass][wave][128][64] slab dump of tile 0 (nullptr = off)
     // cluster form (mlp_cluster_kernel.hip): four workgroups per 16-point tile, layer rows split over their 16 waves
     const float* wcluster;      //   the same chunks laid out per wave slot (two row tiles, two k-steps per 16-byte element; pack_decoder)
     int cl_off[16];             //   first 4 KiB mini-chunk of wave slot u inside wcluster
@@ -310,7 +309,6 @@ void launch_inlier_filter(const ObjConst* oc, ObjState* st, const float* jgrad, 
 constexpr int DSP_RESULT_WIDTH_DEV = 82;   // == DSP_RESULT_WIDTH (dsp_gn.h): t_cam_obj 16 | code 64 | loss | status
 void launch_finalize(ObjState* st, const float* scale, int B, int pose_only, float* packed, unsigned* guard_out /*optional B x 3*/, hipStream_t s);
 
-hipError_t debug_solve_clocks(unsigned long long* out8);
 hipError_t launch_debug_lie(int kind, const float* x_dev, float* out_dev, int n_depth, hipStream_t s);   // testing: exp_sim3 / exp_se3 / rotation prior as k_solve evaluates them
 
 // ---- mesh extraction (mesh_kernels.hip) ---------------------------------------------------------

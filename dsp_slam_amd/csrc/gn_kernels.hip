@@ -667,7 +667,11 @@ __global__ __launch_bounds__(256) void k_render_scan(const ObjConst* oc, ObjStat
     du = __fadd_rn(du, __fmul_rn(d_bg, lane_value(Tj, n_depth - 1)));
     const float obs = (r < c.n_fg) ? depth_fg[c.depth_off + r] : d_bg;   // optimizer.py:126
     float res = __fsub_rn(obs, du);
-    res = fminf(fmaxf(res, -0.30f), 0.30f);                               // loss.py:139-140
+    // loss.py:139-140 as written there -- `res_d[res_d > 0.30] = 0.30; res_d[res_d < -0.30] = -0.30` -- NOT fminf / fmaxf: a NaN residual (a NaN
+    // observed depth) compares false twice and stays NaN, the render loss turns NaN and the object fails (optimizer.py:149-150); fminf / fmaxf
+    // would turn it into a valid 0.30 (found by tests/test_gpu_errors.py).  Identical bits for every finite or infinite residual.
+    res = res > 0.30f ? 0.30f : res;
+    res = res < -0.30f ? -0.30f : res;
     // de_do_k = sum_{l>=k} T_l / (1 - o_k), the suffix sums accumulated back to front; keep > 1e-2;
     // de_ds = de_do * delta_d * (-1/(2 th))  (loss.py:118-130)
     float Sj = 0.f, sacc = 0.f;
@@ -1214,8 +1218,6 @@ __device__ void rotation_prior(const float* t_co, float scale, float* jrot, floa
 
 constexpr int NSOLVE = 71;
 
-__device__ unsigned long long g_solve_clk[8];   // development aid: wall_clock64 (100 MHz) stamps of object 0's last k_solve
-
 // per-slice Gram partials -> one fp64 Gram matrix per (object, term); fixed summation order
 __global__ __launch_bounds__(256) void k_gram_reduce(const ObjState* st, const float* partials, int n_slices, double* gsum) {
     const int b = blockIdx.y, term = blockIdx.z;
@@ -1249,8 +1251,6 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
                                                float* trace /*nullable*/, const float* depths_next /*nullable: forensics*/, int n_obj) {
     __shared__ double A[NS1][NS1 + 1];          // [H | b] in rows 0..n-1 (b = column n); b is also kept as ROW n (rows 64 .. 71 are one register of the elimination)
     const int b = blockIdx.x, tid = threadIdx.x;
-    const bool stamp = (b == 0 && tid == 0);
-    if (stamp) g_solve_clk[0] = wall_clock64();
     const ObjConst c = oc[b];
     ObjState& s = st[b];
     // Everything this launch reads from global memory goes out HERE, before the first of it is waited for -- the status word included
@@ -1342,7 +1342,6 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
         }
     }
     __syncthreads();
-    if (stamp) { g_solve_clk[1] = wall_clock64(); g_solve_clk[5] = clock64(); }
     if (trace) {   // [iter][obj][71*71 H | 71 b | 71 dx | 16 t_oc | 64 code | V m K]
         float* tr = trace + ((size_t)iter * n_obj + b) * TRACE_STRIDE;
         for (int e = tid; e < n * n; e += SOLVE_THREADS) tr[(e / n) * NSOLVE + (e % n)] = (float)A[e / n][e % n];
@@ -1492,9 +1491,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
         }
         }
         __syncthreads();
-        if (stamp) g_solve_clk[7] = wall_clock64();
         if (s_sing) { if (tid == 0) s.status = DSP_STATUS_NAN; return; }      // uniform
-        if (stamp) { g_solve_clk[2] = wall_clock64(); g_solve_clk[6] = clock64(); }
         __syncthreads();
     }
     if (trace) {
@@ -1539,7 +1536,6 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
             s.vsum = 0; s.ksum = 0;
             s.V = 0; s.P = 0;      // the wave-per-ray bookkeeping counts into these (k_front_wave, k_band_wave); the scans of the other forms overwrite them
         }
-        if (stamp) g_solve_clk[3] = wall_clock64();
         if (!prm.pose_only) {
             const IterDerived r = derive_iter_core(nt, prm.n_depth);
             if (!r.ok) {
@@ -1559,7 +1555,6 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const ObjConst* oc, Obj
                 }
             }
         }
-        if (stamp) g_solve_clk[4] = wall_clock64();
     }
     // 4. the next iteration's per-object code bias (k_code_bias: same k-ordered fmaf chains), by the waves that are not busy with the pose
     if (!prm.pose_only && cbias && tid >= 128) {
@@ -1744,10 +1739,6 @@ void launch_inlier_filter(const ObjConst* oc, ObjState* st, const float* jgrad, 
 }
 void launch_finalize(ObjState* st, const float* scale, int B, int pose_only, float* packed, unsigned* guard_out, hipStream_t s) {
     hipLaunchKernelGGL(k_finalize, dim3((B + 63) / 64), dim3(64), 0, s, st, scale, B, pose_only, packed, guard_out);
-}
-
-hipError_t debug_solve_clocks(unsigned long long* out8) {
-    return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_solve_clk), 64);
 }
 
 // Testing (dsp_debug_lie): the Lie-group maps and the rotation prior exactly as k_solve evaluates them -- ONE thread, the same device

@@ -30,7 +30,7 @@ __device__ __forceinline__ void push_mask_bit(unsigned& bits, float x) {
 // |sdf| < th -- the candidates of the render term.  MODE 2: forward + backward (input gradient).  MODE 3: backward only,
 // from the masks and sdf a MODE 1 launch exported for the same point and code (the render rows of the jacobian: their
 // forward pass is not repeated).
-template <int MODE, bool DBG>
+template <int MODE>
 __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
     constexpr bool BWD = MODE >= 2;        // runs the backward sweep
     constexpr bool MASKS = MODE != 0;      // relu masks live in LDS
@@ -324,13 +324,6 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
                 }
             }
 
-            if (DBG && tile == 0) {   // development aid: dump the output slab of every pass of tile 0
-                float* dp = a.dbg + ((size_t)(ps * 4 + wave) * 128) * 64 + lane;
-#pragma unroll
-                for (int i = 0; i < 128; ++i) dp[i * 64] = sin_[i];
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-
             if (DOFWD && ps == a.n_fwd - 1) {
                 // final layer (512 -> 1) on the VALU + tanh  (deep_sdf_decoder.py:93,107-108)
                 const float* wl = bias_l + a.wlast_row * WIDTH + 4 * g;
@@ -400,38 +393,33 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpArgs a) {
     if (a.clk && blockIdx.x == 0 && tid == 0) { a.clk[2] = clock64(); a.clk[3] = wall_clock64(); }
 }
 
-template __global__ void mlp_kernel<0, false>(const MlpArgs);
-template __global__ void mlp_kernel<1, false>(const MlpArgs);
-template __global__ void mlp_kernel<2, false>(const MlpArgs);
-template __global__ void mlp_kernel<2, true>(const MlpArgs);
-template __global__ void mlp_kernel<3, false>(const MlpArgs);
+template __global__ void mlp_kernel<0>(const MlpArgs);
+template __global__ void mlp_kernel<1>(const MlpArgs);
+template __global__ void mlp_kernel<2>(const MlpArgs);
+template __global__ void mlp_kernel<3>(const MlpArgs);
 
 size_t mlp_lds_bytes(int mode) { return BIAS_BYTES + CODEBIAS_BYTES + (mode != 0 ? MASK_BYTES : 0) + NBUF * CHUNK_BYTES; }
 
 // Opt every kernel variant into > 64 KiB of dynamic LDS on the current device (called by dsp_create).
 hipError_t mlp_prepare_device() {
-    const void* fns[5] = {reinterpret_cast<const void*>(&mlp_kernel<0, false>), reinterpret_cast<const void*>(&mlp_kernel<1, false>),
-                          reinterpret_cast<const void*>(&mlp_kernel<2, false>), reinterpret_cast<const void*>(&mlp_kernel<2, true>),
-                          reinterpret_cast<const void*>(&mlp_kernel<3, false>)};
-    const int modes[5] = {0, 1, 2, 2, 3};
-    for (int i = 0; i < 5; ++i) {
-        const hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlp_lds_bytes(modes[i]));
+    const void* fns[4] = {reinterpret_cast<const void*>(&mlp_kernel<0>), reinterpret_cast<const void*>(&mlp_kernel<1>),
+                          reinterpret_cast<const void*>(&mlp_kernel<2>), reinterpret_cast<const void*>(&mlp_kernel<3>)};
+    for (int i = 0; i < 4; ++i) {
+        const hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlp_lds_bytes(i));
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
 }
 
 hipError_t launch_mlp(int mode, const MlpArgs& args, int n_blocks, hipStream_t stream) {
-    if (args.dbg)
-        hipLaunchKernelGGL((mlp_kernel<2, true>), dim3(n_blocks), dim3(256), mlp_lds_bytes(2), stream, args);
-    else if (mode == 0)
-        hipLaunchKernelGGL((mlp_kernel<0, false>), dim3(n_blocks), dim3(256), mlp_lds_bytes(0), stream, args);
+    if (mode == 0)
+        hipLaunchKernelGGL((mlp_kernel<0>), dim3(n_blocks), dim3(256), mlp_lds_bytes(0), stream, args);
     else if (mode == 1)
-        hipLaunchKernelGGL((mlp_kernel<1, false>), dim3(n_blocks), dim3(256), mlp_lds_bytes(1), stream, args);
+        hipLaunchKernelGGL((mlp_kernel<1>), dim3(n_blocks), dim3(256), mlp_lds_bytes(1), stream, args);
     else if (mode == 2)
-        hipLaunchKernelGGL((mlp_kernel<2, false>), dim3(n_blocks), dim3(256), mlp_lds_bytes(2), stream, args);
+        hipLaunchKernelGGL((mlp_kernel<2>), dim3(n_blocks), dim3(256), mlp_lds_bytes(2), stream, args);
     else
-        hipLaunchKernelGGL((mlp_kernel<3, false>), dim3(n_blocks), dim3(256), mlp_lds_bytes(3), stream, args);
+        hipLaunchKernelGGL((mlp_kernel<3>), dim3(n_blocks), dim3(256), mlp_lds_bytes(3), stream, args);
     return hipGetLastError();
 }
 

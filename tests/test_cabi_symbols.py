@@ -68,7 +68,7 @@ def test_isa_assumptions_hold_on_the_built_code_objects():
     rep = B.check_isa()
     assert rep["m0_writes"] > 250 and rep["lds_dma_loads"] >= 1200
     fp32 = [k for k in rep["kernels"] if "mlp_kernelILi" in k]
-    assert len(fp32) == 5 and all(rep["kernels"][k]["private_segment_fixed_size"] == 0 for k in fp32)
+    assert len(fp32) == 4 and all(rep["kernels"][k]["private_segment_fixed_size"] == 0 for k in fp32)
     assert b"ISA assumptions checked at build time" in L.load().dsp_build_info()
 
 

@@ -27,7 +27,10 @@ def _args(o):
     return ([o["t_cam_obj_init"]], [o["pts"]], [o["rays"]], [o["depth"]])
 
 
-@pytest.mark.parametrize("co_points,priority", [(16384, 0), (16384, 1), (100000, 0)])
+# (The highest stream priority was a parameter of this test in round 5: it changed nothing on average -- p50 10.1 against 9.9 ms -- and one run
+# of 50 detections had outliers of 54 and 93 ms where the default had p99 13.4 ms: a detection's kernels are short and dependent, what they wait for
+# is a co-tenant WORKGROUP leaving a CU, not the queue arbiter.  Measured, documented in profiles/r05_latency_cotenant.md, not asserted.)
+@pytest.mark.parametrize("co_points,priority", [(16384, 0), (100000, 0)])
 def test_detections_beside_a_cu_saturating_cotenant(oracle_decoder, co_points, priority):
     eng = E.Engine(oracle_decoder.layers, oracle_decoder.latent_in, oracle_decoder.code_len, device=0)
     if priority:
@@ -88,10 +91,14 @@ def test_detections_beside_a_cu_saturating_cotenant(oracle_decoder, co_points, p
                solo_p50_ms=solo_p50, shared_p50_ms=p50, shared_p99_ms=p99, shared_max_ms=worst, runs=len(shared), fallback_runs=int(fallbacks),
                runs_with_cluster_tiles=int(cluster_runs), cotenant_launches=int(launches[0]))
     assert launches[0] > 0
-    # no stall: a detection is ~110 kernel launches; each can queue behind at most the co-tenant's launch in flight, and a lost hand-off
-    # costs 2 ms once per run (then the handle's cool-down keeps the cluster form off).  Round 4's bound was ~1 s per lost hand-off.
-    co_ms = 1.0 if co_points <= 16384 else 8.0
-    assert worst < solo_p50 + 110 * co_ms + 50.0, (worst, solo_p50)
+    # Bounds that a regression CAN break (measured on two boxes, profiles/r05_latency_cotenant.md: 1 ms co-tenant p50 2.4-3.0 x solo, p99 2.9-3.4 x;
+    # 6 ms persistent co-tenant p50 5.0-5.6 x, max 5.4-6.3 x).  A lost hand-off costs 2 ms once per run (then the cool-down keeps the cluster form
+    # off); round 4's ~1 s stall per lost hand-off, or a detection queueing behind EVERY co-tenant launch instead of the one in flight, is far outside.
+    if co_points <= 16384:
+        assert p99 <= 4.0 * solo_p50, (p99, solo_p50)
+        assert fallbacks <= 1, fallbacks                       # (none in any measured run)
+    else:
+        assert p50 <= 7.0 * solo_p50 and worst <= 10.0 * solo_p50, (p50, worst, solo_p50)
     for b in batches:
         b.close()
     eng.close()
