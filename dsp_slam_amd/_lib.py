@@ -21,6 +21,7 @@ GRAD_DIM = 67
 OBJ_GOOD, OBJ_FEW_SAMPLES, OBJ_NAN = 0, 1, 2
 PREPASS_OFF, PREPASS_F16, PREPASS_BF16 = 0, 1, 2
 PREPASS_SMALL_TILES = 0x100
+COMPUTE_F32, COMPUTE_F16, COMPUTE_BF16 = 0, 1, 2
 # keys of dsp_batch_set_debug (include/dsp_gn.h: DSP_DBG_*)
 (DBG_MASK_REUSE, DBG_SPLIT_ROWS, DBG_TAIL_SPLIT, DBG_WAVE_BOOKKEEPING, DBG_SPECULATIVE_BAND, DBG_MIXED_REUSE, DBG_CLUSTER_TILES, DBG_DIRECT_TILES,
  DBG_PREPASS_TILE, DBG_PREPASS_AUDIT, DBG_CLUSTER_FAULT) = range(1, 12)
@@ -71,6 +72,7 @@ SYMBOLS = [
     ("dsp_decode_sdf_multi", C.c_int, [_VP, c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p]),
     ("dsp_decode_sdf_prepass", C.c_int, [_VP, C.c_int, c_f32p, c_f32p, C.c_int64, c_f32p]),
     ("dsp_debug_pack_prepass", C.c_int, [C.POINTER(DecoderDesc), C.c_int, C.POINTER(C.c_uint16), c_i64p, c_i32p, c_i32p]),
+    ("dsp_debug_pack_lpj", C.c_int, [C.POINTER(DecoderDesc), C.c_int, C.POINTER(C.c_uint16), c_i64p, c_i32p, c_i32p]),
     ("dsp_sdf_jacobian", C.c_int, [_VP, c_f32p, c_f32p, C.c_int64, c_f32p, c_f32p]),
     ("dsp_compute_sdf_loss", C.c_int, [_VP, c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p]),
     ("dsp_compute_render_loss", C.c_int, [_VP, c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_int32, c_f32p, C.c_float,
@@ -88,6 +90,8 @@ SYMBOLS = [
     ("dsp_batch_set_prepass_guard", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_set_kernel_timing", C.c_int, [_VP, C.c_int]),
     ("dsp_batch_set_iterations", C.c_int, [_VP, C.c_int32]),
+    ("dsp_batch_set_compute", C.c_int, [_VP, C.c_int]),
+    ("dsp_sdf_jacobian_lp", C.c_int, [_VP, C.c_int, c_f32p, c_f32p, C.c_int64, c_f32p, c_f32p]),
     ("dsp_batch_set_debug", C.c_int, [_VP, C.c_int, C.c_int]),
     ("dsp_prepass_calibration", C.c_int, [_VP, C.c_int, c_f32p, c_f32p]),
     ("dsp_prepass_calibration_table", C.c_int, [_VP, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p]),

@@ -9,8 +9,9 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libdspgn.so")
-SOURCES = ["mlp_kernel.hip", "mlp_split_kernel.hip", "mlp_cluster_kernel.hip", "mlp_lp_kernel.hip", "gn_kernels.hip", "mesh_kernels.hip", "dsp_gn.hip", "pose_graph.cpp"]
-HEADERS = [os.path.join(CSRC, "dsp_internal.h"), os.path.join(CSRC, "mlp_common.h"), os.path.join(ROOT, "include", "dsp_gn.h"),
+SOURCES = ["mlp_kernel.hip", "mlp_split_kernel.hip", "mlp_cluster_kernel.hip", "mlp_lp_kernel.hip", "mlp_lpj_kernel.hip", "gn_kernels.hip", "mesh_kernels.hip", "dsp_gn.hip",
+           "pose_graph.cpp"]
+HEADERS = [os.path.join(CSRC, "dsp_internal.h"), os.path.join(CSRC, "mlp_common.h"), os.path.join(CSRC, "mlp_lp_common.h"), os.path.join(ROOT, "include", "dsp_gn.h"),
            os.path.join(ROOT, "include", "dsp_pose_graph.h")]
 
 
@@ -65,7 +66,8 @@ def _compile_one(hipcc, src, verbose):
 # A different hipcc may break any of them silently (wrong results for M0, a 10x slowdown for scratch), so the build FAILS instead.
 OBJDUMP_CANDIDATES = ("/opt/rocm/lib/llvm/bin/llvm-objdump", "/opt/rocm/llvm/bin/llvm-objdump")
 READELF_CANDIDATES = ("/opt/rocm/lib/llvm/bin/llvm-readelf", "/opt/rocm/llvm/bin/llvm-readelf")
-NO_SCRATCH_KERNELS = ("mlp_kernelILi0", "mlp_kernelILi1", "mlp_kernelILi2", "mlp_kernelILi3", "mlp_split_kernel", "mlp_cluster_kernel", "mlp_lp_kernelILb0")
+NO_SCRATCH_KERNELS = ("mlp_kernelILi0", "mlp_kernelILi1", "mlp_kernelILi2", "mlp_kernelILi3", "mlp_split_kernel", "mlp_cluster_kernel", "mlp_lp_kernelILb0",
+                      "mlp_lpj_fwd_kernel", "mlp_lpj_bwd_kernel")
 
 
 class IsaCheckError(RuntimeError):
@@ -81,7 +83,7 @@ def check_isa(verbose=False):
     if not objdump or not readelf:
         raise RuntimeError("llvm-objdump / llvm-readelf not found: cannot check the ISA assumptions of the decoder kernels")
     report = {"m0_writes": 0, "lds_dma_loads": 0, "kernels": {}}
-    for src in ("mlp_kernel.hip", "mlp_lp_kernel.hip", "mlp_split_kernel.hip", "mlp_cluster_kernel.hip"):
+    for src in ("mlp_kernel.hip", "mlp_lp_kernel.hip", "mlp_lpj_kernel.hip", "mlp_split_kernel.hip", "mlp_cluster_kernel.hip"):
         obj = os.path.join(OBJ_DIR, src + ".o")
         with tempfile.TemporaryDirectory(prefix="dsp_isa_") as work:
             shutil.copy(obj, os.path.join(work, "k.o"))

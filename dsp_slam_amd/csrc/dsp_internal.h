@@ -154,6 +154,26 @@ struct LpArgs {
     DirectTiles direct;         // one-object batches: no tile list (kind != 0)
 };
 
+// ---- low-precision compute mode (mlp_lpj_kernel.hip): forward + input gradient on 16-bit MFMA operands ------------------------------
+constexpr int LPJ_MAX_PASSES = 8;   // eight forward passes (the prepass stream: mlp_lpj_fwd_kernel) or eight backward passes (mlp_lpj_bwd_kernel)
+struct LpjArgs {
+    const void* wstream;        // the prepass stream (forward kernel) or the transposed stream (backward kernel: pack_decoder_lpj_host), chunk-major
+    const float* bias_tab;
+    float b_last;
+    int n_bias_rows, wlast_row;
+    int total_chunks;
+    LpPass pass[LPJ_MAX_PASSES];   // backward passes, last hidden layer first: kind 3 hidden, 4 latent_in (also yields the re-injected rows' gradient), 5 first layer (two output groups)
+    const int* n_tiles;
+    const int4* tiles;          // {first point, n points (<= 128), object, output offset}
+    const float4* pts;
+    const float* code_bias;     // per object [2][512] fp32 (k_code_bias)
+    int code_bias_stride;
+    float* out_grad;            // [point + offset][GRAD_STRIDE]: d/dcode[64], d/dxyz[3], sdf -- what mlp_kernel<2> writes
+    uint4* mask_buf;            // [tile][8 layers][2 column blocks][256 lanes] x 16 B: the relu masks (forward kernel writes, backward kernel reads)
+    int lat_tile;               // 27 (64-D codes) / 29 (32-D)
+    unsigned long long* clk;
+};
+
 // ---- Gauss-Newton batch state ------------------------------------------------------------------
 constexpr int DSP_STATUS_GOOD = 0;
 constexpr int DSP_STATUS_FEW = 1;    // < 10 in-sphere samples (loss.py:73-74)
@@ -251,6 +271,8 @@ hipError_t mlp_cluster_prepare_device();
 hipError_t launch_mlp_cluster(const MlpArgs& args, int n_clusters, hipStream_t stream);   // 16-point tiles, four workgroups each; grid = 4 x n_clusters (n_clusters a multiple of 8), all resident
 hipError_t mlp_lp_prepare_device();
 hipError_t launch_mlp_lp(bool bf16, const LpArgs& args, int n_blocks, hipStream_t stream, int tile_pts = LP_TILE_PTS);   // 128- or 64-point tiles, forward only
+hipError_t mlp_lpj_prepare_device();
+hipError_t launch_mlp_lpj(int which, bool bf16, const LpjArgs& args, int n_blocks, hipStream_t stream);   // 128-point tiles; which: 0 forward + mask export, 1 backward from the masks
 // run_mask (optional, B bytes): objects with a zero byte are left out of the run (status DSP_STATUS_SKIP, state and result row untouched);
 // summary: the run's counter words, zeroed here (summary_words of them)
 void launch_init_state(ObjState* st, const float* t, const float* codes, const float* scale, const float* depths /*optional B x 64*/, int B, int D, int pose_only,

@@ -82,6 +82,11 @@ class Batch(object):
         """HIP events around every decoder launch (stats ms_mlp_*): -1 = automatic (batches of more than 16 objects), 0 = off, 1 = on."""
         L.check(L.load().dsp_batch_set_kernel_timing(self._h, int(mode)), self.engine._h, "dsp_batch_set_kernel_timing")
 
+    def set_compute(self, mode):
+        """0 = fp32 (default: the parity path), 1 = f16, 2 = bf16: the opt-in low-precision compute mode (dsp_batch_set_compute) -- NOT bit- or
+        1e-4-comparable with the reference; see include/dsp_gn.h."""
+        L.check(L.load().dsp_batch_set_compute(self._h, int(mode)), self.engine._h, "dsp_batch_set_compute")
+
     def set_iterations(self, n):
         L.check(L.load().dsp_batch_set_iterations(self._h, int(n)), self.engine._h, "dsp_batch_set_iterations")
         self.iters = int(n)
@@ -379,6 +384,18 @@ class Engine(object):
         grad = np.zeros((n, L.GRAD_DIM), np.float32)
         L.check(L.load().dsp_sdf_jacobian(self._h, L.ptr(code), L.ptr(pts), n, L.ptr(sdf), L.ptr(grad)), self._h, "dsp_sdf_jacobian")
         if self.code_len != L.CODE_LEN:     # d/d[code(code_len), xyz]: drop the unused code columns
+            grad = np.ascontiguousarray(np.concatenate([grad[:, :self.code_len], grad[:, L.CODE_LEN:]], 1))
+        return sdf, grad
+
+    def sdf_jacobian_lp(self, code, pts, dtype=L.COMPUTE_F16):
+        """sdf and d sdf / d [code, xyz] through the 16-bit jacobian kernels of the low-precision compute mode (accuracy measurements)."""
+        pts = L.f32(pts).reshape(-1, 3)
+        code = L.code64(code)
+        n = pts.shape[0]
+        sdf = np.zeros(n, np.float32)
+        grad = np.zeros((n, L.GRAD_DIM), np.float32)
+        L.check(L.load().dsp_sdf_jacobian_lp(self._h, int(dtype), L.ptr(code), L.ptr(pts), n, L.ptr(sdf), L.ptr(grad)), self._h, "dsp_sdf_jacobian_lp")
+        if self.code_len != L.CODE_LEN:
             grad = np.ascontiguousarray(np.concatenate([grad[:, :self.code_len], grad[:, L.CODE_LEN:]], 1))
         return sdf, grad
 

@@ -146,6 +146,12 @@ int dsp_decode_sdf_prepass(dsp_handle* h, int dtype, const float* code, const fl
 /* The same point set decoded for n_codes shape codes in ONE launch: sdf_out[c * n + i].  Batched form of the
  * MeshExtractor grid decode (reconstruct/optimizer.py:217-218) / the per-object loop of extract_map_objects.py:46-63. */
 int dsp_decode_sdf_multi(dsp_handle* h, const float* codes, int64_t n_codes, const float* pts, int64_t n, float* sdf_out);
+/* get_batch_sdf_jacobian through the 16-bit kernels of the LOW-PRECISION COMPUTE MODE (dsp_batch_set_compute below): f16 / bf16 matrix operands,
+ * fp32 accumulation, forward and backward.  NOT the parity path -- exposed so that its accuracy can be measured point by point. */
+#define DSP_COMPUTE_F32 0
+#define DSP_COMPUTE_F16 1
+#define DSP_COMPUTE_BF16 2
+int dsp_sdf_jacobian_lp(dsp_handle* h, int dtype, const float* code, const float* pts, int64_t n, float* sdf_out, float* grad_out);
 /* get_batch_sdf_jacobian(decoder, lat_vec, x, 1) -- reconstruct/loss_utils.py:82-103.
  * sdf_out (n), grad_out (n, 67) = d sdf / d [code, xyz]. */
 int dsp_sdf_jacobian(dsp_handle* h, const float* code, const float* pts, int64_t n, float* sdf_out, float* grad_out);
@@ -246,6 +252,15 @@ int dsp_batch_set_prepass_guard(dsp_batch* b, int on);
  * the bench's roofline needs them; off for latency-sized batches, where an event record between two kernels is a queue packet of its own),
  * 0 = off, 1 = on.  Launch COUNTS and ms_total are filled either way. */
 int dsp_batch_set_kernel_timing(dsp_batch* b, int mode);
+/* OPT-IN, NON-PARITY fast path (BASELINE.json north_star: "fp32/bf16 GEMMs"; SURVEY.md 8(d): "optional non-parity fast path, reported
+ * separately").  DSP_COMPUTE_F32 (default): everything that reaches a result is decoded in fp32 -- the mode every parity statement is about.
+ * DSP_COMPUTE_F16 / _BF16: the decoder runs on 16-bit matrix operands with fp32 accumulation everywhere -- the ray samples' sdf come from the
+ * 16-bit forward kernel alone (no fp32 re-decode of the band, no guard), the jacobian rows from 16-bit forward + backward kernels
+ * (mlp_lpj_kernel.hip); thresholds, scans, the Gram matrices and the fp64 solve are unchanged.  The precision class of the reference's own
+ * published runs (PyTorch 1.10 on Ampere multiplied in TF32: 10-bit mantissas, as f16).  How far H, b and the results move:
+ * profiles/r06_lp_compute.md, tests/test_gpu_lp_compute.py.  DSP_E_ARG for a decoder geometry other than DeepSDF's (eight hidden layers, the
+ * latent_in layer fourth) and for pose-only batches. */
+int dsp_batch_set_compute(dsp_batch* b, int mode);
 /* The iteration count of the following runs (instead of dsp_gn_params.num_iterations / pose_only_iterations given at creation). */
 int dsp_batch_set_iterations(dsp_batch* b, int32_t n);
 /* The calibration dsp_create made for this decoder at a ZERO code: largest |sdf_lp - sdf_fp32| it measured and the margin it derived

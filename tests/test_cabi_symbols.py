@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     assert set(names) <= bound, "ctypes binding misses %s" % (set(names) - bound)
     assert lib.dsp_abi_version() == L.ABI_VERSION == 6    # 2: dsp_stats grew the prepass fields; 3: the guard fields; 4: kernel-timing setter, partial guard re-run; 5: dsp_debug_lie, dsp_trim, cluster time-out; 6: batch tokens, five setters + dsp_batch_set_debug
     setters = [n for n in names if n.startswith("dsp_batch_set_")]
-    assert sorted(setters) == ["dsp_batch_set_debug", "dsp_batch_set_iterations", "dsp_batch_set_kernel_timing", "dsp_batch_set_prepass", "dsp_batch_set_prepass_guard",
+    assert sorted(setters) == ["dsp_batch_set_compute", "dsp_batch_set_debug", "dsp_batch_set_iterations", "dsp_batch_set_kernel_timing", "dsp_batch_set_prepass", "dsp_batch_set_prepass_guard",
                                "dsp_batch_set_ray_passes"], setters
 
 

@@ -192,3 +192,42 @@ def test_other_depths(depth, lat):
     else:
         with pytest.raises(L.DspError):
             LE.debug_pack(pk["_holder"], L.PREPASS_F16)
+
+
+@pytest.mark.parametrize("code_len", [64, 32])
+def test_lp_jacobian_stream_emulated(code_len):
+    """The low-precision compute mode's backward stream (dsp_debug_pack_lpj) replayed through a numpy model of mlp_lpj_fwd_kernel +
+    mlp_lpj_bwd_kernel: its sdf IS the prepass emulation's (same passes, bit for bit), and its input gradient agrees with the oracle's fp32
+    gradient to what rounding the weights, the activations and the back-propagated gradient to f16 once per layer allows -- which pins the
+    transposed slot order, the mask bit bookkeeping, the re-injected rows of the latent_in layer (rows 445.. / 477..) and the first layer's
+    row layout (code 0 .., xyz 77..79) on the CPU.  bf16 (8-bit mantissas) goes through the same data flow with a 16x looser bound."""
+    import copy
+    import lp_emulator as LE
+    from dsp_slam_amd import _lib as L
+    sp = copy.deepcopy(fixtures.SPECS)
+    sp["CodeLength"] = code_len
+    dec = O.fold_decoder(fixtures.random_state_dict(11, sp), sp)
+    pk = KE.debug_pack(dec.layers, dec.latent_in, dec.code_len)
+    rng = np.random.default_rng(code_len)
+    code = (rng.normal(size=code_len) * 0.3).astype(np.float32)
+    pts32 = rng.uniform(-0.8, 0.8, size=(32, 3)).astype(np.float32)
+    y_ref, g_ref = O.get_batch_sdf_jacobian(dec, code, pts32)
+    assert np.abs(g_ref[:, :code_len]).max() > 1e-4 and np.abs(g_ref[:, code_len:]).max() > 1e-4
+    for dtype, tol in ((L.COMPUTE_F16, 1.0), (L.COMPUTE_BF16, 16.0)):
+        lp = LE.debug_pack(pk["_holder"], dtype)
+        lpj = LE.debug_pack_lpj(pk["_holder"], dtype)
+        assert lpj["n_pass"] == 8 and list(lpj["passes"][:, 3]) == [3, 3, 3, 4, 3, 3, 3, 5] and list(lpj["passes"][:, 0]) == [8] * 7 + [2]
+        assert lpj["lat_tile"] == (27 if code_len == 64 else 29) and lpj["chunks"] == 7 * 32 + 8
+        y, g = LE.run_wave_jac(pk, lp, lpj, code, pts32, dtype)
+        assert np.array_equal(y, LE.run_wave(pk, lp, code, pts32, dtype))
+        g = np.concatenate([g[:, :code_len], g[:, 64:]], 1)
+        scale = np.abs(g_ref).max()
+        per_point = np.abs(g - g_ref).max(1) / scale
+        print("emulated %s jacobian, %d-D codes: |dg| / max |g| per point: median %.2e, 90 %% %.2e, max %.2e" % (
+            "f16" if dtype == L.COMPUTE_F16 else "bf16", code_len, np.median(per_point), np.percentile(per_point, 90), per_point.max()))
+        # rounding alone: ~4e-4 (f16); a point whose 16-bit forward flips ONE relu unit that sits within round-off of zero (random weights have
+        # many) differs by that unit's whole contribution -- a few points in 32, a few % at most
+        assert np.median(per_point) < 1e-3 * tol and per_point.max() < (5e-2 if dtype == L.COMPUTE_F16 else 0.5), per_point
+        if code_len == 32:
+            gfull = LE.run_wave_jac(pk, lp, lpj, code, pts32, dtype)[1]
+            assert not gfull[:, 32:64].any()          # code entries beyond the decoder's code length: zero gradient
