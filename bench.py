@@ -105,7 +105,9 @@ def main():
     ap.add_argument("--prepass", choices=sorted(PREPASS), default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prepass-off", action="store_true")     # skip the prepass-off sub-record
+    ap.add_argument("--no-lp", action="store_true")              # skip the low-precision-compute sub-record (value_lp)
     ap.add_argument("--latency-runs", type=int, default=9)
+    ap.add_argument("--serial-batches", action="store_true")     # cfg5: run the two decoders' batches back to back from one host thread (round 5's form)
     args = ap.parse_args()
 
     import torch
@@ -233,10 +235,23 @@ def main():
             legs[-1][key]["launches"] += int(st[n])
             legs[-1][key]["ms"] += float(st[ms])
 
+    # cfg5 holds TWO resident batches (one per decoder = one per handle = one per HIP stream).  Run from one host thread they execute back to back
+    # and each pays its own partial rounds and launch tails; run from two host threads (ctypes releases the GIL inside dsp_batch_run) the two
+    # streams' kernels interleave on the device ("group objects by decoder").  Results do not depend on it.
+    pool = None
+    if len(batches) > 1 and not args.serial_batches:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=len(batches))
+
     def step():
-        for bt in batches:
-            bt.run()
-            leg_add(bt.stats())
+        if pool is not None:
+            list(pool.map(lambda bt: bt.run(), batches))
+            for bt in batches:
+                leg_add(bt.stats())
+        else:
+            for bt in batches:
+                bt.run()
+                leg_add(bt.stats())
         if dist is not None and backend == "nccl":     # the single collective of the path: results device -> RCCL gather over xGMI -> rank 0's host, no host bounce
             gathered[0] = D.gather_results_device(batches, shards, dist, device=torch.device("cuda", local_rank))
         elif dist is not None:                         # plumbing test on gloo: host rows
@@ -292,6 +307,23 @@ def main():
             bt.set_prepass(PREPASS[args.prepass])
     n_good = int(sum(int((bt.results()[3] == 0).sum()) for bt in batches))
     n_total = sum(b - a for a, b in shards)
+    # the same batch in the OPT-IN low-precision compute mode (dsp_batch_set_compute(F16): 16-bit MFMA operands, fp32 accumulation, everywhere in
+    # the decoder -- a non-parity fast path, reported separately and never mixed into the fp32 figures), timed in the same run
+    lp_run = None
+    if args.config == "cfg2x64" and not args.no_lp:
+        try:
+            for bt in batches:
+                bt.set_compute(1)
+            lp_steps = max(1, args.steps)
+            lp_run = timed(1, lp_steps, "lp_compute") + (lp_steps, int(sum(int((bt.results()[3] == 0).sum()) for bt in batches)),
+                                                          [np.array(x, copy=True) for x in D.unpack_results(gathered[0])] if rank == 0 and gathered[0] is not None else None)
+        except Exception as e:
+            sys.stderr.write("low-precision compute leg failed: %r\n" % (e,))
+            lp_run = None
+        for bt in batches:
+            bt.set_compute(0)
+        mark("restore_fp32_results")
+        step()             # leaves the fp32 results in `gathered` for what follows
 
     # what every rank measured on its own GPU, gathered so that an imbalance in a multi-GPU run is explainable from the line alone:
     # fp32 forward / jacobian / prepass rates (HIP events on the library's stream), the shader clock the chip granted under the
@@ -396,7 +428,8 @@ def main():
             "objects_good": n_good,
             "timed_region": "inputs are resident in HBM before the timed step (dsp_batch_create uploaded them: ~4 MB per 64 objects, ~0.1 ms over PCIe, NOT "
                             "in the step); the step = every GN iteration on the device + the read-back of the 82-float result rows + the gather",
-            "parallelism": "object-sharded x%d, one RCCL gather of results per step" % world + (" [PLUMBING TEST: ranks share GPU 0, %s backend]" % backend if share_gpu else ""),
+            "parallelism": "object-sharded x%d, one RCCL gather of results per step" % world + (" [PLUMBING TEST: ranks share GPU 0, %s backend]" % backend if share_gpu else "") + (
+                "; the %d decoders' batches run concurrently on their own HIP streams (one host thread each)" % len(batches) if pool is not None else ""),
             "prepass": ["off", "f16", "bf16"][mode] + (" (exact pre-classification of ray samples; results bit-identical to off)" if mode else ""),
         },
         "roofline": {
@@ -474,6 +507,44 @@ def main():
         result["value_fp32_only"] = result["prepass_off"]["value"]
     elif mode == 0:
         result["value_fp32_only"] = result["value"]
+    result["value_lp"] = None
+    if lp_run is not None:
+        l_el, l_ranks, l_acc, l_steps, l_good, l_res = lp_run
+        PEAK_LIVE = 1781.0       # profiles/r05_k0_clock.md row F: what a 16x16x32 f16 MFMA stream with live operands and one A-fragment read per two MFMAs sustains
+        lj_tf = l_acc["n_jac_points"] * F_JAC / (l_acc["ms_mlp_jac"] * 1e-3) / 1e12 if l_acc["ms_mlp_jac"] > 0 else 0.0
+        lf_tf = l_acc["n_prepass_points"] * F_FWD / (l_acc["ms_mlp_prepass"] * 1e-3) / 1e12 if l_acc["ms_mlp_prepass"] > 0 else 0.0
+        fp32_res = D.unpack_results(gathered[0])
+        lp_block = {
+            "value": round(n_total * l_steps / l_el, 3), "unit": "objects/s", "steps": l_steps, "ms_per_step": round(l_el / l_steps * 1e3, 3),
+            "dtype": "f16 operands, f32 accumulation (v_mfma_f32_16x16x32_f16) in every decoder launch; thresholds, scans, Gram and the fp64 solve unchanged",
+            "parity": "NOT the parity path (opt-in: dsp_batch_set_compute): accuracy at the reference's recorded states in profiles/r06_lp_compute.md / tests/test_gpu_lp_compute.py",
+            "objects_good": l_good,
+            "vs_value": round((n_total * l_steps / l_el) / value, 3),
+            "roofline": {
+                "bound": "mfma", "peak": PEAK_16BIT_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "jacobian": {"kernel": "mlp_lpj_fwd_kernel<f16> + mlp_lpj_bwd_kernel<f16> (forward with relu-mask export, backward over the transposed stream)",
+                             "achieved": round(lj_tf, 1), "frac": round(lj_tf / PEAK_16BIT_MFMA_TFLOPS, 4), "frac_of_live_operand_ceiling": round(lj_tf / PEAK_LIVE, 4),
+                             "alg_flop_per_launch_pair": round(l_acc["n_jac_points"] * F_JAC / max(l_acc["n_mlp_jac_launches"], 1)),
+                             "avg_launch_pair_ms": round(l_acc["ms_mlp_jac"] / max(l_acc["n_mlp_jac_launches"], 1), 4)},
+                "ray_samples": {"kernel": "mlp_lp_kernel<f16> (the prepass kernel: here its values ARE the samples' sdf)", "achieved": round(lf_tf, 1),
+                                "frac": round(lf_tf / PEAK_16BIT_MFMA_TFLOPS, 4), "frac_of_live_operand_ceiling": round(lf_tf / PEAK_LIVE, 4),
+                                "avg_launch_ms": round(l_acc["ms_mlp_prepass"] / max(l_acc["n_mlp_prepass_launches"], 1), 4)},
+                "live_operand_ceiling_tflops": PEAK_LIVE,
+                "ms_per_step_by_kernel": {"ray_samples_f16": round(l_acc["ms_mlp_prepass"] / l_steps, 2), "jacobian_f16": round(l_acc["ms_mlp_jac"] / l_steps, 2),
+                                          "fwd_fp32": round(l_acc["ms_mlp_fwd"] / l_steps, 2),
+                                          "other": round((l_acc["ms_total"] - l_acc["ms_mlp_prepass"] - l_acc["ms_mlp_jac"] - l_acc["ms_mlp_fwd"]) / l_steps, 2)},
+            },
+            **{k: v for k, v in reference_algorithmic(l_acc, l_el).items() if k != "reference_algorithmic_flop_per_step"},
+        }
+        if l_res is not None:       # how far this run's results sit from the fp32 path's, object by object (chained over ten iterations: includes the map's own amplification)
+            t_lp, c_lp, t_32, c_32 = l_res[0], l_res[1], fp32_res[0], fp32_res[1]
+            dtr = np.abs(t_lp - t_32).reshape(len(t_lp), -1).max(1) / np.abs(t_32).reshape(len(t_32), -1).max(1)
+            dcd = np.abs(c_lp - c_32).max(1)
+            lp_block["chained_result_vs_fp32_path"] = {"pose_rel_median": float(np.median(dtr)), "pose_rel_max": float(dtr.max()), "code_abs_median": float(np.median(dcd)),
+                                                       "code_abs_max": float(dcd.max()),
+                                                       "note": "for scale: the unmodified reference moves these objects by 2e-4 .. 2e-2 (pose) when its inputs move by one float32 ulp or its thread count changes (tests/golden/golden_bench_cfg2x64.npz)"}
+        result["lp_compute"] = lp_block
+        result["value_lp"] = lp_block["value"]
 
     if world == 1 and args.config == "cfg2x64":
         # single-object latency (ms/object p50): batch of ONE cfg2 object

@@ -69,11 +69,16 @@ def main():
     if ars:
         print("## Device linearised at the REFERENCE'S OWN recorded states (pose, code and depth samples injected bit for bit), compared with the reference's recorded H / b / dx / V / K directly\n")
         print("Every iteration of every recorded run (tests/test_gpu_forensics.py::test_linearisation_at_reference_states).  strict = V and K identical to the reference's, H within 3e-5 and b within 1.2e-4 of the reference's recorded values (3x what was measured).\n")
-        print("| golden | iterations | strict | iterations with named flips | max rel dH | max rel db | max rel d(dx) | K per iteration |")
-        print("|---|---|---|---|---|---|---|---|")
+        print("| golden | iterations | strict | iterations with named flips | max rel dH | max rel db | max rel d(dx) | max rel d(loss) | K per iteration |")
+        print("|---|---|---|---|---|---|---|---|---|")
         for r in sorted(ars, key=lambda r: r["case"]):
-            print("| %s | %d | %d | %d | %.2e | %.2e | %.2e | %s |" % (r["case"], r["n"], r["strict"], sum(1 for f in r["flips"] if f), max(r["rel_H"]), max(r["rel_b"]),
-                                                                   max(r["rel_dx"]), r["K"]))
+            print("| %s | %d | %d | %d | %.2e | %.2e | %.2e | %s | %s |" % (r["case"], r["n"], r["strict"], sum(1 for f in r["flips"] if f), max(r["rel_H"]), max(r["rel_b"]),
+                                                                        max(r["rel_dx"]), "%.2e" % max(r["rel_loss"]) if "rel_loss" in r else "-", r["K"]))
+        n_loss = sum(len(r["rel_loss"]) for r in ars if "rel_loss" in r)
+        if n_loss:
+            print("\n`loss` = the result's fourth field after ONE iteration from the recorded state = the reference's loss AT that state (reconstruct/optimizer.py:155; the field "
+                  "src/LocalMapping_util.cc:405-406 branches on); `it_loss` from the reference's own functions at the recorded state (tools/make_golden_it_loss.py; its last entry is "
+                  "bit-identical to the loss the recorded run returned).  **%d loss comparisons, bound 1e-4 (asserted).**" % n_loss)
         print("\n(rel d(dx) is dominated by the three rotation-prior entries of b: k4 = 1e7 times a residual that is a difference of two numbers ~1, i.e. float32 ulp noise in the reference itself; the test bounds dx through |H^-1| with that term.)\n")
     chf = [r for (k, _, _d), r in last.items() if k == "chained_forensic"]
     if chf:
@@ -100,13 +105,15 @@ def main():
               "`k4 (j_i + j_j) 1e-6` on top (the reference builds it in float32 from a residual that is a difference of numbers ~1 and multiplies by k4 = 1e7: "
               "the oracle differs from the recording by the same amount).\n")
         for r in bar:
-            print("%s: **%d iterations, %d strict, %d with named flips**; max rel dH %.2e, max rel db %.2e.\n" % (r["case"], r["n"], r["strict"], r["with_named_flips"],
-                                                                                                                r["max_rel_H"], r["max_rel_b"]))
-            print("| bench object | max rel dH | max rel db | named flips | K per iteration (identical to the reference's) |")
-            print("|---|---|---|---|---|")
+            print("%s: **%d iterations, %d strict, %d with named flips**; max rel dH %.2e, max rel db %.2e%s.\n" % (r["case"], r["n"], r["strict"], r["with_named_flips"],
+                                                                                                                  r["max_rel_H"], r["max_rel_b"],
+                                                                                                                  "; **%d loss comparisons, max rel d(loss) %.2e** (bound 1e-4, asserted)" % (
+                                                                                                                      r["n_loss_comparisons"], r["max_rel_loss"]) if "max_rel_loss" in r else ""))
+            print("| bench object | max rel dH | max rel db | max rel d(loss) | named flips | K per iteration (identical to the reference's) |")
+            print("|---|---|---|---|---|---|")
             for o in sorted(r["per_object"], key=int):
                 q = r["per_object"][o]
-                print("| %s | %.2e | %.2e | %d | %s |" % (o, q["max_rel_H"], q["max_rel_b"], q["named"], q["K"]))
+                print("| %s | %.2e | %.2e | %s | %d | %s |" % (o, q["max_rel_H"], q["max_rel_b"], "%.2e" % q["max_rel_loss"] if "max_rel_loss" in q else "-", q["named"], q["K"]))
             if r.get("beyond_tight_bounds"):
                 print("\nIterations beyond 3e-5 / 1.2e-4 and what the oracle's own response to a 1-ulp state jitter is there (the bound they were held to instead):\n")
                 for x in r["beyond_tight_bounds"]:
@@ -131,6 +138,52 @@ def main():
             if rest:
                 print("\nOther recorded figures: `%s`" % json.dumps(rest)[:900])
             print()
+    mf = {k: r for (k, _, _d), r in last.items() if k in ("mono_flip_at_reference_states", "mono_flip_chained")}
+    if mf:
+        print("## The field the mono path branches on: both hypotheses of one detection (tests/test_mono_flip.py, `golden_mono_flip.npz`)\n")
+        if "mono_flip_at_reference_states" in mf:
+            r = mf["mono_flip_at_reference_states"]
+            print("At the reference's recorded states of BOTH runs (%d linearisations): max rel d(loss) %.2e (detection's pose) / %.2e (yaw-flipped), V and K identical, bound 1e-4 (asserted).\n" % (
+                r["n"], max(r["rel_loss_a"]), max(r["rel_loss_b"])))
+        if "mono_flip_chained" in mf:
+            r = mf["mono_flip_chained"]
+            print("Chained through the mirror's `Optimizer.reconstruct_object` (five-argument form, as `LocalMapping_util.cc:391-406` calls it): device losses %.6f / %.6f, reference %.6f / %.6f "
+                  "(rel %.1e / %.1e; the gap between the hypotheses is 0.28) -> C++ keeps the **%s** hypothesis on both: %s.\n" % (
+                      r["device_loss"][0], r["device_loss"][1], r["reference_loss"][0], r["reference_loss"][1], r["rel"][0], r["rel"][1],
+                      "flipped" if r["reference_loss"][0] > r["reference_loss"][1] else "unflipped", "same branch" if r["same_branch"] else "DIFFERENT BRANCH"))
+    lpk = [r for (k, _, _d), r in last.items() if k == "lp_jacobian_kernel"]
+    lps = [r for (k, _, _d), r in last.items() if k == "lp_compute_at_reference_states"]
+    lpc = [r for (k, _, _d), r in last.items() if k == "lp_compute_chained"]
+    lpv = [r for (k, _, _d), r in last.items() if k == "lp_compute_speed"]
+    if lpk or lps:
+        print("## The OPT-IN low-precision compute mode (`dsp_batch_set_compute`: 16-bit MFMA operands, fp32 accumulation) -- NOT the parity path; measured against it and the reference\n")
+        if lpk:
+            print("Kernel level (tests/test_gpu_lp_compute.py): `mlp_lpj_fwd_kernel` + `mlp_lpj_bwd_kernel` against the fp32 kernel's d sdf / d [code, xyz] on the same points; the sdf equals the prepass kernel's bit for bit (asserted).\n")
+            print("| case | abs(dg) / max abs(g): median | 99 % | max (a relu unit at zero flipped by the 16-bit forward) | max abs(dsdf) |")
+            print("|---|---|---|---|---|")
+            for r in sorted(lpk, key=lambda r: r["case"]):
+                print("| %s | %.2e | %.2e | %.2e | %.2e |" % (r["case"], r["grad_rel_median"], r["grad_rel_p99"], r["grad_rel_max"], r["sdf_abs_max"]))
+            print()
+        for r in sorted(lps, key=lambda r: r["case"]):
+            w, m = r["worst"], r["median"]
+            print("**%s**, at the reference's recorded states (%d linearisations): V identical; abs(dK) <= %d (%.2f %% of K); rel dH median %.2e / max %.2e; rel db %.2e / %.2e; "
+                  "rel d(dx) %.2e / %.2e; rel d(loss) %.2e / %.2e.\n" % (r["case"], r["n"], w["dK"], 100 * r["worst_dK_over_K"], m["rel_H"], w["rel_H"], m["rel_b"], w["rel_b"],
+                                                                          m["rel_dx"], w["rel_dx"], m["rel_loss"], w["rel_loss"]))
+        for r in lpc:
+            print("Chained ten-iteration runs, f16 mode (final result vs the reference's; for scale the fp32 path's distance and the reference's own spread under 1-ulp inputs / other thread counts):\n")
+            print("| golden | f16 mode: rot / trans / code | fp32 path: rot / trans / code | reference's own spread | rel d(loss) |")
+            print("|---|---|---|---|---|")
+            for x in r["rows"]:
+                a, f, sp = x["lp_vs_reference"], x["fp32_vs_reference"], x["reference_spread"]
+                print("| %s | %.1e / %.1e / %.1e | %.1e / %.1e / %.1e | %.1e / %.1e / %.1e | %.1e |" % (x["case"], a["rot"], a["trans"], a["code"], f["rot"], f["trans"], f["code"],
+                                                                                                    sp["rot"], sp["trans"], sp["code"], x["loss_rel_vs_reference"]))
+            print()
+        for r in lpv:
+            print("%s: decoder time per run %.1f ms (fp32 path with the f16 classifier) -> %.1f ms (f16 compute mode); whole run %.1f -> %.1f ms.\n" % (
+                r["case"], r["decoder_ms_fp32_path"], r["decoder_ms_lp"], r["run_ms_fp32_path"], r["run_ms_lp"]))
+    sv = [r for (k, _, _d), r in last.items() if k == "solve_vs_lapack"]
+    for r in sv:
+        print("## `k_solve` against float64 LAPACK\n\n%s: max rel d(dx) %.2e (what rounding the traced H, b to float32 allows: %.2e).\n" % (r["case"], r["rel_dx_max"], r["rounding_bound_rel"]))
     r4 = [r for (k, _, _d), r in last.items() if k in ("solver_ab", "partial_guard_rerun", "one_shot", "reoptimise_map")]
     if r4:
         print("## Round-4 paths\n")
