@@ -17,10 +17,12 @@ DST = os.path.join(ROOT, "profiles")
 F_FWD = 3671040.0
 PEAK32, PEAK16 = 157.3, 2500.0
 
-K1 = "_ZN3dsp10mlp_kernelILi1ELb0EEEvNS_7MlpArgsE.kd"
-K2 = "_ZN3dsp10mlp_kernelILi2ELb0EEEvNS_7MlpArgsE.kd"
-K2R = "_ZN3dsp10mlp_kernelILi3ELb0EEEvNS_7MlpArgsE.kd"
-K0 = "_ZN3dsp13mlp_lp_kernelILb0ELi2ELi4EEEvNS_6LpArgsE.kd"      # f16, two column blocks per wave, four waves: the 128-point-tile form
+K1 = "_ZN3dsp10mlp_kernelILi1EEEvNS_7MlpArgsE.kd"
+K2 = "_ZN3dsp10mlp_kernelILi2EEEvNS_7MlpArgsE.kd"
+K2R = "_ZN3dsp10mlp_kernelILi3EEEvNS_7MlpArgsE.kd"
+K0 = "_ZN3dsp13mlp_lp_kernelILb0ELi2EEEvNS_6LpArgsE.kd"      # f16, two column blocks per wave: the 128-point-tile form
+KJF = "_ZN3dsp18mlp_lpj_fwd_kernelILb0EEEvNS_7LpjArgsE.kd"   # low-precision compute mode: forward with mask export
+KJB = "_ZN3dsp18mlp_lpj_bwd_kernelILb0EEEvNS_7LpjArgsE.kd"   # ... backward from the masks
 
 
 def read(name):
@@ -74,6 +76,11 @@ def main():
         po = b["prepass_off"]
         lines += ["| cfg2x64, prepass off = `value_fp32_only` (same process, %d steps) | %.1f | %.1f | %.3f | %.3f | - |" % (
             po["steps"], po["value"], po["ms_per_step"], po["roofline_frac"], po["jac_kernel_frac"])]
+    if "lp_compute" in b:
+        lc = b["lp_compute"]
+        lines += ["| cfg2x64, OPT-IN low-precision compute mode = `value_lp` (same process, %d steps; NOT the parity path) | %.1f | %.1f | - | f16 jacobian pair %.0f TFLOP/s (%.3f of 2500) | ray samples %.0f (%.3f) |" % (
+            lc["steps"], lc["value"], lc["ms_per_step"], lc["roofline"]["jacobian"]["achieved"], lc["roofline"]["jacobian"]["frac"], lc["roofline"]["ray_samples"]["achieved"],
+            lc["roofline"]["ray_samples"]["frac"])]
     if boff:
         lines += [row("cfg2x64, --prepass off (own process)", boff)]
     lines += [row("cfg4 (%s scaling: %d objects on this GPU)" % (b4["scaling"], b4["config"]["objects_per_gpu"]), b4), row("cfg5", b5), ""]
@@ -173,6 +180,41 @@ def main():
            % (wr[(K0, "WRITE_SIZE")][1], wr[(K0, "WRITE_SIZE")][1] * 1024 / k0_pts),
            "* LDS: %d bank conflicts (A fragments are read as lane-linear `ds_read_b128`)." % ld[(K0, "SQ_LDS_BANK_CONFLICT")][1], "",
            "**Jacobian kernels**: `mlp_kernel<3>` (backward only) %.1f %% matrix-pipe busy, `mlp_kernel<2>` (forward + backward) %.1f %%." % (100 * busy(K2R), 100 * busy(K2)), ""]
+    # ---- the low-precision compute leg (markers 3 .. 5 of the same counter runs) ----
+    if os.path.exists(os.path.join(SRC, "pmc_lp_mfma.md")) and "lp_compute" in b:
+        mfl, dml = pmc("pmc_lp_mfma.md")
+        fel, dfl = pmc("pmc_lp_fetch.md")
+        wrl, _ = pmc("pmc_lp_write.md")
+        ldl, _ = pmc("pmc_lp_lds.md")
+        lpc = b["lp_compute"]["roofline"]
+
+        def busy_l(k):
+            return mfl[(k, "SQ_VALU_MFMA_BUSY_CYCLES")][1] / (mfl[(k, "GRBM_GUI_ACTIVE")][1] / 8 * 1024)
+
+        def clk_l(k):
+            return mfl[(k, "GRBM_GUI_ACTIVE")][1] / 8 / (dml[k][1] * 1e-3) / 1e9
+
+        jac_pts = lpc["jacobian"]["alg_flop_per_launch_pair"] / (2 * F_FWD) * dml[KJF][0]
+        txt += ["## The low-precision compute leg (`dsp_batch_set_compute(F16)`; the same counter runs, dispatches between markers 3 and 5: 2 steps)", "",
+                "### FETCH_SIZE (KiB)", "", table_only("pmc_lp_fetch.md"), "", "### WRITE_SIZE (KiB)", "", table_only("pmc_lp_write.md"), "",
+                "### MFMA / busy counters", "", table_only("pmc_lp_mfma.md"), "", "### LDS / wait counters", "", table_only("pmc_lp_lds.md"), "", "### Reading", ""]
+        for k, label in ((KJF, "`mlp_lpj_fwd_kernel<f16>` (forward + relu-mask export over the jacobian rows)"), (KJB, "`mlp_lpj_bwd_kernel<f16>` (backward over the transposed stream)"),
+                         (K0, "`mlp_lp_kernel<f16>` (the ray samples: here its values are the results)")):
+            if k not in dml:
+                continue
+            issued = mfl[(k, "SQ_INSTS_VALU_MFMA_MOPS_F16")][1] * 512
+            fetch = fel[(k, "FETCH_SIZE")][1] * 1024 * 2
+            write = wrl[(k, "WRITE_SIZE")][1] * 1024
+            txt += ["* %s: %d launches, %.1f ms; `SQ_INSTS_VALU_MFMA_MOPS_F16` x 512 = %.1f TFLOP issued = **%.2f PFLOP/s**; matrix pipe busy **%.1f %%**, shader clock %.2f GHz; "
+                    "fabric reads %.2f GB (%.0f GB/s), writes %.2f GB; %d LDS bank conflicts." % (
+                        label, dml[k][0], dml[k][1], issued / 1e12, issued / (dml[k][1] * 1e-3) / 1e15, 100 * busy_l(k), clk_l(k), fetch / 1e9, fetch / (dfl[k][1] * 1e-3) / 1e9,
+                        write / 1e9, ldl[(k, "SQ_LDS_BANK_CONFLICT")][1])]
+        if KJF in dml and KJB in dml:
+            mw = wrl[(KJF, "WRITE_SIZE")][1] * 1024
+            txt += ["", "The masks: the forward kernel writes %.0f B per jacobian point (algorithmic: 512 B of relu bits + 4 B of sdf), the backward kernel reads them back and writes the "
+                        "68-float rows (272 B per point): %.2f GB/s of fabric traffic in the pair -- %.1f %% of the HBM peak; MFMA-bound like every decoder kernel here." % (
+                            mw / max(jac_pts, 1.0), (fel[(KJF, "FETCH_SIZE")][1] + fel[(KJB, "FETCH_SIZE")][1]) * 2048 / ((dfl[KJF][1] + dfl[KJB][1]) * 1e-3) / 1e9,
+                            100 * (fel[(KJF, "FETCH_SIZE")][1] + fel[(KJB, "FETCH_SIZE")][1]) * 2048 / ((dfl[KJF][1] + dfl[KJB][1]) * 1e-3) / 8e12), ""]
     open(os.path.join(DST, TAG + "_pmc.md"), "w").write("\n".join(txt))
     traffic = {
         "fwd_fetch_bytes_per_point": round(k1_fetch / k1_pts, 1),

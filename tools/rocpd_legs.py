@@ -16,7 +16,9 @@ import sys
 
 SHORT = (("mlp_kernelILi0", "mlp_kernel<0>"), ("mlp_kernelILi1", "mlp_kernel<1>"), ("mlp_kernelILi2", "mlp_kernel<2>"), ("mlp_kernelILi3", "mlp_kernel<3>"),
          ("mlp_lp_kernelILb0", "mlp_lp_kernel<f16>"), ("mlp_lp_kernelILb1", "mlp_lp_kernel<bf16>"), ("mlp_split_kernelILi0", "mlp_split_kernel<0>"),
-         ("mlp_split_kernelILi1", "mlp_split_kernel<1>"), ("mlp_split_kernelILi2", "mlp_split_kernel<2>"), ("mlp_cluster_kernel", "mlp_cluster_kernel"))
+         ("mlp_split_kernelILi1", "mlp_split_kernel<1>"), ("mlp_split_kernelILi2", "mlp_split_kernel<2>"), ("mlp_cluster_kernel", "mlp_cluster_kernel"),
+         ("mlp_lpj_fwd_kernelILb0", "mlp_lpj_fwd_kernel<f16>"), ("mlp_lpj_bwd_kernelILb0", "mlp_lpj_bwd_kernel<f16>"),
+         ("mlp_lpj_fwd_kernelILb1", "mlp_lpj_fwd_kernel<bf16>"), ("mlp_lpj_bwd_kernelILb1", "mlp_lpj_bwd_kernel<bf16>"))
 JSON_KEY = {"mlp_kernel<1>": "fwd_fp32", "mlp_lp_kernel<f16>": "prepass", "mlp_lp_kernel<bf16>": "prepass"}
 F_FWD = 3671040.0
 
@@ -87,6 +89,20 @@ def main():
                     tf = res["prepass"]["alg_flop_per_launch"] / (avg * 1e-3) / 1e12
                     out += ["Headline leg, `%s`: %d launches, trace average %.4f ms -> %.1f TFLOP/s = %.4f of the %.0f TFLOP/s dense 16-bit peak "
                             "(bench JSON: %.4f)." % (k, len(d), avg, tf, tf / res["prepass"]["peak"], res["prepass"]["peak"], res["prepass"]["frac"])]
+        if l["leg"] == "lp_compute_timed" and "lp_compute" in res:
+            lp = res["lp_compute"]["roofline"]
+            f, b2 = per.get((lg, "mlp_lpj_fwd_kernel<f16>")), per.get((lg, "mlp_lpj_bwd_kernel<f16>"))
+            if f and b2:
+                pair = sum(f) / len(f) + sum(b2) / len(b2)
+                tf = lp["jacobian"]["alg_flop_per_launch_pair"] / (pair * 1e-3) / 1e12
+                out += ["Low-precision compute leg, jacobian pair: `mlp_lpj_fwd_kernel<f16>` %d launches, trace average %.4f ms + `mlp_lpj_bwd_kernel<f16>` %d launches, %.4f ms = %.4f ms per pair "
+                        "(bench JSON, HIP events around each: %.4f) -> %.1f TFLOP/s = %.4f of the %.0f TFLOP/s dense 16-bit peak (bench JSON: %.4f); forward share of the pair %.3f." % (
+                            len(f), sum(f) / len(f), len(b2), sum(b2) / len(b2), pair, lp["jacobian"]["avg_launch_pair_ms"], tf, tf / lp["peak"], lp["peak"], lp["jacobian"]["frac"],
+                            (sum(f) / len(f)) / pair)]
+            k0 = per.get((lg, "mlp_lp_kernel<f16>"))
+            if k0:
+                out += ["Low-precision compute leg, `mlp_lp_kernel<f16>` (ray samples): %d launches, trace average %.4f ms (bench JSON: %.4f)." % (
+                    len(k0), sum(k0) / len(k0), lp["ray_samples"]["avg_launch_ms"])]
     out += ["", "Largest |trace - JSON| / JSON over the timed legs: %.2f %%" % (100 * worst)]
     text = "\n".join(out)
     print(text)

@@ -4,7 +4,7 @@
 # them into profiles/<tag>_*.md.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r05}
+TAG=${1:-r06}
 STEPS=${2:-20}
 WARM=${3:-5}
 OUT=$R/gpurun_out/$TAG
@@ -24,8 +24,10 @@ for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "mfma:SQ_INSTS_VALU_MFMA_MOPS_
   name=${pass%%:*}; ctrs=${pass#*:}
   timeout 300 rocprofv3 --pmc $ctrs -d /tmp/prof_pmc_$name -o pmc -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --latency-runs 1 --no-prepass-off > $OUT/pmc_$name.log 2>&1
   DB=$(find /tmp/prof_pmc_$name -name "*.db" | head -1)
-  # markers: 1 headline_warmup, 2 headline_timed, 3 clock_probe -> the headline leg's two steps only
+  # markers: 1 headline_warmup, 2 headline_timed, 3 lp_compute_warmup, 4 lp_compute_timed, 5 restore_fp32_results, 6 clock_probe
+  # -> [1, 3) the headline leg's two steps, [3, 5) the low-precision compute leg's two steps
   python $R/tools/rocpd_pmc.py $DB mlp_ --between 1 3 > $OUT/pmc_$name.md 2>&1
+  python $R/tools/rocpd_pmc.py $DB mlp_ --between 3 5 > $OUT/pmc_lp_$name.md 2>&1
 done
 # latency-sized: one real-KITTI-size detection per call
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_lat -o stats -- python $R/tools/gpu_small_loop.py 250 200 50 > $OUT/latency_run.txt 2>&1
