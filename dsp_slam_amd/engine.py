@@ -458,11 +458,14 @@ class Engine(object):
     def batch(self, prm, t_cam_obj, pts, rays, depth, codes=None, trace=False):
         return Batch(self, prm, t_cam_obj, pts, rays, depth, codes, trace)
 
-    def reconstruct_batch(self, prm, t_cam_obj, pts, rays, depth, codes=None):
+    def reconstruct_batch(self, prm, t_cam_obj, pts, rays, depth, codes=None, compute=L.COMPUTE_F32):
+        """compute: L.COMPUTE_F32 (default, the parity path) or the opt-in low-precision mode L.COMPUTE_F16 / _BF16 (dsp_batch_set_compute)."""
         if len(pts) == 0:      # an empty shard (more ranks than objects): nothing to run, but the caller still joins the gather
             return (np.zeros((0, 4, 4), np.float32), np.zeros((0, self.code_len), np.float32), np.zeros(0, np.float32), np.zeros(0, np.int32))
         b = Batch(self, prm, t_cam_obj, pts, rays, depth, codes)
         try:
+            if compute != L.COMPUTE_F32:
+                b.set_compute(compute)
             b.run()
             return b.results()
         finally:

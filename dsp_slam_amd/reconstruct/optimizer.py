@@ -46,6 +46,15 @@ class Optimizer(object):
         if decoder is not None and self.code_len != getattr(decoder, "latent_size", self.code_len):
             raise ValueError("optimizer.code_len (%d) does not match the decoder's CodeLength (%d)" % (self.code_len, decoder.latent_size))
         self.verbose = True
+        # ADDITION (not in the reference's configs): "compute_dtype": "f16" | "bf16" under "optimizer" opts into the low-precision compute mode
+        # (dsp_batch_set_compute: 16-bit MFMA operands, fp32 accumulation -- NOT the parity path; include/dsp_gn.h).  Absent: fp32.
+        try:
+            dt = optim_cfg["compute_dtype"] if "compute_dtype" in optim_cfg else "f32"
+        except TypeError:
+            dt = "f32"
+        if dt not in ("f32", "f16", "bf16"):
+            raise ValueError("optimizer.compute_dtype must be f32, f16 or bf16 (got %r)" % (dt,))
+        self.compute = {"f32": _L.COMPUTE_F32, "f16": _L.COMPUTE_F16, "bf16": _L.COMPUTE_BF16}[dt]
 
     def _params(self):
         return _engine.gn_params(self.k1, self.k2, self.k3, self.k4, self.b1, self.b2, self.lr, self.s_damp,
@@ -78,7 +87,7 @@ class Optimizer(object):
             codes_in = [np.zeros(self.code_len, np.float32) if c is None else _f32(c)[:self.code_len] for c in codes]
         t, code, loss, status = self.decoder.engine.reconstruct_batch(
             self._params(), [_f32(x) for x in t_cam_obj_list], [_f32(p) for p in pts_list],
-            [_f32(r) for r in rays_list], [_f32(d).reshape(-1) for d in depth_list], codes_in)
+            [_f32(r) for r in rays_list], [_f32(d).reshape(-1) for d in depth_list], codes_in, compute=self.compute)
         out = []
         for i in range(B):
             if status[i] == _L.OBJ_GOOD:

@@ -224,3 +224,45 @@ def test_lp_compute_batch_throughput_shape(eng):
     assert dec16 < 0.6 * dec32
     dt = np.abs(r16[0] - r32[0]).max(axis=(1, 2)) / np.abs(r32[0]).max(axis=(1, 2))
     print("   final pose, f16 mode vs fp32 path, per object (relative): %s" % np.array2string(dt, precision=1))
+
+
+def test_mirror_api_opt_in(tmp_path):
+    """`"compute_dtype": "f16"` under "optimizer" (an ADDITION: the reference's configs do not have the key, its absence is fp32) switches the
+    mirror's Optimizer to the low-precision mode: same call surface, same result dict, a result within the mode's accuracy of the fp32 one."""
+    import sys
+    pkg = os.path.join(ROOT, "dsp_slam_amd")
+    sys.path.insert(0, pkg)
+    try:
+        for m in [k for k in sys.modules if k.split(".")[0] in ("reconstruct", "deep_sdf")]:
+            del sys.modules[m]
+        from reconstruct.utils import get_configs, get_decoder
+        from reconstruct.optimizer import Optimizer
+        g = golden("golden_recon_freiburg.npz")
+        cfg_d = json.loads(str(g["cfg_json"]))
+        cfg_d["DeepSDF_DIR"] = fixtures.materialize_decoder_dir("cars", str(tmp_path / "cars_64"))
+        out = {}
+        for dt in ("f32", "f16"):
+            c = json.loads(json.dumps(cfg_d))
+            if dt != "f32":
+                c["optimizer"]["compute_dtype"] = dt
+            with open(tmp_path / ("cfg_%s.json" % dt), "w") as f:
+                json.dump(c, f)
+            cfg = get_configs(str(tmp_path / ("cfg_%s.json" % dt)))
+            opt = Optimizer(get_decoder(cfg), cfg)
+            opt.verbose = False
+            assert opt.compute == (L.COMPUTE_F16 if dt == "f16" else L.COMPUTE_F32)
+            out[dt] = opt.reconstruct_object(g["in_t_cam_obj_init"], g["in_pts"], g["in_rays"], g["in_depth"])
+            assert out[dt].is_good is True
+        assert np.abs(out["f32"].t_cam_obj - g["t_cam_obj"]).max() <= 1e-4 * np.abs(g["t_cam_obj"]).max()        # the parity path, as ever
+        d = np.abs(out["f16"].t_cam_obj - out["f32"].t_cam_obj).max() / np.abs(out["f32"].t_cam_obj).max()
+        assert 0 < d < 5e-3, d
+        c = json.loads(json.dumps(cfg_d))
+        c["optimizer"]["compute_dtype"] = "fp8"
+        with open(tmp_path / "cfg_bad.json", "w") as f:
+            json.dump(c, f)
+        with pytest.raises(ValueError):
+            Optimizer(None, get_configs(str(tmp_path / "cfg_bad.json")))
+    finally:
+        sys.path.remove(pkg)
+        for m in [k for k in sys.modules if k.split(".")[0] in ("reconstruct", "deep_sdf")]:
+            del sys.modules[m]
