@@ -103,7 +103,7 @@ def test_complex_prepass_is_exact_and_pays(eng):
     assert n_obj / t_on > 1.3 * n_obj / t_off
 
 
-def test_complex_reconstruct_end_to_end(eng, complex_decoder):
+def test_complex_chained_run_within_the_references_own_spread(eng, complex_decoder):
     """The recorded cfg2-size object of the complex family, all ten iterations chained, against the reference's result inside the
     reference's own spread (1-ulp inputs and thread counts: golden ulps_* / thr_*)."""
     import test_gpu_parity as P

@@ -6,7 +6,7 @@ Tolerances (float32 path, north_star: 1e-4 relative):
     1e-5 relative (max-norm) on gradients;
   * one Gauss-Newton linearisation from an identical state: H, b, dx within 1e-4 relative (max-norm) when the
     ragged sets (V, m, K) are identical, which is asserted;
-  * ten chained iterations: see test_reconstruct_end_to_end for the sensitivity-calibrated bound.
+  * ten chained iterations: see test_chained_run_within_the_references_own_spread for the sensitivity-calibrated bound.
 """
 import json
 
@@ -143,7 +143,7 @@ def _run_traced(eng, cfg, obj, code=None):
     return res, traces, oprm
 
 
-# chained runs: bound = this x the largest of the reference's 9 recorded round-off draws (see test_reconstruct_end_to_end).  Measured on
+# chained runs: bound = this x the largest of the reference's 9 recorded round-off draws (see test_chained_run_within_the_references_own_spread).  Measured on
 # MI355X (profiles/parity_r03.md): device / spread <= 0.9 on five of the six goldens, 1.07 on `small` (the device is one more draw: it
 # exceeds the largest of nine exchangeable draws one time in ten per quantity).  Round 2 used 3.0.
 E2E_SPREAD_FACTOR = 1.5
@@ -310,7 +310,7 @@ def end_to_end_differences(g, t44, code):
 
 @pytest.mark.parametrize("name", ["golden_recon_small.npz", "golden_recon_cfg1.npz", "golden_recon_redwood.npz", "golden_recon_freiburg.npz",
                                   "golden_recon_cfg2.npz"])
-def test_reconstruct_end_to_end(eng, name):
+def test_chained_run_within_the_references_own_spread(eng, name):
     """All iterations chained, against the reference's final pose / code (north_star: 1e-4 relative).
 
     Tolerance per quantity: 1e-4, or E2E_SPREAD_FACTOR x the REFERENCE'S OWN spread when every element of its inputs moves to an adjacent

@@ -98,7 +98,7 @@ def main():
     bar = sorted(bar, key=lambda r: r.get("_t", 0.0))[-1:]           # the latest run (the case label carries the number of traced objects)
     if bar:
         print("## The HEADLINE workload (64 x cfg2 bench batch) at the reference's own recorded states, inside the resident 64-object batch\n")
-        print("tests/test_gpu_bench_objects.py::test_bench_objects_at_reference_states: `tests/golden/golden_bench_cfg2x64.npz` (made by `tools/make_golden_bench.py` "
+        print("tests/test_gpu_bench_objects.py::test_batch64_at_the_references_recorded_states: `tests/golden/golden_bench_cfg2x64.npz` (made by `tools/make_golden_bench.py` "
               "from the unmodified reference) holds all ten iterations of sixteen of bench.py's 64 objects; each traced object's recorded pose, code and depth samples "
               "are injected into ITS slot of the 64-object batch (the other 56 run on), one Gauss-Newton iteration is taken and V, K, H, b are compared with the "
               "reference's recorded values.  strict = V and K identical, H within 3e-5, b within 1.2e-4; the rotation-prior block H[3:6,3:6] is held to "
@@ -125,7 +125,7 @@ def main():
     if bch:
         print("## The headline workload chained: all 64 bench objects, ten iterations, against the reference's recorded results\n")
         for r in bch:
-            print("tests/test_gpu_bench_objects.py::test_bench_batch_chained: iteration 0 -- %d of %d objects with sample sets IDENTICAL to the reference's, the rest within "
+            print("tests/test_gpu_bench_objects.py::test_batch64_first_iteration_and_chained_result_vs_reference: iteration 0 -- %d of %d objects with sample sets IDENTICAL to the reference's, the rest within "
                   "dV <= %d, dK <= %d (asserted: <= 2 and >= B - 8 exact); after ten iterations the traced objects are held to 1.5x the reference's OWN spread "
                   "under a 1-ulp jitter of its inputs (recorded in the golden), the others to 3x the worst traced spread.\n" % (
                       r["objects_identical_sets_iteration0"], r["n_objects"], r["max_dV_iteration0"], r["max_dK_iteration0"]))
