@@ -169,7 +169,7 @@ struct LpjArgs {
     const float* code_bias;     // per object [2][512] fp32 (k_code_bias)
     int code_bias_stride;
     float* out_grad;            // [point + offset][GRAD_STRIDE]: d/dcode[64], d/dxyz[3], sdf -- what mlp_kernel<2> writes
-    uint4* mask_buf;            // [tile][8 layers][2 column blocks][256 lanes] x 16 B: the relu masks (forward kernel writes, backward kernel reads)
+    uint4* mask_buf;            // [tile][8 layers][4 waves][2 column blocks][64 lanes] x 16 B: the relu masks (forward kernel writes, backward kernel reads)
     int lat_tile;               // 27 (64-D codes) / 29 (32-D)
     unsigned long long* clk;
 };

@@ -19,8 +19,11 @@
 //                        latent_in layer's pass also yields the gradient of the re-injected [xyz | code] rows (unmasked; kept as packed pairs,
 //                        20 registers), the first layer's pass leaves d sdf / d [code | xyz] in the accumulators: + the kept rows,
 //                        x (1 - y^2) / S, stored as the fp32 kernel stores it (68 floats per point: d/dcode[64], d/dxyz[3], sdf).
-// Masks travel through memory that the kernels also stream weights through by hand-counted vmcnt: a store / load the compiler manages adds to
-// the counter, so a counted wait can only wait LONGER than needed (outstanding <= k still implies that at most k DMA pieces are in flight).
+// Masks travel through memory that the kernels also stream weights through by hand-counted vmcnt.  The forward kernel's mask stores are
+// compiler-managed: they add to the counter, so a counted wait can only wait LONGER than needed (outstanding <= k still implies that at most k
+// DMA pieces are in flight).  The backward kernel fetches a layer's masks by LDS-DMA a pass ahead of their use into the (otherwise unused) bias
+// area and reads them back from the LDS: a compiler-managed global load would put an s_waitcnt vmcnt(0) in front of the first use and drain
+// the weight ring once per pass (measured: profiles/r06_lp_compute.md).
 #include "dsp_internal.h"
 #include "mlp_common.h"
 #include "mlp_lp_common.h"
@@ -30,6 +33,7 @@ namespace dsp {
 constexpr float LPJ_SEED_SCALE = 16.f;
 constexpr int LPJ_SKIP_T0 = 27;            // first 16-row tile that may hold re-injected input rows of the latent_in layer (27: 64-D codes, 29: 32-D)
 constexpr int LPJ_SKIP_TILES = 32 - LPJ_SKIP_T0;
+constexpr int LPJ_MASK_TILE = 8 * 4 * 2 * 64;      // uint4 per 128-point tile: [layer 8][wave 4][column block 2][lane 64]
 
 // relu-mask bit of one accumulator, shifted into `bits` (bits = 2 * bits + (x > 0)): v_cmp + v_addc (mlp_kernel.hip).  Element i of the 32
 // pushed into a word ends at bit 31 - i.
@@ -39,6 +43,19 @@ __device__ __forceinline__ void lpj_push_bit(unsigned& bits, float x) {
 // x where bit (31 - i) of word is set, else +0: one v_bfe_i32 (0 / all ones) + one v_and
 __device__ __forceinline__ float lpj_keep(float x, unsigned word, int i) {
     return __int_as_float(__float_as_int(x) & __builtin_amdgcn_sbfe((int)word, 31u - (unsigned)i, 1u));
+}
+
+// one layer's masks of one wave (two column blocks, 2 x 1 KiB) from global memory into its staging buffer by LDS-DMA.  Writes M0: only between
+// a chunk's last DMA piece and the next chunk's glds_set_dst, i.e. outside lpj_pass
+__device__ __forceinline__ void lpj_mask_dma(const char* gsrc_uniform, unsigned lane_off, unsigned lds_dst) {
+    asm volatile(
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, %1\n\t"
+        "global_load_lds_dwordx4 %0, %1 offset:1024"
+        :
+        : "v"(lane_off), "s"(gsrc_uniform), "s"(lds_dst)
+        : "memory");
 }
 
 // KIND of a pass: 0 forward (relu, mask bits out), 1 forward LAST hidden layer (mask bits out + the final dot product; no slab), 2 backward (mask
@@ -238,7 +255,7 @@ __device__ __forceinline__ f32x2 lpj_unpack(unsigned p) {
         _Pragma("unroll") for (int rt = 0; rt < LP_RT; ++rt)                                                                    \
             _Pragma("unroll") for (int blk = 0; blk < 2; ++blk) acc[i][rt][blk] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-// ---- forward with mask export: tile t's masks at mask_buf[(t * 16 + 2 slot + blk) * 256 + tid], slot = layer ----
+// ---- forward with mask export: tile t's masks at mask_buf[t * 4096 + ((slot * 4 + wave) * 2 + blk) * 64 + lane], slot = layer ----
 template <bool BF>
 __global__ __launch_bounds__(256, 1) void mlp_lpj_fwd_kernel(const LpjArgs a) {
     LPJ_PROLOGUE((void)0)
@@ -291,11 +308,11 @@ __global__ __launch_bounds__(256, 1) void mlp_lpj_fwd_kernel(const LpjArgs a) {
         }
 
         float part[2] = {0.f, 0.f};
-        uint4* msc = a.mask_buf + (size_t)tile * (16 * 256) + tid;
+        uint4* msc = a.mask_buf + (size_t)tile * LPJ_MASK_TILE + wave * 128 + lane;
         auto bias_of = [&](const LpPass& pd) { return pd.bias_row == -2 ? cb_l + WIDTH : (pd.bias_row == -3 ? cb_l : bias_l + pd.bias_row * WIDTH); };
         auto store_masks = [&](int slot) {
-            msc[(2 * slot + 0) * 256] = make_uint4(mw[0][0], mw[0][1], mw[0][2], mw[0][3]);
-            msc[(2 * slot + 1) * 256] = make_uint4(mw[1][0], mw[1][1], mw[1][2], mw[1][3]);
+            msc[slot * 512] = make_uint4(mw[0][0], mw[0][1], mw[0][2], mw[0][3]);
+            msc[slot * 512 + 64] = make_uint4(mw[1][0], mw[1][1], mw[1][2], mw[1][3]);
         };
         // the prepass kernel's passes: first layer Y -> X, then X -> Y / Y -> X pairs, the last hidden layer reads X (eight hidden layers: the host
         // offers this kernel for that depth only)
@@ -334,6 +351,13 @@ __global__ __launch_bounds__(256, 1) void mlp_lpj_bwd_kernel(const LpjArgs a) {
     unsigned skip[LPJ_SKIP_TILES][2][2];
     u32x4 xb[2] = {(u32x4){0u, 0u, 0u, 0u}, (u32x4){0u, 0u, 0u, 0u}};
     float part[2] = {0.f, 0.f};
+    // mask staging: two 8 KiB buffers in the bias area (the backward sweep adds no bias), [wave][column block][lane] uint4 each
+    const unsigned stage0 = lds_addr(bias_l) + wave * 2048;
+    const uint4* stage_l = reinterpret_cast<const uint4*>(bias_l) + wave * 128 + lane;
+    const char* mbase = reinterpret_cast<const char*>(a.mask_buf) + wave * 2048;
+    lpj_mask_dma(mbase + (size_t)blockIdx.x * (LPJ_MASK_TILE * 16) + 7 * 8192, rg.lane_off, stage0);
+    lpj_mask_dma(mbase + (size_t)blockIdx.x * (LPJ_MASK_TILE * 16) + 6 * 8192, rg.lane_off, stage0 + 8192);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int4 td = a.tiles[tile];
         bool valid[2];
@@ -346,9 +370,13 @@ __global__ __launch_bounds__(256, 1) void mlp_lpj_bwd_kernel(const LpjArgs a) {
             prow[blk] = td.x + (valid[blk] ? local : 0) + td.w;
             y[blk] = valid[blk] ? a.out_grad[(size_t)prow[blk] * GRAD_STRIDE + 67] : 0.f;      // the forward kernel's sdf
         }
-        const uint4* msc = a.mask_buf + (size_t)tile * (16 * 256) + tid;
-        auto load_masks = [&](int slot) {
-            const uint4 m0 = msc[(2 * slot + 0) * 256], m1 = msc[(2 * slot + 1) * 256];
+        // next tile of this workgroup (the last one fetches its own masks again: no branch around the DMA)
+        const int ntile = tile + (int)gridDim.x < n_tiles ? tile + (int)gridDim.x : tile;
+        const char* msrc = mbase + (size_t)tile * (LPJ_MASK_TILE * 16), *nsrc = mbase + (size_t)ntile * (LPJ_MASK_TILE * 16);
+        // masks of layer `slot`: staged by fetch_masks a pass earlier, read back by the lanes that the DMA wrote them for
+        auto fetch_masks = [&](const char* src, int slot, int buf) { lpj_mask_dma(src + slot * 8192, rg.lane_off, stage0 + buf * 8192); };
+        auto load_masks = [&](int buf) {
+            const uint4 m0 = stage_l[buf * 512], m1 = stage_l[buf * 512 + 64];
             mw[0][0] = m0.x; mw[0][1] = m0.y; mw[0][2] = m0.z; mw[0][3] = m0.w;
             mw[1][0] = m1.x; mw[1][1] = m1.y; mw[1][2] = m1.z; mw[1][3] = m1.w;
         };
@@ -358,7 +386,7 @@ __global__ __launch_bounds__(256, 1) void mlp_lpj_bwd_kernel(const LpjArgs a) {
             for (int b2 = 0; b2 < 2; ++b2) { skip[t][b2][0] = 0u; skip[t][b2][1] = 0u; }
         // the sweep's input slab: S w_last where the last hidden layer's accumulator was positive (its mask, slot 7), in the slab's slot order --
         // registers 2 (T & 1), 2 (T & 1) + 1 of Y[2 (T >> 1) + blk] hold rows 16 T + 4 gq + {0, 1}, {2, 3}
-        load_masks(7);
+        load_masks(0);
 #pragma unroll
         for (int T = 0; T < 32; ++T) {
             const f32x4 ws = *reinterpret_cast<const f32x4*>(wls_l + 16 * T + 4 * gq);
@@ -374,14 +402,18 @@ __global__ __launch_bounds__(256, 1) void mlp_lpj_bwd_kernel(const LpjArgs a) {
         // geometry, the only one the host offers this kernel for.  No loop and no branch: a join with both slabs live costs the compiler a hundred
         // spilled registers (mlp_lp_kernel.hip).
 #define LPJ_BWD(KIND_, NOG_, P_, IN_, OUT_) lpj_pass<BF, LP_NCH, KIND_, NOG_>(a.pass[P_], IN_, OUT_, acc, abuf, rg, xb, zero_l, zero_l, gq, part, mw, skip)
-        load_masks(6); LPJ_BWD(2, LP_NOG, 0, Y, X);
-        load_masks(5); LPJ_BWD(2, LP_NOG, 1, X, Y);
-        load_masks(4); LPJ_BWD(2, LP_NOG, 2, Y, X);
-        load_masks(3); LPJ_BWD(4, LP_NOG, 3, X, Y);
-        load_masks(2); LPJ_BWD(2, LP_NOG, 4, Y, X);
-        load_masks(1); LPJ_BWD(2, LP_NOG, 5, X, Y);
-        load_masks(0); LPJ_BWD(2, LP_NOG, 6, Y, X);
-        LPJ_BWD(3, 2, 7, X, Y);
+        // staging: buffer 0 holds layer 7's masks and buffer 1 layer 6's when the tile starts (fetched during the previous tile's last pass, or
+        // ahead of the loop); the pass that reads buffer b fetches the masks of the pass after it into the other buffer, whose last reader is a
+        // pass behind.  A fetch is two LDS-DMA pieces older than the 32 (16) chunks the pass then issues: the ring's counted waits (at most 20
+        // pieces outstanding) retire it within five chunks.
+        load_masks(1); fetch_masks(msrc, 5, 0); LPJ_BWD(2, LP_NOG, 0, Y, X);
+        load_masks(0); fetch_masks(msrc, 4, 1); LPJ_BWD(2, LP_NOG, 1, X, Y);
+        load_masks(1); fetch_masks(msrc, 3, 0); LPJ_BWD(2, LP_NOG, 2, Y, X);
+        load_masks(0); fetch_masks(msrc, 2, 1); LPJ_BWD(4, LP_NOG, 3, X, Y);
+        load_masks(1); fetch_masks(msrc, 1, 0); LPJ_BWD(2, LP_NOG, 4, Y, X);
+        load_masks(0); fetch_masks(msrc, 0, 1); LPJ_BWD(2, LP_NOG, 5, X, Y);
+        load_masks(1); LPJ_BWD(2, LP_NOG, 6, Y, X);
+        fetch_masks(nsrc, 7, 0); fetch_masks(nsrc, 6, 1); LPJ_BWD(3, 2, 7, X, Y);
 #undef LPJ_BWD
         // acc[0][j][blk]: rows 16 j + 4 gq + r of d / d code through the first layer (j < 4); acc[1][0][blk]: lane group 3, registers 1..3 =
         // d / d xyz through the first layer (rows 77..79 of the pass).  + the rows the latent_in layer's pass kept; x (1 - y^2) / S.
