@@ -59,13 +59,13 @@ __device__ __forceinline__ void lpj_mask_dma(const char* gsrc_uniform, unsigned 
 }
 
 // KIND of a pass: 0 forward (relu, mask bits out), 1 forward LAST hidden layer (mask bits out + the final dot product; no slab), 2 backward (mask
-// bits applied), 4 backward through the latent_in layer (as 2, and the re-injected rows of its input are kept), 3 backward FIRST layer (two
-// output groups, accumulators kept)
+// bits applied; with `cap`, the latent_in layer's pass, the re-injected rows of its input are kept as well), 3 backward FIRST layer (two output
+// groups, accumulators kept)
 //
 // One half (two accumulators of one 16-row tile and column block) of an epilogue unit.  T, blk, half are compile-time after unrolling.
 template <bool BF, int KIND>
 __device__ __forceinline__ void lpj_half(int T, int blk, int half, float e0, float e1, u32x4 (&out)[32], unsigned (&mw)[2][4], const float* dp,
-                                         int gq, float (&part)[2], unsigned (&skip)[LPJ_SKIP_TILES][2][2]) {
+                                         int gq, float (&part)[2], unsigned (&skip)[LPJ_SKIP_TILES][2][2], bool cap) {
     const int i0 = 4 * (T & 7) + 2 * half;                  // element index of e0 inside its mask word (T >> 3)
     unsigned packed;
     if constexpr (KIND == 0) {
@@ -80,7 +80,10 @@ __device__ __forceinline__ void lpj_half(int T, int blk, int half, float e0, flo
         part[blk] = fmaf(relu1(e1), w.y, part[blk]);
         return;                                               // nothing reads the last hidden layer's slab
     } else {
-        if (KIND == 4 && T >= LPJ_SKIP_T0) skip[T - LPJ_SKIP_T0][blk][half] = lp_pack<BF>(e0, e1);      // (compile-time) rows of the re-injected input, unmasked
+        if (T >= LPJ_SKIP_T0) {          // (compile-time) rows that are re-injected input in the latent_in layer's pass: kept unmasked there (cap is wave-uniform)
+            const unsigned raw = lp_pack<BF>(e0, e1);
+            skip[T - LPJ_SKIP_T0][blk][half] = cap ? raw : skip[T - LPJ_SKIP_T0][blk][half];
+        }
         packed = lp_pack<BF>(lpj_keep(e0, mw[blk][T >> 3], i0), lpj_keep(e1, mw[blk][T >> 3], i0 + 1));
     }
     out[2 * (T >> 1) + blk][2 * (T & 1) + half] = packed;
@@ -90,7 +93,7 @@ __device__ __forceinline__ void lpj_half(int T, int blk, int half, float e0, flo
 template <bool BF, int NCH, int KIND, int NOG>
 __device__ __forceinline__ void lpj_pass(const LpPass pd, u32x4 (&in)[32], u32x4 (&out)[32], f32x4 (&acc)[2][LP_RT][2], u32x4 (&abuf)[2][LP_RT], LpRing& rg,
                                          const u32x4 (&xb)[2], const float* bp, const float* dp, int gq, float (&part)[2],
-                                         unsigned (&mw)[2][4], unsigned (&skip)[LPJ_SKIP_TILES][2][2]) {
+                                         unsigned (&mw)[2][4], unsigned (&skip)[LPJ_SKIP_TILES][2][2], bool cap = false) {
     constexpr bool FWD = KIND <= 1;
     // ---- prologue (forward only): the xyz B operands at their fixed step, padding cleared (lp_pass) ----
     if constexpr (FWD) {
@@ -168,16 +171,16 @@ __device__ __forceinline__ void lpj_pass(const LpPass pd, u32x4 (&in)[32], u32x4
 #pragma unroll
                             for (int b2 = 0; b2 < 2; ++b2) {
                                 const f32x4 v = acc[par ^ 1][rt][b2];
-                                lpj_half<BF, KIND>(4 * (g - 1) + rt, b2, 0, v.x, v.y, out, mw, dp, gq, part, skip);
-                                lpj_half<BF, KIND>(4 * (g - 1) + rt, b2, 1, v.z, v.w, out, mw, dp, gq, part, skip);
+                                lpj_half<BF, KIND>(4 * (g - 1) + rt, b2, 0, v.x, v.y, out, mw, dp, gq, part, skip, cap);
+                                lpj_half<BF, KIND>(4 * (g - 1) + rt, b2, 1, v.z, v.w, out, mw, dp, gq, part, skip, cap);
                             }
                         }
                     } else if (epi) {
                         const int T = 4 * (g - 1) + ert;
                         if (m == E0 + 0) { e0 = acc[par ^ 1][ert][eblk].x; e1 = acc[par ^ 1][ert][eblk].y; asm volatile("" : "+v"(e0), "+v"(e1)); }
-                        if (m == E0 + 1) lpj_half<BF, KIND>(T, eblk, 0, e0, e1, out, mw, dp, gq, part, skip);
+                        if (m == E0 + 1) lpj_half<BF, KIND>(T, eblk, 0, e0, e1, out, mw, dp, gq, part, skip, cap);
                         if (m == E0 + 2) { e0 = acc[par ^ 1][ert][eblk].z; e1 = acc[par ^ 1][ert][eblk].w; asm volatile("" : "+v"(e0), "+v"(e1)); }
-                        if (m == E0 + 3) lpj_half<BF, KIND>(T, eblk, 1, e0, e1, out, mw, dp, gq, part, skip);
+                        if (m == E0 + 3) lpj_half<BF, KIND>(T, eblk, 1, e0, e1, out, mw, dp, gq, part, skip, cap);
                     }
                     if (ks == LP_KQ * NCH - 1 && m == 1 && g + 1 < NOG) lp_load_rows(bp, g + 1, gq, bias);
                     __builtin_amdgcn_sched_barrier(0);
@@ -192,8 +195,8 @@ __device__ __forceinline__ void lpj_pass(const LpPass pd, u32x4 (&in)[32], u32x4
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
                 const f32x4 v = acc[(NOG - 1) & 1][rt][blk];
-                lpj_half<BF, KIND>(4 * (NOG - 1) + rt, blk, 0, v.x, v.y, out, mw, dp, gq, part, skip);
-                lpj_half<BF, KIND>(4 * (NOG - 1) + rt, blk, 1, v.z, v.w, out, mw, dp, gq, part, skip);
+                lpj_half<BF, KIND>(4 * (NOG - 1) + rt, blk, 0, v.x, v.y, out, mw, dp, gq, part, skip, cap);
+                lpj_half<BF, KIND>(4 * (NOG - 1) + rt, blk, 1, v.z, v.w, out, mw, dp, gq, part, skip, cap);
             }
     }
 }
@@ -401,19 +404,19 @@ __global__ __launch_bounds__(256, 1) void mlp_lpj_bwd_kernel(const LpjArgs a) {
         // layers 7 .. 0, straight-line (pass 7 - L of the table, masks of layer L - 1): eight hidden layers with the latent_in layer fourth -- DeepSDF's
         // geometry, the only one the host offers this kernel for.  No loop and no branch: a join with both slabs live costs the compiler a hundred
         // spilled registers (mlp_lp_kernel.hip).
-#define LPJ_BWD(KIND_, NOG_, P_, IN_, OUT_) lpj_pass<BF, LP_NCH, KIND_, NOG_>(a.pass[P_], IN_, OUT_, acc, abuf, rg, xb, zero_l, zero_l, gq, part, mw, skip)
-        // staging: buffer 0 holds layer 7's masks and buffer 1 layer 6's when the tile starts (fetched during the previous tile's last pass, or
+#define LPJ_BWD(KIND_, NOG_, P_, IN_, OUT_, CAP_) lpj_pass<BF, LP_NCH, KIND_, NOG_>(a.pass[P_], IN_, OUT_, acc, abuf, rg, xb, zero_l, zero_l, gq, part, mw, skip, CAP_)
+        // staging: buffer 0 holds layer 7's masks and buffer 1 layer 6's when the tile starts (fetched during the previous tile's pass 6 / 7, or
         // ahead of the loop); the pass that reads buffer b fetches the masks of the pass after it into the other buffer, whose last reader is a
-        // pass behind.  A fetch is two LDS-DMA pieces older than the 32 (16) chunks the pass then issues: the ring's counted waits (at most 20
+        // pass behind.  A fetch is two LDS-DMA pieces older than the 32 (8) chunks the pass then issues: the ring's counted waits (at most 20
         // pieces outstanding) retire it within five chunks.
-        load_masks(1); fetch_masks(msrc, 5, 0); LPJ_BWD(2, LP_NOG, 0, Y, X);
-        load_masks(0); fetch_masks(msrc, 4, 1); LPJ_BWD(2, LP_NOG, 1, X, Y);
-        load_masks(1); fetch_masks(msrc, 3, 0); LPJ_BWD(2, LP_NOG, 2, Y, X);
-        load_masks(0); fetch_masks(msrc, 2, 1); LPJ_BWD(4, LP_NOG, 3, X, Y);
-        load_masks(1); fetch_masks(msrc, 1, 0); LPJ_BWD(2, LP_NOG, 4, Y, X);
-        load_masks(0); fetch_masks(msrc, 0, 1); LPJ_BWD(2, LP_NOG, 5, X, Y);
-        load_masks(1); LPJ_BWD(2, LP_NOG, 6, Y, X);
-        fetch_masks(nsrc, 7, 0); fetch_masks(nsrc, 6, 1); LPJ_BWD(3, 2, 7, X, Y);
+        // Passes 1 .. 6 are ONE loop body of two passes run three times (the latent_in layer's pass differs from its neighbours by a uniform flag):
+        // four pass bodies of ~25 KB instead of eight, and the loop's 50 KB stay in the instruction cache for its second and third trip.
+        load_masks(1); fetch_masks(msrc, 5, 0); LPJ_BWD(2, LP_NOG, 0, Y, X, false);
+        for (int it = 0; it < 3; ++it) {
+            load_masks(0); fetch_masks(msrc, 4 - 2 * it, 1); LPJ_BWD(2, LP_NOG, 2 * it + 1, X, Y, it == 1);
+            load_masks(1); fetch_masks(it < 2 ? msrc : nsrc, it < 2 ? 3 - 2 * it : 7, 0); LPJ_BWD(2, LP_NOG, 2 * it + 2, Y, X, false);
+        }
+        fetch_masks(nsrc, 6, 1); LPJ_BWD(3, 2, 7, X, Y, false);
 #undef LPJ_BWD
         // acc[0][j][blk]: rows 16 j + 4 gq + r of d / d code through the first layer (j < 4); acc[1][0][blk]: lane group 3, registers 1..3 =
         // d / d xyz through the first layer (rows 77..79 of the pass).  + the rows the latent_in layer's pass kept; x (1 - y^2) / S.
