@@ -109,7 +109,8 @@ int dsp_create(const dsp_decoder_desc* decoder, int device, dsp_handle** out);
 /* Destroys the handle AND every resident batch still alive on it.  A dsp_batch* is an opaque, generation-tagged TOKEN, not an address: once its
  * batch is gone -- destroyed, or taken by dsp_destroy of its handle -- every call that is handed the token returns DSP_E_ARG (dsp_batch_destroy:
  * does nothing), also after the memory has been reused for another batch.  So the two destroy calls are safe in either order and from any
- * thread (finalisers at interpreter exit run in no particular order); dsp_destroy waits for calls in flight on the handle's batches. */
+ * thread (finalisers at interpreter exit run in no particular order); dsp_destroy waits for calls in flight on the handle's batches, and
+ * dsp_batch_destroy for calls in flight on that batch (a call that starts after it sees a stale token). */
 void dsp_destroy(dsp_handle* h);
 /* A handle keeps device blocks (up to 1 GiB, size-classed) and pinned host staging of dropped one-shot batches for its next call.  dsp_trim
  * hands all of it back to the runtime: for a process that shares the GPU with another allocator (torch, RCCL, a second handle).  Destroying

@@ -264,3 +264,38 @@ def test_concurrent_destroy_from_a_finaliser_thread(oracle_decoder):
     th.join(timeout=60)
     assert not th.is_alive(), "dsp_batch_run did not return after its handle was destroyed"
     assert rcs[0] == 0 and all(r in (0, -1) for r in rcs) and rcs[-1] == -1, rcs
+
+
+def test_concurrent_batch_destroy_waits_for_the_run_in_flight(oracle_decoder):
+    """dsp_batch_destroy from one thread while another is inside dsp_batch_run on THAT batch: the destroy retires the token, waits for the call
+    in flight (pinned batch), frees; the runner's later calls see a stale token.  The handle stays usable."""
+    import threading
+    lib = L.load()
+    prm = E.gn_params(num_iterations=10)
+    objs = [synth.make_object(3400 + i, n_surface=600, n_background=200) for i in range(8)]
+    e = E.Engine(oracle_decoder.layers, oracle_decoder.latent_in, oracle_decoder.code_len, device=0)
+    b = e.batch(prm, *_args(objs))
+    b.run()
+    want = b.results()
+    tok = C.c_void_p(b._h.value)
+    rcs = []
+
+    def runner():
+        for _ in range(6):
+            rcs.append(lib.dsp_batch_run(tok))
+
+    th = threading.Thread(target=runner)
+    th.start()
+    while not rcs:
+        pass
+    b._h = C.c_void_p()                  # (Python's own close must not destroy it a second time)
+    lib.dsp_batch_destroy(tok)
+    th.join(timeout=60)
+    assert not th.is_alive()
+    assert rcs[0] == 0 and all(r in (0, -1) for r in rcs) and rcs[-1] == -1, rcs
+    b2 = e.batch(prm, *_args(objs))      # the handle is intact: same inputs, same bits
+    b2.run()
+    got = b2.results()
+    for x, y in zip(want, got):
+        assert np.array_equal(np.asarray(x), np.asarray(y), equal_nan=True)
+    e.close()
