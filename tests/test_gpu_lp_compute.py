@@ -19,7 +19,7 @@ import numpy as np
 import pytest
 
 import forensics as F
-from conftest import ROOT, golden, have_complex_fixture, parity_log
+from conftest import GOLDEN, ROOT, golden, have_complex_fixture, parity_log
 from oracle import dsp_oracle as O
 from dsp_slam_amd import engine as E, synth, _lib as L, fixtures
 
@@ -158,6 +158,64 @@ def test_lp_compute_at_the_references_recorded_states(eng, dtype):
     assert worst["dV"] == 0
     bound = 1.0 if dtype == L.COMPUTE_F16 else 8.0
     assert rel_dk <= 0.05 * bound and worst["rel_H"] <= 0.05 * bound and worst["rel_loss"] <= 0.05 * bound, worst
+
+
+BENCH_GOLD = "golden_bench_cfg2x64.npz"
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(GOLDEN, BENCH_GOLD)), reason="tests/golden/%s not generated" % BENCH_GOLD)
+def test_lp_compute_at_the_bench_objects_recorded_states(eng):
+    """The same table on the HEADLINE workload: the sixteen traced bench objects at the reference's recorded states, all ten iterations, inside
+    the resident 64-object batch running in the f16 mode (160 linearisations; with the 35 above: 195 of the 205 the fp32 path is held to --
+    the other ten are the 32-D decoder's and the complex one's, whose kernels test_lp_jacobian_other_decoders covers)."""
+    g = golden(BENCH_GOLD)
+    objs = synth.make_batch(int(g["all_it_V"].shape[0]), first_seed=int(g["first_seed"]), n_surface=int(g["n_surface"]), n_background=int(g["n_background"]))
+    cfg = json.loads(str(g["cfg_json"]))
+    prm = E.params_from_configs(cfg)
+    n_d = int(cfg["optimizer"]["num_depth_samples"]) if "num_depth_samples" in cfg["optimizer"] else 50
+    B = len(objs)
+    full = [int(i) for i in g["full_objects"]]
+    b = eng.batch(prm, [o["t_cam_obj_init"] for o in objs], [o["pts"] for o in objs], [o["rays"] for o in objs], [o["depth"] for o in objs], trace=True)
+    b.set_compute(L.COMPUTE_F16)
+    zero_codes = [np.zeros(64, np.float32)] * B
+    b.set_start_state(None, zero_codes, None)
+    b.set_iterations(1)
+    b.run()
+    base = b.trace(0)
+    mask = np.ones(71, bool)
+    mask[3:6] = False
+    rows = []
+    for e in range(10):
+        t_oc = [base["t_obj_cam"][i] for i in range(B)]
+        codes = [base["code"][i] for i in range(B)]
+        depths = [base["depths"][i][:n_d] for i in range(B)]
+        for i in full:
+            t_oc[i], codes[i], depths[i] = g["tr%d_it_t_obj_cam" % i][e], g["tr%d_it_code" % i][e], g["tr%d_it_depths" % i][e]
+        b.set_start_state(t_oc, codes, depths)
+        b.set_iterations(1)
+        b.run()
+        res = b.results()
+        tr = b.trace(0)
+        for i in full:
+            assert res[3][i] == 0
+            assert np.array_equal(tr["t_obj_cam"][i], g["tr%d_it_t_obj_cam" % i][e]) and np.array_equal(tr["code"][i], g["tr%d_it_code" % i][e])
+            k_ref = int(g["tr%d_it_K" % i][e])
+            rows.append(dict(case="bench object %d" % i, it=e, dV=int(tr["V"][i]) - int(g["tr%d_it_V" % i][e]), dK=int(tr["K"][i]) - k_ref, K=k_ref,
+                             rel_H=F.rel_max(tr["H"][i], g["tr%d_it_H" % i][e]), rel_b=F.rel_max(tr["b"][i][mask], g["tr%d_it_b" % i][e][mask]),
+                             rel_dx=F.rel_max(tr["dx"][i], g["tr%d_it_dx" % i][e]), rel_loss=F.loss_rel(res[2][i], g["tr%d_it_loss" % i][e])))
+    st = b.stats()
+    assert st["n_mlp_fwd_launches"] == 0 and st["n_mlp_prepass_launches"] > 0
+    b.close()
+    worst = {k: max(abs(r[k]) for r in rows) for k in ("dV", "dK", "rel_H", "rel_b", "rel_dx", "rel_loss")}
+    med = {k: float(np.median([abs(r[k]) for r in rows])) for k in ("rel_H", "rel_b", "rel_dx", "rel_loss")}
+    rel_dk = max(abs(r["dK"]) / max(r["K"], 1) for r in rows)
+    print("f16 compute at %d recorded states of the bench objects: |dV| <= %d, |dK| <= %d (%.4f of K), rel dH median %.2e max %.2e, rel db median %.2e max %.2e, "
+          "rel ddx median %.2e max %.2e, rel dloss median %.2e max %.2e" % (len(rows), worst["dV"], worst["dK"], rel_dk, med["rel_H"], worst["rel_H"],
+                                                                          med["rel_b"], worst["rel_b"], med["rel_dx"], worst["rel_dx"], med["rel_loss"], worst["rel_loss"]))
+    parity_log(kind="lp_compute_at_reference_states", case="f16 compute mode, 64 x cfg2 bench batch: 16 traced objects x 10 iterations inside the resident batch", n=len(rows),
+               rows=rows, worst=worst, median=med, worst_dK_over_K=rel_dk)
+    assert worst["dV"] == 0 and len(rows) == 160
+    assert rel_dk <= 0.05 and worst["rel_H"] <= 0.05 and worst["rel_loss"] <= 0.05, worst
 
 
 def test_lp_compute_chained_runs(eng):
