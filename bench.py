@@ -561,8 +561,21 @@ def main():
             one.results()
             lat.append((time.perf_counter() - t1) * 1e3)
             leg_add(one.stats())
-        one.close()
         result["latency_ms_p50"] = round(statistics.median(lat), 3)
+        if result.get("lp_compute") is not None:     # the same object in the opt-in low-precision compute mode (a non-parity figure: kept inside that block)
+            one.set_compute(1)
+            mark("latency_cfg2_object_lp_compute")
+            one.run()
+            lat = []
+            for _ in range(max(args.latency_runs, 1)):
+                t1 = time.perf_counter()
+                one.run()
+                one.results()
+                lat.append((time.perf_counter() - t1) * 1e3)
+            result["lp_compute"]["latency_cfg2_object_ms_p50"] = round(statistics.median(lat), 3)
+            result["lp_compute"]["latency_note"] = ("one cfg2 object, resident batch, p50 as latency_ms_p50; a detection of SLAM's real size keeps the fp32 latency path with the mode set "
+                                                    "(faster there: profiles/r06_latency_ab.md), so latency_kitti_size_ms_p50 is the same in both modes")
+        one.close()
         # a detection of the reference's real KITTI size (config_kitti.json:17 num_lidar_max 250, kitti_sequence.py:203-205 <= 200 background rays)
         k = synth.make_object(4242, n_surface=250, n_background=200)
         one = eng.batch(prm, [k["t_cam_obj_init"]], [k["pts"]], [k["rays"]], [k["depth"]])

@@ -24,7 +24,7 @@ PREPASS_SMALL_TILES = 0x100
 COMPUTE_F32, COMPUTE_F16, COMPUTE_BF16 = 0, 1, 2
 # keys of dsp_batch_set_debug (include/dsp_gn.h: DSP_DBG_*)
 (DBG_MASK_REUSE, DBG_SPLIT_ROWS, DBG_TAIL_SPLIT, DBG_WAVE_BOOKKEEPING, DBG_SPECULATIVE_BAND, DBG_MIXED_REUSE, DBG_CLUSTER_TILES, DBG_DIRECT_TILES,
- DBG_PREPASS_TILE, DBG_PREPASS_AUDIT, DBG_CLUSTER_FAULT) = range(1, 12)
+ DBG_PREPASS_TILE, DBG_PREPASS_AUDIT, DBG_CLUSTER_FAULT, DBG_LP_SMALL_BATCHES) = range(1, 13)
 ABI_VERSION = 6
 
 

@@ -134,6 +134,10 @@ class Batch(object):
     def set_prepass_audit(self, on=True):
         self.set_debug(L.DBG_PREPASS_AUDIT, int(bool(on)))
 
+    def set_lp_small_batches(self, mode):
+        """-1 / 0 = a detection-sized batch keeps the fp32 latency path when the low-precision compute mode is set (faster there), 1 = the mode applies to it too."""
+        self.set_debug(L.DBG_LP_SMALL_BATCHES, mode)
+
     def set_cluster_fault(self, on):
         """Fault injection: the following runs' cluster launches lose one workgroup's hand-off; False also ends the handle's cool-down."""
         self.set_debug(L.DBG_CLUSTER_FAULT, int(bool(on)))

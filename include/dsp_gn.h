@@ -260,7 +260,9 @@ int dsp_batch_set_kernel_timing(dsp_batch* b, int mode);
  * (mlp_lpj_kernel.hip); thresholds, scans, the Gram matrices and the fp64 solve are unchanged.  The precision class of the reference's own
  * published runs (PyTorch 1.10 on Ampere multiplied in TF32: 10-bit mantissas, as f16).  How far H, b and the results move:
  * profiles/r06_lp_compute.md, tests/test_gpu_lp_compute.py.  DSP_E_ARG for a decoder geometry other than DeepSDF's (eight hidden layers, the
- * latent_in layer fourth) and for pose-only batches. */
+ * latent_in layer fourth) and for pose-only batches.  A DETECTION-SIZED batch (<= 16 objects whose surface points + band samples fit one round of
+ * 16-point tiles over the CUs: SLAM's own per-detection calls) keeps the fp32 latency path with the mode set -- it is faster there (2.89 against
+ * 3.40 ms) and exact; one cfg2-size object: 14.0 -> 6.0 ms in the mode (profiles/r06_latency_ab.md). */
 int dsp_batch_set_compute(dsp_batch* b, int mode);
 /* The iteration count of the following runs (instead of dsp_gn_params.num_iterations / pose_only_iterations given at creation). */
 int dsp_batch_set_iterations(dsp_batch* b, int32_t n);
@@ -290,6 +292,7 @@ int dsp_prepass_reset_guard(dsp_handle* h);
 #define DSP_DBG_DIRECT_TILES 8      /* one-object batches: the decoder kernels derive their tile lists themselves */
 #define DSP_DBG_PREPASS_TILE 9      /* value = 128 or 64 points per prepass tile, -1 / 0 automatic */
 #define DSP_DBG_PREPASS_AUDIT 10    /* value != 0: every run also decodes all in-sphere samples in fp32 and fills dsp_stats.prepass_max_err / _misclassified / _audited */
+#define DSP_DBG_LP_SMALL_BATCHES 12 /* 1: the low-precision compute mode also on detection-sized batches (automatic: they keep the fp32 latency path, which is faster there) */
 #define DSP_DBG_CLUSTER_FAULT 11    /* value != 0: the following runs' cluster launches lose one workgroup's hand-off (the device-side fallback takes over); 0 also ends the cool-down */
 int dsp_batch_set_debug(dsp_batch* b, int key, int value);
 /* Forensics: front-to-back ranges with explicit depth-index boundaries: bounds[0] = 0 <= ... <= bounds[n_passes] = num_depth_samples. */

@@ -40,7 +40,8 @@ for name, (M, Bg) in (("KITTI-size 250+200", (250, 200)), ("cfg2-size 2000+500",
                 ("tile lists built by k_build_tiles (direct tiles off)", dict(direct_tiles=0)),
                 # (the per-object fused bookkeeping and the earlier solver kernels were measured in rounds 3-5 -- profiles/r04_latency_ab.md,
                 #  profiles/r05_latency_ab.md -- and left the library in round 6: profiles/r06_removed_experiments.md)
-                ("prepass off", dict(prepass=0))]
+                ("prepass off", dict(prepass=0)),
+                ("OPT-IN low-precision compute mode, f16 (NOT the parity path: bits differ by design)", dict(compute=1))]
     ref = None
     for label, kw in variants:
         b = eng.batch(prm, *args)
