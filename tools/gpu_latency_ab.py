@@ -41,7 +41,8 @@ for name, (M, Bg) in (("KITTI-size 250+200", (250, 200)), ("cfg2-size 2000+500",
                 # (the per-object fused bookkeeping and the earlier solver kernels were measured in rounds 3-5 -- profiles/r04_latency_ab.md,
                 #  profiles/r05_latency_ab.md -- and left the library in round 6: profiles/r06_removed_experiments.md)
                 ("prepass off", dict(prepass=0)),
-                ("OPT-IN low-precision compute mode, f16 (NOT the parity path: bits differ by design)", dict(compute=1))]
+                ("OPT-IN low-precision compute mode, f16 (NOT the parity path; a detection-sized batch keeps the fp32 path)", dict(compute=1)),
+                ("... pinned on for this batch whatever its size (DSP_DBG_LP_SMALL_BATCHES)", dict(compute=1, lp_small_batches=1))]
     ref = None
     for label, kw in variants:
         b = eng.batch(prm, *args)
