@@ -149,5 +149,10 @@ def test_reoptimise_map_sharded_equals_unsharded(tmp_path, mirror, oracle_decode
     for o, w in zip(back, ten):
         assert np.allclose(o["pose"][:3], np.asarray(w["pose"], np.float32)[:3], rtol=0, atol=1e-6 * max(1.0, float(np.abs(w["pose"]).max())))
         assert np.allclose(o["code"], w["code"], rtol=0, atol=2e-9 + 1e-7 * float(np.abs(w["code"]).max()))
+    # --compute f16: the opt-in low-precision mode on the same map (NOT the parity path): every observed object still good, poses close to the fp32 run's
+    _run_tool("reoptimise_map.py", ["--config", _config(tmp_path), "--map_dir", str(map_dir), "--gpus", "1", "--compute", "f16", "--out", str(map_dir / "MapObjects.f16.txt")])
+    lp = read_map_objects(str(map_dir / "MapObjects.f16.txt"))
+    d = [float(np.abs(np.asarray(a["pose"]) - np.asarray(w["pose"])).max() / np.abs(np.asarray(w["pose"])).max()) for a, w in zip(lp, back)]
+    assert max(d) < 5e-2, d
     parity_log(kind="reoptimise_map", case="9-object synthetic map, 8 observed", n_good=int(st1["n_good"]), seconds=float(st1["seconds"]),
-               sharded_equals_unsharded=True)
+               sharded_equals_unsharded=True, lp_pose_rel_max=max(d))

@@ -43,9 +43,10 @@ def load_observations(map_dir, objs):
     return out
 
 
-def reoptimise(engines, prm, objs, obs, code_len, shards=None):
+def reoptimise(engines, prm, objs, obs, code_len, shards=None, compute=0):
     """objs / obs as read; engines: one dsp_slam_amd.engine.Engine per GPU.  -> (objects with updated pose / code, stats dict).
-    shards: optional explicit (start, stop) blocks over the objects that have observations (default: cost-balanced over the engines)."""
+    shards: optional explicit (start, stop) blocks over the objects that have observations (default: cost-balanced over the engines).
+    compute: 0 = fp32 (the parity path), 1 / 2 = the opt-in f16 / bf16 compute mode (include/dsp_gn.h: dsp_batch_set_compute)."""
     from dsp_slam_amd import distributed as D
     idx = [i for i, ob in enumerate(obs) if ob is not None]
     t_in, codes_in = [], []
@@ -62,7 +63,7 @@ def reoptimise(engines, prm, objs, obs, code_len, shards=None):
         sel = idx[a:b]
         eng = engines[r % len(engines)]
         res = eng.reconstruct_batch(prm, t_in[a:b], [obs[i]["pts"] for i in sel], [obs[i]["rays"] for i in sel], [obs[i]["depth"] for i in sel],
-                                    codes_in[a:b])
+                                    codes_in[a:b], compute=compute)
         parts[r] = D.pack_results(*res)
 
     t0 = time.perf_counter()
@@ -92,6 +93,8 @@ def main():
     ap.add_argument("--map_dir", required=True)
     ap.add_argument("--gpus", type=int, default=0, help="0 = every MI355X the library accepts")
     ap.add_argument("--out", default=None, help="default: <map_dir>/MapObjects.reopt.txt")
+    ap.add_argument("--compute", choices=("f32", "f16", "bf16"), default="f32",
+                    help="f32 = the parity path (default); f16 / bf16 = the opt-in low-precision compute mode: ~3.7 x the objects/s on large maps, accuracy in profiles/r06_lp_compute.md")
     args = ap.parse_args()
     from reconstruct.utils import get_configs
     from deep_sdf.workspace import config_decoder
@@ -103,7 +106,7 @@ def main():
     n_dev = args.gpus or max(1, L.load().dsp_device_count())
     decoders = [config_decoder(cfg.DeepSDF_DIR).cuda(d) for d in range(n_dev)]        # one decoder (= one handle, one stream) per GPU
     prm = E.params_from_configs(cfg)
-    out, st = reoptimise([d.engine for d in decoders], prm, objs, obs, cfg.optimizer.code_len)
+    out, st = reoptimise([d.engine for d in decoders], prm, objs, obs, cfg.optimizer.code_len, compute={"f32": 0, "f16": 1, "bf16": 2}[args.compute])
     dst = args.out or os.path.join(args.map_dir, "MapObjects.reopt.txt")
     write_map_objects(dst, out)
     print("re-optimised %d of %d objects (%d with observations) on %d GPU(s) in %.3f s = %.1f objects/s -> %s" % (
