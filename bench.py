@@ -33,7 +33,7 @@ The JSON line also carries
                 tools/rocpd_legs.py can split a rocprofv3 kernel trace of the same command at the marker dispatches and compare each
                 population of a kernel with its own figure (profiles/rNN_kernel_stats.md);
   cpu_baseline  the reference itself (kind "reference") when DSP_REFERENCE_ROOT points at a DSP-SLAM checkout, else
-                oracle/torch_baseline.py (kind "torch-restatement": the reference's own torch op sequence written out, bit-identical
+                oracle/torch_baseline.py (kind "port", `port` = "torch-restatement": the reference's own torch op sequence written out, bit-identical
                 results; `calibrated_vs_reference` = its time / the unmodified reference's, measured in the build container,
                 profiles/cpu_baseline_calibration.json), timed on this box's host cores on one warm-up + THREE cfg2 objects (rank 0, N=1 only;
                 objects/s = 1 / mean, p50 alongside: BASELINE.md section 2) -- a reported baseline, not a target.
@@ -649,7 +649,7 @@ def main():
         torch.set_num_threads(best_threads)
         # one warm-up, then >= 3 objects (the bench's first three: seeds 1, 2, 3 on rank 0), objects/s = 1 / mean, p50 reported
         n_base = min(3, len(objs))
-        kind = "torch-restatement"
+        kind = "port"
         use_ref = args.config != "cfg5" and bool(os.environ.get("DSP_REFERENCE_ROOT"))      # never probed unless asked for: the GPU box has no checkout
         TB.reconstruct_object(tb_dec, O.GNParams(num_iterations=1), small["t_cam_obj_init"], small["pts"], small["rays"], small["depth"])     # warm-up at the chosen thread count
         times, times_tb, r = [], [], None
@@ -674,6 +674,7 @@ def main():
             "unit": "objects/s",
             "cores": int(best_threads),
             "kind": kind,
+            "port": None if kind == "reference" else "torch-restatement (oracle/torch_baseline.py: the reference's torch op sequence, bit-identical results, 1.016 x its time)",
             "n_objects": n_base,
             "s_per_object": [round(x, 3) for x in times],
             "s_per_object_p50": round(float(np.median(times)), 3),

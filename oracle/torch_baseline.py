@@ -15,7 +15,7 @@ reference's wall time on that host:
     torch.inverse of the 71 x 71 system (:186).
 
 tools/calibrate_cpu_baseline.py times it against the unmodified reference (oracle/ref_shim.py) in the build container and commits
-the ratio under profiles/; bench.py reports `kind: "torch-restatement"` with that ratio.  tests/test_torch_baseline.py checks that
+the ratio under profiles/; bench.py reports `kind: "port"` (`port: "torch-restatement ..."`) with that ratio.  tests/test_torch_baseline.py checks that
 its result agrees with the numpy oracle's (same algorithm, same fixture).
 """
 import math
