@@ -24,23 +24,17 @@ def _f32(a):
 
 class Optimizer(object):
     def __init__(self, decoder, configs):
+        # Attribute names are the reference's (optimizer.py:27-43): C++ reads `code_len` (LocalMapping_util.cc:413), scripts read the rest.
         self.decoder = decoder
         optim_cfg = configs.optimizer
-        self.k1 = optim_cfg.joint_optim.k1
-        self.k2 = optim_cfg.joint_optim.k2
-        self.k3 = optim_cfg.joint_optim.k3
-        self.k4 = optim_cfg.joint_optim.k4
-        self.b1 = optim_cfg.joint_optim.b1
-        self.b2 = optim_cfg.joint_optim.b2
-        self.lr = optim_cfg.joint_optim.learning_rate
-        self.s_damp = optim_cfg.joint_optim.scale_damping
-        self.num_iterations_joint_optim = optim_cfg.joint_optim.num_iterations
-        self.code_len = optim_cfg.code_len
-        self.num_depth_samples = optim_cfg.num_depth_samples
-        self.cut_off = optim_cfg.cut_off_threshold
-        self.num_iterations_pose_only = 5
-        if configs.data_type == "KITTI":
-            self.num_iterations_pose_only = optim_cfg.pose_only_optim.num_iterations
+        joint = optim_cfg.joint_optim
+        for attr, key in (("k1", "k1"), ("k2", "k2"), ("k3", "k3"), ("k4", "k4"), ("b1", "b1"), ("b2", "b2"), ("lr", "learning_rate"),
+                          ("s_damp", "scale_damping"), ("num_iterations_joint_optim", "num_iterations")):
+            setattr(self, attr, joint[key])            # KeyError on a missing key, as attribute access on the reference's config dict (utils.py:82-84)
+        for attr, key in (("code_len", "code_len"), ("num_depth_samples", "num_depth_samples"), ("cut_off", "cut_off_threshold")):
+            setattr(self, attr, optim_cfg[key])
+        # only the KITTI configuration carries a pose-only block; elsewhere the reference hard-codes five iterations (:41-43)
+        self.num_iterations_pose_only = optim_cfg.pose_only_optim.num_iterations if configs.data_type == "KITTI" else 5
         if self.code_len not in (32, _L.CODE_LEN):      # the two code lengths the reference's C++ casts (LocalMapping_util.cc:413-423)
             raise NotImplementedError("the MI355X decoder kernels are built for 64-D and 32-D codes (got %d)" % self.code_len)
         if decoder is not None and self.code_len != getattr(decoder, "latent_size", self.code_len):
@@ -68,13 +62,9 @@ class Optimizer(object):
                                                        [_f32(p) for p in pts_list], [_f32(c) for c in codes])
 
     def estimate_pose_cam_obj(self, t_co_se3, scale, pts, code):
-        """
-        :param t_co_se3: o2c transformation (4, 4) in SE(3)
-        :param scale: object scale
-        :param pts: surface points (M, 3)
-        :param code: shape code
-        :return: optimized o2c transformation (torch.Tensor (4,4), as the reference returns)
-        """
+        """Pose-only refinement of one detection (reference optimizer.py:45-86; called from LocalMapping_util.cc:109-110).
+        t_co_se3: (4, 4) rigid object-to-camera guess; scale: the object's scale (float); pts: (M, 3) surface points in the camera frame;
+        code: the object's shape code.  Returns the refined rigid object-to-camera matrix as a (4, 4) CPU torch.Tensor, like the reference."""
         out = self.estimate_poses_cam_obj([t_co_se3], [float(scale)], [pts], [code])
         return torch.from_numpy(out[0].copy())
 
@@ -98,13 +88,11 @@ class Optimizer(object):
         return out
 
     def reconstruct_object(self, t_cam_obj, pts, rays, depth, code=None):
-        """
-        :param t_cam_obj: object pose, object-to-camera transformation
-        :param pts: surface points, under camera coordinate (M, 3)
-        :param rays: sampled ray directions (N, 3)
-        :param depth: depth values (K,) only contain foreground pixels, K = M for KITTI
-        :return: optimized opject pose and shape, saved as a dict
-        """
+        """Joint shape + pose optimisation of one object (reference optimizer.py:88-203; LocalMapping_util.cc:179-180,391-392,402-403).
+        t_cam_obj: (4, 4) Sim(3) object-to-camera start; pts: (M, 3) surface points in the camera frame; rays: (R, 3) ray directions, the
+        first len(depth) of them foreground; depth: observed depth of the foreground rays (KITTI: one per surface point); code: optional
+        start code (zeros when None).  Returns the reference's result dict: t_cam_obj, code, is_good, loss -- attribute access, KeyError on
+        anything else."""
         start = get_time()
         rst = self.reconstruct_objects([t_cam_obj], [pts], [rays], [depth], None if code is None else [code])[0]
         if self.verbose and rst.is_good:
