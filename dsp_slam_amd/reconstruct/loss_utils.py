@@ -18,10 +18,11 @@ def _np(x):
 
 
 def get_rays(sampled_pixels, invK):
-    """reference loss_utils.py:23-37."""
-    n = sampled_pixels.shape[0]
-    u_hom = np.concatenate([sampled_pixels, np.ones((n, 1))], axis=-1)
-    return (u_hom[:, None, :] * invK).sum(-1).astype(np.float32)
+    """Pixel coordinates (N, 2) as [u, v] and the inverse intrinsics (3, 3) -> ray directions (N, 3) in the camera frame, float32
+    (reference loss_utils.py:23-37: invK @ [u, v, 1] in float64, terms added left to right, rounded once)."""
+    px = np.asarray(sampled_pixels, dtype=np.result_type(np.asarray(sampled_pixels).dtype, np.float64))
+    k = np.asarray(invK)
+    return ((px[:, 0:1] * k[:, 0] + px[:, 1:2] * k[:, 1]) + k[:, 2]).astype(np.float32)
 
 
 def sdf_to_occupancy(sdf_tensor, th=0.015):
