@@ -132,6 +132,7 @@ def main():
     if world > 1 or os.environ.get("DSP_BENCH_FORCE_DIST") == "1":   # the env switch exercises the RCCL path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # this pool's host driver only supports dmabuf IPC (RCCL needs it across processes)
         os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
