@@ -263,33 +263,28 @@ __global__ __launch_bounds__(256) void k_scan_rays(const ObjConst* oc, ObjState*
     scan_rays_block<256>(c, st, b, cnt, off, which, part);
 }
 
-__device__ __forceinline__ void sample_write_ray(const ObjConst& c, const ObjState& s, const float* rays, const unsigned long long* raymask,
-                                                 const int* rayoff, float4* spts, float* ssdf, unsigned char* alive, int n_depth, int r) {
-    if (s.status != DSP_STATUS_GOOD) return;
-    unsigned long long mask = raymask[c.ray_off + r];
-    const float* d3 = rays + 3 * (size_t)(c.ray_off + r);
-    const float dx = d3[0], dy = d3[1], dz = d3[2];
-    alive[c.ray_off + r] = mask ? 1 : 0;
-    float4* dst = spts + c.samp_off + rayoff[c.ray_off + r];
-    float* sd = ssdf + c.samp_off + rayoff[c.ray_off + r];
-    while (mask) {
-        const int j = __ffsll((long long)mask) - 1;
-        mask &= mask - 1;
-        const float d = s.depths[j];
-        const float3 p = xform(s.t_oc, __fmul_rn(dx, d), __fmul_rn(dy, d), __fmul_rn(dz, d));
-        *dst++ = make_float4(p.x, p.y, p.z, __int_as_float((r << 6) | j));
-        *sd++ = 1.0f;   // "not evaluated": free space (o = 0).  Only samples BEHIND a solid one stay unevaluated, where the
-                        // transmittance is exactly 0, so the value cannot reach d_u, de_do, H or b (see k_pass_update).
-    }
-}
-
-__global__ void k_sample_write(const ObjConst* oc, const ObjState* st, const float* rays, const unsigned long long* raymask,
-                               const int* rayoff, float4* spts, float* ssdf, unsigned char* alive, int n_depth) {
+// One WAVE per ray, one lane per depth index: a ray's in-sphere samples are contiguous in the compact list, so the wave's stores coalesce
+// (one thread per ray wrote 16 bytes at a stride of the ray's length: 149 us per iteration on the bench batch; this form: see
+// profiles/r06_bookkeeping.md).  Per sample the same arithmetic as before: p_o = T_oc (dir * d) with the products rounded first.
+__global__ __launch_bounds__(256) void k_sample_write(const ObjConst* oc, const ObjState* st, const float* rays, const unsigned long long* raymask,
+                                                      const int* rayoff, float4* spts, float* ssdf, unsigned char* alive, int n_depth) {
     const int b = blockIdx.y;
     const ObjConst c = oc[b];
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
     if (r >= c.n_rays) return;
-    sample_write_ray(c, st[b], rays, raymask, rayoff, spts, ssdf, alive, n_depth, r);
+    const ObjState& s = st[b];
+    if (s.status != DSP_STATUS_GOOD) return;
+    const int j = threadIdx.x & 63;
+    const unsigned long long mask = raymask[c.ray_off + r];
+    if (j == 0) alive[c.ray_off + r] = mask ? 1 : 0;
+    if (!((mask >> j) & 1ull)) return;
+    const float* d3 = rays + 3 * (size_t)(c.ray_off + r);
+    const float d = s.depths[j];
+    const float3 p = xform(s.t_oc, __fmul_rn(d3[0], d), __fmul_rn(d3[1], d), __fmul_rn(d3[2], d));
+    const size_t o = (size_t)c.samp_off + rayoff[c.ray_off + r] + __popcll(mask & ((1ull << j) - 1ull));
+    spts[o] = make_float4(p.x, p.y, p.z, __int_as_float((r << 6) | j));
+    ssdf[o] = 1.0f;     // "not evaluated": free space (o = 0).  Only samples BEHIND a solid one stay unevaluated, where the
+                        // transmittance is exactly 0, so the value cannot reach d_u, de_do, H or b (see k_pass_update).
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -821,7 +816,7 @@ __global__ __launch_bounds__(WAVE_THREADS) void k_front_wave(const ObjConst* oc,
     if (in) {
         const int k = __popcll(mask & lanes_below(lane));
         spts[c.samp_off + off + k] = make_float4(p.x, p.y, p.z, __int_as_float((r << 6) | lane));
-        ssdf[c.samp_off + off + k] = 1.0f;       // "not evaluated": free space (see sample_write_ray)
+        ssdf[c.samp_off + off + k] = 1.0f;       // "not evaluated": free space (see k_sample_write)
     }
 }
 
@@ -1654,7 +1649,7 @@ void launch_scan_rays(const ObjConst* oc, ObjState* st, const int* cnt, int* off
 }
 void launch_sample_write(const ObjConst* oc, const ObjState* st, const float* rays, const unsigned long long* m, const int* off, float4* spts,
                          float* ssdf, unsigned char* alive, int D, int maxR, int B, hipStream_t s) {
-    hipLaunchKernelGGL(k_sample_write, GRID2(maxR, B), dim3(256), 0, s, oc, st, rays, m, off, spts, ssdf, alive, D);
+    hipLaunchKernelGGL(k_sample_write, dim3((unsigned)std::max(1, (maxR + 3) / 4), (unsigned)B), dim3(256), 0, s, oc, st, rays, m, off, spts, ssdf, alive, D);
 }
 void launch_pass_select(const ObjConst* oc, ObjState* st, const unsigned long long* raymask, const int* rayoff, const unsigned char* alive,
                         int* pcnt, const PassSpec& ps, int maxR, int B, hipStream_t s) {
