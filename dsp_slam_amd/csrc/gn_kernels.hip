@@ -264,8 +264,8 @@ __global__ __launch_bounds__(256) void k_scan_rays(const ObjConst* oc, ObjState*
 }
 
 // One WAVE per ray, one lane per depth index: a ray's in-sphere samples are contiguous in the compact list, so the wave's stores coalesce
-// (one thread per ray wrote 16 bytes at a stride of the ray's length: 149 us per iteration on the bench batch; this form: see
-// profiles/r06_bookkeeping.md).  Per sample the same arithmetic as before: p_o = T_oc (dir * d) with the products rounded first.
+// (one thread per ray wrote 16 bytes at a stride of the ray's length: 149 us per iteration on the bench batch; this form ~40: the step's
+// `other` 10.8 -> 9.8 ms, profiles/r06_kernel_stats.md).  Per sample the same arithmetic as before: p_o = T_oc (dir * d) with the products rounded first.
 __global__ __launch_bounds__(256) void k_sample_write(const ObjConst* oc, const ObjState* st, const float* rays, const unsigned long long* raymask,
                                                       const int* rayoff, float4* spts, float* ssdf, unsigned char* alive, int n_depth) {
     const int b = blockIdx.y;
@@ -695,43 +695,29 @@ __global__ __launch_bounds__(256) void k_render_scan(const ObjConst* oc, ObjStat
     }
 }
 
-__device__ __forceinline__ void render_write_ray(const ObjConst& c, const ObjState& s, const int* raycnt, const int* rayoff, const int* koff,
-                                                 const float4* spts, const float* sdeds, const float* ray_res, float4* jpts, float2* jaux, int r,
-                                                 const int* srow = nullptr, int* jrow = nullptr) {
-    if (s.status != DSP_STATUS_GOOD) return;
-    const int gr = c.ray_off + r;
-    const int n = raycnt[gr];
-    const int base = c.samp_off + rayoff[gr];
-    const int dst0 = c.jren_off + koff[gr];
-    const float res = ray_res[gr];
-    // kept samples of the ray = those with de_ds != 0: found with independent loads (no pointer chasing along the ray), then the
-    // few kept ones (typically 2-4 of 50) are written
-    unsigned long long kept = 0ull;
-#pragma unroll
-    for (int k = 0; k < 64; ++k) {
-        const float dv = sdeds[k < n ? base + k : c.samp_off];
-        if (k < n && dv != 0.f) kept |= 1ull << k;
-    }
-    int dst = dst0;
-    while (kept) {
-        const int k = __ffsll((long long)kept) - 1;
-        kept &= kept - 1;
-        float4 p = spts[base + k];
-        p.w = __int_as_float(base + k);   // compact sample index: where the forward launch left this sample's sdf and relu masks
-        jpts[dst] = p;
-        jaux[dst] = make_float2(sdeds[base + k], res);
-        if (jrow) jrow[dst] = srow[base + k];     // speculative band rows: this row's gradient already sits in jgrad row srow[sample]
-        ++dst;
-    }
-}
-
+// Row compaction: the kept samples of a ray (those with de_ds != 0: typically 2-4 of its <= 50) become jacobian rows, in depth order behind
+// the rows of the rays in front (koff).  One WAVE per ray, lane = position in the ray's compact sample run: one coalesced load finds the kept
+// ones, a ballot places them.
 __global__ __launch_bounds__(256) void k_render_write(const ObjConst* oc, const ObjState* st, const int* raycnt, const int* rayoff, const int* koff,
                                const float4* spts, const float* sdeds, const float* ray_res, float4* jpts, float2* jaux) {
     const int b = blockIdx.y;
     const ObjConst c = oc[b];
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
     if (r >= c.n_rays) return;
-    render_write_ray(c, st[b], raycnt, rayoff, koff, spts, sdeds, ray_res, jpts, jaux, r);
+    if (st[b].status != DSP_STATUS_GOOD) return;
+    const int k = threadIdx.x & 63;
+    const int gr = c.ray_off + r;
+    const int n = raycnt[gr];
+    const int base = c.samp_off + rayoff[gr];
+    const float dv = k < n ? sdeds[base + k] : 0.f;
+    const bool kept = k < n && dv != 0.f;
+    const unsigned long long keptm = __ballot(kept);
+    if (!kept) return;
+    const int dst = c.jren_off + koff[gr] + __popcll(keptm & ((1ull << k) - 1ull));
+    float4 p = spts[base + k];
+    p.w = __int_as_float(base + k);   // compact sample index: where the forward launch left this sample's sdf and relu masks
+    jpts[dst] = p;
+    jaux[dst] = make_float2(dv, ray_res[gr]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1710,7 +1696,8 @@ void launch_render_scan(const ObjConst* oc, ObjState* st, const unsigned long lo
 }
 void launch_render_write(const ObjConst* oc, const ObjState* st, const int* raycnt, const int* rayoff, const int* koff, const float4* spts,
                          const float* sdeds, const float* ray_res, float4* jpts, float2* jaux, int maxR, int B, hipStream_t s) {
-    hipLaunchKernelGGL(k_render_write, GRID2(maxR, B), dim3(256), 0, s, oc, st, raycnt, rayoff, koff, spts, sdeds, ray_res, jpts, jaux);
+    hipLaunchKernelGGL(k_render_write, dim3((unsigned)std::max(1, (maxR + 3) / 4), (unsigned)B), dim3(256), 0, s, oc, st, raycnt, rayoff, koff, spts, sdeds, ray_res,
+                       jpts, jaux);     // one wave per ray
 }
 void launch_sum_m(const ObjConst* oc, ObjState* st, const int* mcnt, int B, hipStream_t s) {
     hipLaunchKernelGGL(k_sum_m, dim3(B), dim3(256), 0, s, oc, st, mcnt);
